@@ -1,0 +1,161 @@
+/*
+ * kofft_hip.h -- C ABI of the MI355X (gfx950) implementation of kofft's hot path:
+ * batched power-of-two complex FFT, real-FFT post-pass, windowed STFT.
+ *
+ * This is the drop-in boundary.  Each entry point names the reference interface
+ * (okian/kofft v0.1.5, file:line) it stands in for; a Rust shim implementing
+ * kofft's `FftImpl<T>` trait (fft.rs:466-587) binds exactly these symbols --
+ * see INTEGRATION.md for the shim and for the C++/Python host mirrors.
+ *
+ * Conventions
+ *   - Complex data is interleaved {re, im}: kofft's #[repr(C)] Complex<T>
+ *     (num.rs:105-110; tests/complex_repr.rs proves [T;2] compatibility), so a
+ *     `&mut [Complex32]` passes as `float*` with 2*len floats.
+ *   - Plain pointers and sizes only.  No torch / HIP types in any signature; a
+ *     HIP stream crosses as `void*`.
+ *   - Return value: 0 = Ok; 1..6 = kofft's FftError variants in declaration order
+ *     (fft.rs:447-454); negative = runtime failure that FftError cannot express
+ *     (the shim maps those to a panic).
+ *   - `*_dev` entry points take DEVICE pointers, enqueue on the context's stream and
+ *     return without synchronising.  The un-suffixed twins take HOST pointers, stage
+ *     through device memory and return after the result is back in the host buffer.
+ *   - A context is cheap, owns its twiddle-table cache (the role of FftPlanner,
+ *     fft.rs:332-408) and is NOT thread-safe: one context per thread, exactly like
+ *     ScalarFftImpl (Send + !Sync, fft.rs:589-605).
+ *   - Arithmetic: every butterfly performs the reference's un-fused operations with
+ *     the reference's recurrence-generated twiddle tables (generated on the host with
+ *     the reference's recipe and uploaded; no device-side trigonometry).
+ *   - Lengths: n = 1 and every power of two.  Non-power-of-two lengths (the
+ *     reference's Bluestein arm, fft.rs:1088-1132) return KOFFT_ERR_UNSUPPORTED.
+ */
+#ifndef KOFFT_HIP_H
+#define KOFFT_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ---------------------------------------------------------- */
+#define KOFFT_OK 0
+/* FftError (fft.rs:447-454), discriminant + 1 */
+#define KOFFT_ERR_EMPTY_INPUT 1
+#define KOFFT_ERR_NON_POWER_OF_TWO_NO_STD 2
+#define KOFFT_ERR_MISMATCHED_LENGTHS 3
+#define KOFFT_ERR_INVALID_STRIDE 4
+#define KOFFT_ERR_INVALID_HOP_SIZE 5
+#define KOFFT_ERR_INVALID_VALUE 6
+/* outside FftError */
+#define KOFFT_ERR_HIP (-1)         /* a HIP runtime call failed; see kofft_hip_last_error */
+#define KOFFT_ERR_UNSUPPORTED (-2) /* length not supported by the device path */
+#define KOFFT_ERR_NULL (-3)        /* null context / pointer */
+#define KOFFT_ERR_ALLOC (-4)       /* host or device allocation failed */
+
+typedef struct kofft_hip_ctx kofft_hip_ctx;
+
+/* Human-readable name of a status code (static string). */
+const char *kofft_hip_strerror(int status);
+/* Text of the last HIP failure seen by this context ("" if none). */
+const char *kofft_hip_last_error(const kofft_hip_ctx *ctx);
+/* Library version string, e.g. "kofft-hip 0.1.0 (gfx950)". */
+const char *kofft_hip_version(void);
+
+/* ---- context: stands in for ScalarFftImpl::<T>::default() + its FftPlanner ----
+ * (fft.rs:600-613, 332-366).  `device` is the HIP device ordinal. */
+int kofft_hip_device_count(int *count);
+int kofft_hip_create(int device, kofft_hip_ctx **out);
+int kofft_hip_destroy(kofft_hip_ctx *ctx);
+/* Use a caller-owned hipStream_t (passed as void*) for all *_dev work; NULL restores
+ * the context's own stream. */
+int kofft_hip_set_stream(kofft_hip_ctx *ctx, void *hip_stream);
+int kofft_hip_synchronize(kofft_hip_ctx *ctx);
+
+/* ---- tables: the planner recipes, on the host --------------------------------
+ * kofft_hip_twiddles_*: FftPlanner::get_twiddles(n) (fft.rs:370-408), n/2 complex.
+ * kofft_hip_rfft_table_*: build_twiddle_table(m) (rfft.rs:172-183), m complex.
+ * kofft_hip_hann_f32: window::hann(len) (window.rs:24-28). */
+int kofft_hip_twiddles_f32(size_t n, float *out);
+int kofft_hip_twiddles_f64(size_t n, double *out);
+int kofft_hip_rfft_table_f32(size_t m, float *out);
+int kofft_hip_rfft_table_f64(size_t m, double *out);
+int kofft_hip_hann_f32(size_t len, float *out);
+
+/* ---- complex FFT --------------------------------------------------------------
+ * FftImpl::fft / FftImpl::ifft (fft.rs:467-468; ScalarFftImpl fft.rs:1054-1082,
+ * 1134-1174) applied in place to `batch` contiguous transforms of length n:
+ * fft::batch / batch_inverse (fft.rs:2156-2175) over a contiguous layout.
+ * data: batch*n complex.  inverse != 0 selects ifft (conj, fft, conj, *1/n).
+ * batch == 0 -> KOFFT_OK (batch() over an empty slice); otherwise n == 0 ->
+ * KOFFT_ERR_EMPTY_INPUT; n == 1 is a no-op for both directions. */
+int kofft_hip_fft_c32(kofft_hip_ctx *ctx, float *data, size_t n, size_t batch, int inverse);
+int kofft_hip_fft_c64(kofft_hip_ctx *ctx, double *data, size_t n, size_t batch, int inverse);
+int kofft_hip_fft_c32_dev(kofft_hip_ctx *ctx, float *d_data, size_t n, size_t batch, int inverse);
+int kofft_hip_fft_c64_dev(kofft_hip_ctx *ctx, double *d_data, size_t n, size_t batch, int inverse);
+/* FftImpl::fft_out_of_place / ifft_out_of_place (fft.rs:469-490), device pointers.
+ * d_in and d_out must not partially overlap (d_in == d_out is allowed). */
+int kofft_hip_fft_c32_dev_oop(kofft_hip_ctx *ctx, const float *d_in, float *d_out, size_t n,
+                              size_t batch, int inverse);
+int kofft_hip_fft_c64_dev_oop(kofft_hip_ctx *ctx, const double *d_in, double *d_out, size_t n,
+                              size_t batch, int inverse);
+
+/* FftImpl::fft_strided / ifft_strided (fft.rs:1175-1199, 1236-1260), host pointers:
+ * gathers n = scratch_len elements data[i*stride], transforms, scatters back.
+ * stride == 0 -> KOFFT_ERR_INVALID_STRIDE; n == 0 -> KOFFT_OK;
+ * data_len < (n-1)*stride+1 -> KOFFT_ERR_MISMATCHED_LENGTHS. */
+int kofft_hip_fft_c32_strided(kofft_hip_ctx *ctx, float *data, size_t data_len, size_t stride,
+                              size_t n, int inverse);
+int kofft_hip_fft_c64_strided(kofft_hip_ctx *ctx, double *data, size_t data_len, size_t stride,
+                              size_t n, int inverse);
+
+/* ---- real FFT -----------------------------------------------------------------
+ * RfftPlanner::rfft_with_scratch -> rfft_direct (rfft.rs:264-282, 425-465) on `batch`
+ * contiguous rows of n reals; out: batch * (n/2+1) complex.  `window` (n reals or
+ * NULL) is multiplied into each row first -- the framing product of stft.rs:96.
+ * n == 0 -> EMPTY_INPUT; odd n -> INVALID_VALUE.  The reference's scratch argument
+ * has no counterpart: the post-pass runs out of LDS.
+ * irfft: RfftPlanner::irfft_with_scratch -> irfft_direct (rfft.rs:302-320, 468-508);
+ * in: batch * (n/2+1) complex, out: batch * n reals. */
+int kofft_hip_rfft_f32(kofft_hip_ctx *ctx, const float *in, float *out, const float *window,
+                       size_t n, size_t batch);
+int kofft_hip_rfft_f32_dev(kofft_hip_ctx *ctx, const float *d_in, float *d_out,
+                           const float *d_window, size_t n, size_t batch);
+int kofft_hip_irfft_f32(kofft_hip_ctx *ctx, const float *in, float *out, size_t n, size_t batch);
+int kofft_hip_irfft_f32_dev(kofft_hip_ctx *ctx, const float *d_in, float *d_out, size_t n,
+                            size_t batch);
+int kofft_hip_rfft_f64(kofft_hip_ctx *ctx, const double *in, double *out, const double *window,
+                       size_t n, size_t batch);
+int kofft_hip_rfft_f64_dev(kofft_hip_ctx *ctx, const double *d_in, double *d_out,
+                           const double *d_window, size_t n, size_t batch);
+int kofft_hip_irfft_f64(kofft_hip_ctx *ctx, const double *in, double *out, size_t n, size_t batch);
+int kofft_hip_irfft_f64_dev(kofft_hip_ctx *ctx, const double *d_in, double *d_out, size_t n,
+                            size_t batch);
+
+/* ---- STFT ---------------------------------------------------------------------
+ * stft::stft (stft.rs:76-105): out = frames * win_len complex, contiguous (the
+ * reference's &mut [Vec<Complex32>] flattened).  hop == 0 -> INVALID_HOP_SIZE;
+ * frames < ceil(len/hop) -> MISMATCHED_LENGTHS; every provided frame is computed,
+ * zero-padded past the end of the signal; win_len == 0 with frames > 0 -> EMPTY_INPUT.
+ * The _dev form computes frames [first_frame, first_frame+count) of the same STFT
+ * into d_out[0 .. count*win_len) -- the unit one rank owns when frames are sharded
+ * across GPUs; it performs stft::parallel's checks only (stft.rs:232-263: hop != 0).
+ */
+int kofft_hip_stft_f32(kofft_hip_ctx *ctx, const float *signal, size_t len, const float *window,
+                       size_t win_len, size_t hop, float *out, size_t frames);
+/* stft::parallel (stft.rs:232-263): identical frames, but the only check is hop != 0 --
+ * it does not require frames >= ceil(len/hop). */
+int kofft_hip_stft_parallel_f32(kofft_hip_ctx *ctx, const float *signal, size_t len,
+                                const float *window, size_t win_len, size_t hop, float *out,
+                                size_t frames);
+/* stft::frame (stft.rs:355-372) and StftStream::next_frame (stft.rs:186-205): the one frame
+ * that starts at sample `start` (zero-padded past the end); frame_out: win_len complex. */
+int kofft_hip_stft_frame_f32(kofft_hip_ctx *ctx, const float *signal, size_t len,
+                             const float *window, size_t win_len, size_t start, float *frame_out);
+int kofft_hip_stft_f32_dev(kofft_hip_ctx *ctx, const float *d_signal, size_t len,
+                           const float *d_window, size_t win_len, size_t hop, float *d_out,
+                           size_t first_frame, size_t count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KOFFT_HIP_H */

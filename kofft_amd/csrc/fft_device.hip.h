@@ -1,0 +1,201 @@
+// fft_device.hip.h -- device-side building blocks shared by every kernel of the hot path.
+//
+// The arithmetic contract (what makes results identical to kofft's ScalarFftImpl):
+//   * every radix-2 butterfly is  t = o * w  (4 mul, 1 sub, 1 add, un-fused),
+//     out0 = e + t, out1 = e - t            -- fft.rs:881-893 (f32) / 1020-1032 (f64)
+//   * w is looked up from the reference-recipe table T_n (uploaded from the host),
+//     entry k*n2 for group k of a stage with half-span n2 -- fft.rs:839
+//   * lengths 2,4,8,16 use the straight-line kernels of fft_kernels.rs with their
+//     f32-literal constants.
+// The translation unit is compiled with -ffp-contract=off so no FMA is formed.
+//
+// Stage/bit bookkeeping used throughout (derived from fft.rs:834-898):
+//   stage s (s = 0..L-1, n2 = 2^(L-1-s)) reads  src[(2k+b)*n2 + j]  and writes
+//   dst[(k + b'*2^s)*n2 + j]:  in index bits, [k : s bits][b][j] -> [b'][k][j].
+//   A register pass that runs stages S0..S0+Q-1 therefore needs, per (k, j), the 2^Q
+//   elements  i = k*2^(L-S0) + c*2^(L-S0-Q) + j  (c = 0..2^Q-1) and produces
+//   o = rev_Q(c')*2^(L-Q) + (k*2^(L-S0-Q) + j), where c' is the in-place register index.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace kofft {
+
+template <typename T>
+struct alignas(2 * sizeof(T)) cpx {
+    T re, im;
+};
+
+template <typename T>
+__device__ __forceinline__ cpx<T> mk(T re, T im)
+{
+    cpx<T> c;
+    c.re = re;
+    c.im = im;
+    return c;
+}
+
+// num.rs:127-141, 161-166 (non-FMA arm)
+template <typename T>
+__device__ __forceinline__ cpx<T> cadd(cpx<T> a, cpx<T> b) { return mk<T>(a.re + b.re, a.im + b.im); }
+template <typename T>
+__device__ __forceinline__ cpx<T> csub(cpx<T> a, cpx<T> b) { return mk<T>(a.re - b.re, a.im - b.im); }
+template <typename T>
+__device__ __forceinline__ cpx<T> cmul(cpx<T> a, cpx<T> b)
+{
+    return mk<T>(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re);
+}
+
+// One Stockham butterfly, in place on (e, o).  fft.rs:881-893.
+template <typename T>
+__device__ __forceinline__ void bfly(cpx<T> &e, cpx<T> &o, const cpx<T> w)
+{
+    const T t_re = o.re * w.re - o.im * w.im;
+    const T t_im = o.re * w.im + o.im * w.re;
+    const T e_re = e.re, e_im = e.im;
+    e.re = e_re + t_re;
+    e.im = e_im + t_im;
+    o.re = e_re - t_re;
+    o.im = e_im - t_im;
+}
+
+__host__ __device__ constexpr int bitrev(int x, int bits)
+{
+    int r = 0;
+    for (int i = 0; i < bits; ++i) r |= ((x >> i) & 1) << (bits - 1 - i);
+    return r;
+}
+
+// Q Stockham stages (global stages S0 .. S0+Q-1 of a 2^L-point transform) on the 2^Q
+// registers v[], for group index k (the S0-bit frequency prefix built so far).
+// Register index bit (Q-1-t) is the bit consumed (and replaced by b') at local stage t.
+// Twiddle for local stage t, prefix bits h (register bits Q-1..Q-t):
+//   kk = k + 2^S0 * rev_t(h),  index = kk * 2^(L-1-S0-t).
+template <typename T, int L, int S0, int Q>
+__device__ __forceinline__ void reg_pass(cpx<T> *v, const int k, const cpx<T> *__restrict__ tw)
+{
+#pragma unroll
+    for (int t = 0; t < Q; ++t) {
+        const int pos = Q - 1 - t;
+#pragma unroll
+        for (int h = 0; h < (1 << t); ++h) {
+            const int idx = (k << (L - 1 - S0 - t)) + (bitrev(h, t) << (L - 1 - t));
+            const cpx<T> w = tw[idx];
+#pragma unroll
+            for (int lo = 0; lo < (1 << pos); ++lo) {
+                const int c = (h << (pos + 1)) | lo;
+                bfly(v[c], v[c | (1 << pos)], w);
+            }
+        }
+    }
+}
+
+// ---- straight-line kernels for n = 2, 4, 8, 16 (fft_kernels.rs) -----------------
+
+// fft_kernels.rs:4-10
+template <typename T>
+__device__ __forceinline__ void small_fft2(cpx<T> *x)
+{
+    const cpx<T> a = x[0], b = x[1];
+    x[0] = cadd(a, b);
+    x[1] = csub(a, b);
+}
+
+// fft_kernels.rs:13-29 ; the (0,-1) factor goes through the general complex multiply.
+template <typename T>
+__device__ __forceinline__ void small_fft4(cpx<T> *x)
+{
+    const cpx<T> mi = mk<T>(T(0), -T(1));
+    const cpx<T> s02 = cadd(x[0], x[2]), d02 = csub(x[0], x[2]);
+    const cpx<T> s13 = cadd(x[1], x[3]), d13 = csub(x[1], x[3]);
+    const cpx<T> r = cmul(d13, mi);
+    x[0] = cadd(s02, s13);
+    x[2] = csub(s02, s13);
+    x[1] = cadd(d02, r);
+    x[3] = csub(d02, r);
+}
+
+// The 4-point sub-transform used inside fft8/fft16: inputs p0..p3, outputs q0..q3 with
+// q0 = (p0+p2)+(p1+p3), q2 = (p0+p2)-(p1+p3), q1 = (p0-p2)+(p1-p3)*(0,-1), q3 = ... - ...
+template <typename T>
+__device__ __forceinline__ void quad(const cpx<T> p0, const cpx<T> p1, const cpx<T> p2, const cpx<T> p3,
+                                     cpx<T> &q0, cpx<T> &q1, cpx<T> &q2, cpx<T> &q3)
+{
+    const cpx<T> mi = mk<T>(T(0), -T(1));
+    const cpx<T> a0 = cadd(p0, p2), a1 = csub(p0, p2);
+    const cpx<T> a2 = cadd(p1, p3), a3 = csub(p1, p3);
+    const cpx<T> r = cmul(a3, mi);
+    q0 = cadd(a0, a2);
+    q2 = csub(a0, a2);
+    q1 = cadd(a1, r);
+    q3 = csub(a1, r);
+}
+
+// 8-point combine used by fft8 and by each half of fft16: e[0..3] from the even comb,
+// o[0..3] from the odd comb; o1*(s,-s), o2*(0,-1), o3*(-s,-s); y[i] = e+o', y[i+4] = e-o'.
+// fft_kernels.rs:69-85 and 133-144 / 167-178 (s = 0.70710677 as an f32 literal).
+template <typename T>
+__device__ __forceinline__ void oct_combine(const cpx<T> *e, const cpx<T> *o, cpx<T> *y)
+{
+    const T s = T(0.70710677f);
+    const cpx<T> t0 = o[0];
+    const cpx<T> t1 = cmul(o[1], mk<T>(s, -s));
+    const cpx<T> t2 = cmul(o[2], mk<T>(T(0), -T(1)));
+    const cpx<T> t3 = cmul(o[3], mk<T>(-s, -s));
+    y[0] = cadd(e[0], t0);
+    y[1] = cadd(e[1], t1);
+    y[2] = cadd(e[2], t2);
+    y[3] = cadd(e[3], t3);
+    y[4] = csub(e[0], t0);
+    y[5] = csub(e[1], t1);
+    y[6] = csub(e[2], t2);
+    y[7] = csub(e[3], t3);
+}
+
+// fft_kernels.rs:32-86
+template <typename T>
+__device__ __forceinline__ void small_fft8(cpx<T> *x)
+{
+    cpx<T> e[4], o[4], y[8];
+    quad(x[0], x[2], x[4], x[6], e[0], e[1], e[2], e[3]);
+    quad(x[1], x[3], x[5], x[7], o[0], o[1], o[2], o[3]);
+    oct_combine(e, o, y);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = y[i];
+}
+
+// fft_kernels.rs:89-224
+template <typename T>
+__device__ __forceinline__ void small_fft16(cpx<T> *x)
+{
+    cpx<T> e[4], o[4], E[8], O[8];
+    // even comb x0,x2,..,x14: its own even comb is x0,x4,x8,x12, odd comb x2,x6,x10,x14
+    quad(x[0], x[4], x[8], x[12], e[0], e[1], e[2], e[3]);
+    quad(x[2], x[6], x[10], x[14], o[0], o[1], o[2], o[3]);
+    oct_combine(e, o, E);
+    quad(x[1], x[5], x[9], x[13], e[0], e[1], e[2], e[3]);
+    quad(x[3], x[7], x[11], x[15], o[0], o[1], o[2], o[3]);
+    oct_combine(e, o, O);
+    // fft_kernels.rs:181-197: f32 literals, widened for f64
+    const T c1 = T(0.9238795f), s1 = T(-0.38268343f);
+    const T c2 = T(0.70710677f), s2 = T(-0.70710677f);
+    const T c3 = T(0.38268343f), s3 = T(-0.9238795f);
+    cpx<T> q[8];
+    q[0] = O[0];
+    q[1] = cmul(O[1], mk<T>(c1, s1));
+    q[2] = cmul(O[2], mk<T>(c2, s2));
+    q[3] = cmul(O[3], mk<T>(c3, s3));
+    q[4] = cmul(O[4], mk<T>(T(0), T(-1.0f)));
+    q[5] = cmul(O[5], mk<T>(-c3, s3));
+    q[6] = cmul(O[6], mk<T>(-c2, s2));
+    q[7] = cmul(O[7], mk<T>(-c1, s1));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        x[i] = cadd(E[i], q[i]);
+        x[i + 8] = csub(E[i], q[i]);
+    }
+}
+
+}  // namespace kofft

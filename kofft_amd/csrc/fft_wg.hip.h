@@ -1,0 +1,273 @@
+// fft_wg.hip.h -- the generic "one transform per thread group" Stockham kernel.
+//
+// A transform of N = 2^L points is owned by TPT = N/R threads (R = 2^RL points per
+// thread); a workgroup of BLOCK threads carries BLOCK/TPT transforms.  The L radix-2
+// stages run as ceil(L/RL) register passes of up to RL stages each (reg_pass), with the
+// data exchanged through LDS between passes.  The first pass reads through the IO
+// policy (HBM, with the caller's fused pre-processing) and the last pass writes through
+// it, so each element crosses HBM exactly once in each direction.
+//
+// LDS layout: element i of a transform lives at lds_pad(i) = i + (i >> 4) (one pad
+// element per 16), which makes both access shapes of the exchanges conflict-free for
+// ds_read_b64 / ds_write_b64 at N = 4096 and N = 1024 ("LDS exchange").
+#pragma once
+
+#include "fft_device.hip.h"
+
+namespace kofft {
+
+__host__ __device__ constexpr int lds_pad(int i) { return i + (i >> 4); }
+__host__ __device__ constexpr int lds_elems(int n) { return n + (n >> 4) + 1; }
+
+// ---- IO policies -----------------------------------------------------------------
+// load(xf, i)  : element i of transform xf as the FFT must see it.
+// store(xf, o, v): element o of the finished transform.
+
+// FftImpl::fft (fft.rs:1054) / ifft (fft.rs:1134-1174: conj, fft, conj, *scale).
+template <typename T, bool INVERSE>
+struct ComplexIO {
+    const cpx<T> *__restrict__ in;
+    cpx<T> *__restrict__ out;
+    int n;
+    T scale;  // 1 / (n as f32 as T), fft.rs:1167
+    __device__ __forceinline__ cpx<T> load(size_t xf, int i) const
+    {
+        cpx<T> v = in[xf * (size_t)n + i];
+        if (INVERSE) v.im = -v.im;
+        return v;
+    }
+    __device__ __forceinline__ void store(size_t xf, int o, cpx<T> v) const
+    {
+        if (INVERSE) {
+            const T im = -v.im;
+            v.re = v.re * scale;
+            v.im = im * scale;
+        }
+        out[xf * (size_t)n + o] = v;
+    }
+};
+
+// stft.rs:91-103: frame f starts at start0 + f*hop; x = signal[start+i]*window[i] or 0.
+struct StftIO {
+    const float *__restrict__ signal;
+    const float *__restrict__ window;
+    cpx<float> *__restrict__ out;
+    size_t len, hop, start0;
+    int n;
+    __device__ __forceinline__ cpx<float> load(size_t xf, int i) const
+    {
+        const size_t pos = start0 + xf * hop + (size_t)i;
+        const float x = (pos < len) ? signal[pos] * window[i] : 0.0f;
+        return mk<float>(x, 0.0f);
+    }
+    __device__ __forceinline__ void store(size_t xf, int o, cpx<float> v) const
+    {
+        out[xf * (size_t)n + o] = v;
+    }
+};
+
+// rfft.rs:444-446 pack z[i] = (x[2i], x[2i+1]) (with the optional row window of the
+// batched entry point); the post-pass of rfft.rs:450-463 runs in the kernel epilogue
+// (rfft_post), which writes the m+1 outputs.
+template <typename T>
+struct RfftIO {
+    const T *__restrict__ in;         // batch rows of 2*m reals
+    const T *__restrict__ window;     // 2*m reals or nullptr
+    cpx<T> *__restrict__ out;         // batch rows of m+1 complex
+    const cpx<T> *__restrict__ rtab;  // build_twiddle_table(m), rfft.rs:172-183
+    int m;
+    __device__ __forceinline__ cpx<T> load(size_t xf, int i) const
+    {
+        const cpx<T> *row = reinterpret_cast<const cpx<T> *>(in + xf * (size_t)(2 * m));
+        cpx<T> v = row[i];
+        if (window) {
+            const cpx<T> w = reinterpret_cast<const cpx<T> *>(window)[i];
+            v.re = v.re * w.re;
+            v.im = v.im * w.im;
+        }
+        return v;
+    }
+    // X[k] for 1 <= k < m from Y[k], Y[m-k]  (rfft.rs:454-463)
+    __device__ __forceinline__ cpx<T> post(int k, cpx<T> a, cpx<T> ymk) const
+    {
+        const T half = T(0.5f);
+        const cpx<T> b = mk<T>(ymk.re, -ymk.im);
+        const cpx<T> sum = cadd(a, b), diff = csub(a, b);
+        const cpx<T> t = cmul(rtab[k], diff);
+        const cpx<T> temp = cadd(sum, mk<T>(t.im, -t.re));
+        return mk<T>(temp.re * half, temp.im * half);
+    }
+};
+
+// irfft_direct (rfft.rs:487-506): scratch[k] from input[k], input[m-k]; then fft.ifft
+// (conj, fft, conj, *1/m); output[2i], output[2i+1] = scratch[i].re, .im.
+template <typename T>
+struct IrfftIO {
+    const cpx<T> *__restrict__ in;  // batch rows of m+1 complex
+    cpx<T> *__restrict__ out;       // batch rows of m complex == 2*m reals
+    const cpx<T> *__restrict__ rtab;
+    int m;
+    T scale;  // 1 / (m as f32 as T)
+    __device__ __forceinline__ cpx<T> load(size_t xf, int k) const
+    {
+        const cpx<T> *row = in + xf * (size_t)(m + 1);
+        const T half = T(0.5f);
+        cpx<T> s;
+        if (k == 0) {
+            const T a = row[0].re, b = row[m].re;
+            s = mk<T>((a + b) * half, (a - b) * half);
+        } else {
+            const cpx<T> a = row[k];
+            const cpx<T> rb = row[m - k];
+            const cpx<T> b = mk<T>(rb.re, -rb.im);
+            const cpx<T> sum = cadd(a, b), diff = csub(a, b);
+            const cpx<T> tw = rtab[k];
+            const cpx<T> w = mk<T>(tw.re, -tw.im);
+            const cpx<T> t = cmul(w, diff);
+            const cpx<T> temp = csub(sum, mk<T>(t.im, -t.re));
+            s = mk<T>(temp.re * half, temp.im * half);
+        }
+        if (m > 1) s.im = -s.im;  // ifft: conj on the way in (fft.rs:1163-1165); n == 1 returns early
+        return s;
+    }
+    __device__ __forceinline__ void store(size_t xf, int o, cpx<T> v) const
+    {
+        if (m > 1) {  // ifft: conj, then scale (fft.rs:1168-1172)
+            const T im = -v.im;
+            v = mk<T>(v.re * scale, im * scale);
+        }
+        out[xf * (size_t)m + o] = v;
+    }
+};
+
+enum : int { EPI_STORE = 0, EPI_RFFT = 1 };
+
+// One register pass (compile-time pass number P) of the workgroup kernel.
+template <typename T, int L, int RL, int BLOCK, int EPI, int P, class IO>
+__device__ __forceinline__ void wg_pass(cpx<T> *v, cpx<T> *buf, const IO &io, const cpx<T> *__restrict__ tw,
+                                        const size_t xf, const bool active, const int tau)
+{
+    constexpr int N = 1 << L;
+    constexpr int R = 1 << RL;
+    constexpr int TPT = N / R;
+    constexpr int NP = (L + RL - 1) / RL;
+    constexpr int S0 = P * RL;
+    constexpr int Q = (P == NP - 1) ? (L - RL * (NP - 1)) : RL;
+    constexpr int G = R >> Q;       // independent (k, j) groups held by this thread
+    constexpr int JB = L - S0 - Q;  // bits of j
+
+    // ---- gather the pass inputs
+    if (P > 0) __syncthreads();  // the exchange written by pass P-1 is complete
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int m = tau + g * TPT;
+        const int k = m >> JB;
+        const int j = m & ((1 << JB) - 1);
+#pragma unroll
+        for (int c = 0; c < (1 << Q); ++c) {
+            const int i = (k << (L - S0)) | (c << JB) | j;
+            if (P == 0)
+                v[g * (1 << Q) + c] = active ? io.load(xf, i) : mk<T>(T(0), T(0));
+            else
+                v[g * (1 << Q) + c] = buf[lds_pad(i)];
+        }
+    }
+    // ---- Q stages in registers
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int m = tau + g * TPT;
+        reg_pass<T, L, S0, Q>(&v[g * (1 << Q)], m >> JB, tw);
+    }
+    // ---- scatter the pass outputs
+    constexpr bool to_lds = (P < NP - 1) || (EPI == EPI_RFFT);
+    if (P > 0 && to_lds) __syncthreads();  // every gather of this pass is done
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int m = tau + g * TPT;
+#pragma unroll
+        for (int c = 0; c < (1 << Q); ++c) {
+            const int o = (bitrev(c, Q) << (L - Q)) | m;
+            if constexpr (to_lds) {
+                buf[lds_pad(o)] = v[g * (1 << Q) + c];
+            } else {
+                if (active) io.store(xf, o, v[g * (1 << Q) + c]);
+            }
+        }
+    }
+}
+
+template <typename T, int L, int RL, int BLOCK, int EPI, class IO>
+__global__ __launch_bounds__(BLOCK) void fft_wg_kernel(const IO io, const cpx<T> *__restrict__ tw, const size_t batch)
+{
+    constexpr int N = 1 << L;
+    constexpr int R = 1 << RL;
+    constexpr int TPT = N / R;
+    static_assert(TPT >= 1 && BLOCK % TPT == 0, "bad geometry");
+    constexpr int XPB = BLOCK / TPT;
+    constexpr int NP = (L + RL - 1) / RL;
+    static_assert(NP >= 1 && NP <= 5, "pass count");
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cpx<T> *lds = reinterpret_cast<cpx<T> *>(smem_raw);
+
+    const int tid = threadIdx.x;
+    const int tau = tid % TPT;
+    const int slot = tid / TPT;
+    const size_t xf = (size_t)blockIdx.x * XPB + slot;
+    const bool active = xf < batch;
+    cpx<T> *buf = lds + slot * lds_elems(N);
+
+    cpx<T> v[R];
+    wg_pass<T, L, RL, BLOCK, EPI, 0>(v, buf, io, tw, xf, active, tau);
+    if constexpr (NP > 1) wg_pass<T, L, RL, BLOCK, EPI, 1>(v, buf, io, tw, xf, active, tau);
+    if constexpr (NP > 2) wg_pass<T, L, RL, BLOCK, EPI, 2>(v, buf, io, tw, xf, active, tau);
+    if constexpr (NP > 3) wg_pass<T, L, RL, BLOCK, EPI, 3>(v, buf, io, tw, xf, active, tau);
+    if constexpr (NP > 4) wg_pass<T, L, RL, BLOCK, EPI, 4>(v, buf, io, tw, xf, active, tau);
+
+    if constexpr (EPI == EPI_RFFT) {
+        // rfft.rs:450-463 on Y = buf (natural order), m = N.
+        __syncthreads();
+        if (active) {
+            cpx<T> *orow = io.out + xf * (size_t)(N + 1);
+#pragma unroll
+            for (int g = 0; g < R; ++g) {
+                const int k = tau + g * TPT;
+                if (k == 0) {
+                    const cpx<T> y0 = buf[lds_pad(0)];
+                    orow[0] = mk<T>(y0.re + y0.im, T(0));
+                    orow[N] = mk<T>(y0.re - y0.im, T(0));
+                } else {
+                    orow[k] = io.post(k, buf[lds_pad(k)], buf[lds_pad(N - k)]);
+                }
+            }
+        }
+    }
+}
+
+// ---- n = 1, 2, 4, 8, 16: one thread per transform, straight-line kernels ---------
+// (fft.rs:1059-1071 dispatch; ifft wraps them with conj / conj*scale via the IO policy)
+template <typename T, int N, int EPI, class IO>
+__global__ __launch_bounds__(256) void fft_small_kernel(const IO io, const size_t batch)
+{
+    const size_t xf = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (xf >= batch) return;
+    cpx<T> x[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = io.load(xf, i);
+    if constexpr (N == 2) small_fft2(x);
+    if constexpr (N == 4) small_fft4(x);
+    if constexpr (N == 8) small_fft8(x);
+    if constexpr (N == 16) small_fft16(x);
+    if constexpr (EPI == EPI_RFFT) {
+        cpx<T> *orow = io.out + xf * (size_t)(N + 1);
+        orow[0] = mk<T>(x[0].re + x[0].im, T(0));
+        orow[N] = mk<T>(x[0].re - x[0].im, T(0));
+#pragma unroll
+        for (int k = 1; k < N; ++k) orow[k] = io.post(k, x[k], x[N - k]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) io.store(xf, i, x[i]);
+    }
+}
+
+}  // namespace kofft

@@ -1,0 +1,606 @@
+// kofft_hip.hip -- context, planner cache, launch dispatch and the extern "C" ABI of
+// include/kofft_hip.h.  gfx950 only; compiled with -ffp-contract=off.
+#include "../../include/kofft_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "fft_wg.hip.h"
+#include "tables.h"
+
+using namespace kofft;
+
+// ---------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------
+struct kofft_hip_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+    // planner caches: (kind, n) -> device table.  kind 0/1 = FftPlanner twiddles f32/f64,
+    // 2/3 = RfftPlanner post-pass table f32/f64.
+    std::map<std::pair<int, size_t>, void *> tables;
+    // staging for the host-pointer entry points
+    void *stage[3] = {nullptr, nullptr, nullptr};
+    size_t stage_bytes[3] = {0, 0, 0};
+};
+
+namespace {
+
+#define KOFFT_HIP_TRY(ctx, expr)                                                              \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            (ctx)->last_error = std::string(#expr) + ": " + hipGetErrorString(e_);            \
+            return KOFFT_ERR_HIP;                                                             \
+        }                                                                                     \
+    } while (0)
+
+inline bool is_pow2(size_t n) { return n != 0 && (n & (n - 1)) == 0; }
+inline int ilog2(size_t n)
+{
+    int l = 0;
+    while ((size_t(1) << l) < n) ++l;
+    return l;
+}
+
+template <typename T> struct Kind;
+template <> struct Kind<float> { static constexpr int tw = 0, rt = 2; };
+template <> struct Kind<double> { static constexpr int tw = 1, rt = 3; };
+
+template <typename T>
+int get_table(kofft_hip_ctx *ctx, int kind, size_t n, const cpx<T> **out)
+{
+    auto key = std::make_pair(kind, n);
+    auto it = ctx->tables.find(key);
+    if (it != ctx->tables.end()) {
+        *out = static_cast<const cpx<T> *>(it->second);
+        return KOFFT_OK;
+    }
+    const bool is_rfft = kind >= 2;
+    const size_t entries = is_rfft ? n : n / 2;
+    std::vector<T> host(2 * (entries ? entries : 1));
+    if (is_rfft) {
+        if constexpr (sizeof(T) == 4) kofft_tables::rfft_table_f32(n, (float *)host.data());
+        else kofft_tables::rfft_table_f64(n, (double *)host.data());
+    } else {
+        if constexpr (sizeof(T) == 4) kofft_tables::twiddles_f32(n, (float *)host.data());
+        else kofft_tables::twiddles_f64(n, (double *)host.data());
+    }
+    void *d = nullptr;
+    KOFFT_HIP_TRY(ctx, hipMalloc(&d, host.size() * sizeof(T)));
+    // synchronous copy: tables are built once per (context, n), never in a timed region
+    hipError_t e = hipMemcpy(d, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        ctx->last_error = std::string("table upload: ") + hipGetErrorString(e);
+        return KOFFT_ERR_HIP;
+    }
+    ctx->tables[key] = d;
+    *out = static_cast<const cpx<T> *>(d);
+    return KOFFT_OK;
+}
+
+int ensure_stage(kofft_hip_ctx *ctx, int which, size_t bytes)
+{
+    if (ctx->stage_bytes[which] >= bytes) return KOFFT_OK;
+    if (ctx->stage[which]) KOFFT_HIP_TRY(ctx, hipFree(ctx->stage[which]));
+    ctx->stage[which] = nullptr;
+    ctx->stage_bytes[which] = 0;
+    KOFFT_HIP_TRY(ctx, hipMalloc(&ctx->stage[which], bytes));
+    ctx->stage_bytes[which] = bytes;
+    return KOFFT_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// launch geometry
+// ---------------------------------------------------------------------------------
+constexpr int rl_for(int L) { return (L == 5 || L == 6 || L == 9) ? 3 : (L >= 13 ? 5 : 4); }
+constexpr int block_for(int L)
+{
+    const int tpt = (1 << L) >> rl_for(L);
+    return tpt > 256 ? tpt : 256;
+}
+template <typename T> constexpr int max_log2();
+template <> constexpr int max_log2<float>() { return 14; }
+template <> constexpr int max_log2<double>() { return 13; }
+
+template <typename T, int L, int EPI, class IO>
+int launch_wg(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t batch)
+{
+    constexpr int RL = rl_for(L);
+    constexpr int BLOCK = block_for(L);
+    constexpr int TPT = (1 << L) >> RL;
+    constexpr int XPB = BLOCK / TPT;
+    constexpr size_t lds = (size_t)XPB * lds_elems(1 << L) * sizeof(cpx<T>);
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = fft_wg_kernel<T, L, RL, BLOCK, EPI, IO>;
+    if (lds > 64 * 1024) {
+        KOFFT_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    const size_t blocks = (batch + XPB - 1) / XPB;
+    if (blocks > 0x7fffffffULL) return KOFFT_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BLOCK), lds, ctx->stream, io, tw, batch);
+    KOFFT_HIP_TRY(ctx, hipGetLastError());
+    return KOFFT_OK;
+}
+
+template <typename T, int N, int EPI, class IO>
+int launch_small(kofft_hip_ctx *ctx, const IO &io, size_t batch)
+{
+    const size_t blocks = (batch + 255) / 256;
+    if (blocks > 0x7fffffffULL) return KOFFT_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((fft_small_kernel<T, N, EPI, IO>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, io,
+                       batch);
+    KOFFT_HIP_TRY(ctx, hipGetLastError());
+    return KOFFT_OK;
+}
+
+// Run the n-point transform described by `io` (n a power of two >= 1) over `batch` units.
+template <typename T, int EPI, class IO>
+int dispatch(kofft_hip_ctx *ctx, const IO &io, size_t n, size_t batch)
+{
+    if (batch == 0) return KOFFT_OK;
+    const int L = ilog2(n);
+    if (L > max_log2<T>()) return KOFFT_ERR_UNSUPPORTED;
+    switch (L) {
+    case 0: return launch_small<T, 1, EPI>(ctx, io, batch);
+    case 1: return launch_small<T, 2, EPI>(ctx, io, batch);
+    case 2: return launch_small<T, 4, EPI>(ctx, io, batch);
+    case 3: return launch_small<T, 8, EPI>(ctx, io, batch);
+    case 4: return launch_small<T, 16, EPI>(ctx, io, batch);
+    default: break;
+    }
+    const cpx<T> *tw = nullptr;
+    int rc = get_table<T>(ctx, Kind<T>::tw, n, &tw);
+    if (rc) return rc;
+    switch (L) {
+#define KOFFT_CASE(LL) \
+    case LL: return launch_wg<T, LL, EPI>(ctx, io, tw, batch);
+        KOFFT_CASE(5)
+        KOFFT_CASE(6)
+        KOFFT_CASE(7)
+        KOFFT_CASE(8)
+        KOFFT_CASE(9)
+        KOFFT_CASE(10)
+        KOFFT_CASE(11)
+        KOFFT_CASE(12)
+        KOFFT_CASE(13)
+    case 14:
+        if constexpr (sizeof(T) == 4) return launch_wg<T, 14, EPI>(ctx, io, tw, batch);
+        else return KOFFT_ERR_UNSUPPORTED;
+#undef KOFFT_CASE
+    default: return KOFFT_ERR_UNSUPPORTED;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// typed entry points behind the C ABI
+// ---------------------------------------------------------------------------------
+template <typename T>
+int fft_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t batch, int inverse)
+{
+    // argument checks come first and need no device, so the reference's error order is testable anywhere
+    if (batch == 0) return KOFFT_OK;
+    if (n == 0) return KOFFT_ERR_EMPTY_INPUT;  // fft.rs:1056 / 1136
+    if (!is_pow2(n)) return KOFFT_ERR_UNSUPPORTED;  // Bluestein arm (fft.rs:1088-1132) not on the device path
+    if (n > (size_t(1) << max_log2<T>())) return KOFFT_ERR_UNSUPPORTED;
+    if (!ctx || !d_in || !d_out) return KOFFT_ERR_NULL;
+    KOFFT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (n == 1) {  // fft.rs:1059 / 1139: nothing to do
+        if (d_in != d_out)
+            KOFFT_HIP_TRY(ctx, hipMemcpyAsync(d_out, d_in, batch * 2 * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
+        return KOFFT_OK;
+    }
+    const T scale = (T)1 / (T)(float)n;  // fft.rs:1167
+    if (inverse) {
+        ComplexIO<T, true> io{reinterpret_cast<const cpx<T> *>(d_in), reinterpret_cast<cpx<T> *>(d_out), (int)n, scale};
+        return dispatch<T, EPI_STORE>(ctx, io, n, batch);
+    }
+    ComplexIO<T, false> io{reinterpret_cast<const cpx<T> *>(d_in), reinterpret_cast<cpx<T> *>(d_out), (int)n, scale};
+    return dispatch<T, EPI_STORE>(ctx, io, n, batch);
+}
+
+template <typename T>
+int fft_host(kofft_hip_ctx *ctx, T *data, size_t n, size_t batch, int inverse)
+{
+    if (batch == 0) return KOFFT_OK;
+    if (n == 0) return KOFFT_ERR_EMPTY_INPUT;
+    if (!is_pow2(n) || n > (size_t(1) << max_log2<T>())) return KOFFT_ERR_UNSUPPORTED;
+    if (n == 1) return KOFFT_OK;
+    if (!ctx || !data) return KOFFT_ERR_NULL;
+    KOFFT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = batch * n * 2 * sizeof(T);
+    int rc = ensure_stage(ctx, 0, bytes);
+    if (rc) return rc;
+    T *d = static_cast<T *>(ctx->stage[0]);
+    KOFFT_HIP_TRY(ctx, hipMemcpyAsync(d, data, bytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = fft_dev<T>(ctx, d, d, n, batch, inverse);
+    if (rc) return rc;
+    KOFFT_HIP_TRY(ctx, hipMemcpyAsync(data, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    KOFFT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return KOFFT_OK;
+}
+
+// fft_strided / ifft_strided (fft.rs:1175-1199, 1236-1260): gather, transform, scatter.
+template <typename T>
+int fft_strided_host(kofft_hip_ctx *ctx, T *data, size_t data_len, size_t stride, size_t n, int inverse)
+{
+    if (stride == 0) return KOFFT_ERR_INVALID_STRIDE;  // fft.rs:1181
+    if (n == 0) return KOFFT_OK;                       // fft.rs:1185
+    if (data_len < (n - 1) * stride + 1) return KOFFT_ERR_MISMATCHED_LENGTHS;  // fft.rs:1188
+    if (!ctx || !data) return KOFFT_ERR_NULL;
+    std::vector<T> scratch(2 * n);
+    for (size_t i = 0; i < n; ++i) {
+        scratch[2 * i] = data[2 * i * stride];
+        scratch[2 * i + 1] = data[2 * i * stride + 1];
+    }
+    int rc = fft_host<T>(ctx, scratch.data(), n, 1, inverse);
+    if (rc) return rc;
+    for (size_t i = 0; i < n; ++i) {
+        data[2 * i * stride] = scratch[2 * i];
+        data[2 * i * stride + 1] = scratch[2 * i + 1];
+    }
+    return KOFFT_OK;
+}
+
+template <typename T>
+int rfft_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, const T *d_window, size_t n, size_t batch)
+{
+    if (batch == 0) return KOFFT_OK;
+    if (n == 0) return KOFFT_ERR_EMPTY_INPUT;   // rfft.rs:434
+    if (n % 2 != 0) return KOFFT_ERR_INVALID_VALUE;  // rfft.rs:437
+    const size_t m = n / 2;
+    if (!is_pow2(m) || m > (size_t(1) << max_log2<T>())) return KOFFT_ERR_UNSUPPORTED;
+    if (!ctx || !d_in || !d_out) return KOFFT_ERR_NULL;
+    KOFFT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const cpx<T> *rtab = nullptr;
+    int rc = get_table<T>(ctx, Kind<T>::rt, m, &rtab);
+    if (rc) return rc;
+    RfftIO<T> io{d_in, d_window, reinterpret_cast<cpx<T> *>(d_out), rtab, (int)m};
+    return dispatch<T, EPI_RFFT>(ctx, io, m, batch);
+}
+
+template <typename T>
+int irfft_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t batch)
+{
+    if (batch == 0) return KOFFT_OK;
+    if (n == 0) return KOFFT_ERR_EMPTY_INPUT;   // rfft.rs:477
+    if (n % 2 != 0) return KOFFT_ERR_INVALID_VALUE;  // rfft.rs:480
+    const size_t m = n / 2;
+    if (!is_pow2(m) || m > (size_t(1) << max_log2<T>())) return KOFFT_ERR_UNSUPPORTED;
+    if (!ctx || !d_in || !d_out) return KOFFT_ERR_NULL;
+    KOFFT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const cpx<T> *rtab = nullptr;
+    int rc = get_table<T>(ctx, Kind<T>::rt, m, &rtab);
+    if (rc) return rc;
+    IrfftIO<T> io{reinterpret_cast<const cpx<T> *>(d_in), reinterpret_cast<cpx<T> *>(d_out), rtab, (int)m,
+                  (T)1 / (T)(float)m};
+    return dispatch<T, EPI_STORE>(ctx, io, m, batch);
+}
+
+template <typename T>
+int rfft_host(kofft_hip_ctx *ctx, const T *in, T *out, const T *window, size_t n, size_t batch)
+{
+    if (batch == 0) return KOFFT_OK;
+    if (n == 0) return KOFFT_ERR_EMPTY_INPUT;
+    if (n % 2 != 0) return KOFFT_ERR_INVALID_VALUE;
+    const size_t m = n / 2;
+    if (!is_pow2(m) || m > (size_t(1) << max_log2<T>())) return KOFFT_ERR_UNSUPPORTED;
+    if (!ctx || !in || !out) return KOFFT_ERR_NULL;
+    KOFFT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t in_bytes = batch * n * sizeof(T), out_bytes = batch * (m + 1) * 2 * sizeof(T);
+    int rc = ensure_stage(ctx, 0, in_bytes);
+    if (rc) return rc;
+    rc = ensure_stage(ctx, 1, out_bytes);
+    if (rc) return rc;
+    T *d_win = nullptr;
+    if (window) {
+        rc = ensure_stage(ctx, 2, n * sizeof(T));
+        if (rc) return rc;
+        d_win = static_cast<T *>(ctx->stage[2]);
+        KOFFT_HIP_TRY(ctx, hipMemcpyAsync(d_win, window, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    }
+    KOFFT_HIP_TRY(ctx, hipMemcpyAsync(ctx->stage[0], in, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = rfft_dev<T>(ctx, static_cast<const T *>(ctx->stage[0]), static_cast<T *>(ctx->stage[1]), d_win, n, batch);
+    if (rc) return rc;
+    KOFFT_HIP_TRY(ctx, hipMemcpyAsync(out, ctx->stage[1], out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    KOFFT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return KOFFT_OK;
+}
+
+template <typename T>
+int irfft_host(kofft_hip_ctx *ctx, const T *in, T *out, size_t n, size_t batch)
+{
+    if (batch == 0) return KOFFT_OK;
+    if (n == 0) return KOFFT_ERR_EMPTY_INPUT;
+    if (n % 2 != 0) return KOFFT_ERR_INVALID_VALUE;
+    const size_t m = n / 2;
+    if (!is_pow2(m) || m > (size_t(1) << max_log2<T>())) return KOFFT_ERR_UNSUPPORTED;
+    if (!ctx || !in || !out) return KOFFT_ERR_NULL;
+    KOFFT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t in_bytes = batch * (m + 1) * 2 * sizeof(T), out_bytes = batch * n * sizeof(T);
+    int rc = ensure_stage(ctx, 0, in_bytes);
+    if (rc) return rc;
+    rc = ensure_stage(ctx, 1, out_bytes);
+    if (rc) return rc;
+    KOFFT_HIP_TRY(ctx, hipMemcpyAsync(ctx->stage[0], in, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = irfft_dev<T>(ctx, static_cast<const T *>(ctx->stage[0]), static_cast<T *>(ctx->stage[1]), n, batch);
+    if (rc) return rc;
+    KOFFT_HIP_TRY(ctx, hipMemcpyAsync(out, ctx->stage[1], out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    KOFFT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return KOFFT_OK;
+}
+
+int stft_dev(kofft_hip_ctx *ctx, const float *d_signal, size_t len, const float *d_window, size_t win_len,
+             size_t start0, size_t hop, float *d_out, size_t count)
+{
+    if (count == 0) return KOFFT_OK;
+    if (win_len == 0) return KOFFT_ERR_EMPTY_INPUT;  // fft.fft(&mut []) -> fft.rs:1056
+    if (!is_pow2(win_len) || win_len > (size_t(1) << max_log2<float>())) return KOFFT_ERR_UNSUPPORTED;
+    if (!ctx || (!d_signal && len) || !d_window || !d_out) return KOFFT_ERR_NULL;
+    KOFFT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    StftIO io{d_signal, d_window, reinterpret_cast<cpx<float> *>(d_out), len, hop, start0, (int)win_len};
+    return dispatch<float, EPI_STORE>(ctx, io, win_len, count);
+}
+
+// Host-pointer STFT of frames starting at start0, start0+hop, ...: uploads only the samples
+// those frames can see.
+int stft_host(kofft_hip_ctx *ctx, const float *signal, size_t len, const float *window, size_t win_len,
+              size_t start0, size_t hop, float *out, size_t count)
+{
+    if (count == 0) return KOFFT_OK;
+    if (win_len == 0) return KOFFT_ERR_EMPTY_INPUT;
+    if (!is_pow2(win_len) || win_len > (size_t(1) << max_log2<float>())) return KOFFT_ERR_UNSUPPORTED;
+    if (!ctx || (!signal && len) || !window || !out) return KOFFT_ERR_NULL;
+    KOFFT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t lo = start0 < len ? start0 : len;
+    size_t hi = start0 + (count - 1) * hop + win_len;
+    if (hi > len) hi = len;
+    if (hi < lo) hi = lo;
+    const size_t span = hi - lo;
+    const size_t out_bytes = count * win_len * 2 * sizeof(float);
+    int rc = ensure_stage(ctx, 0, (span ? span : 1) * sizeof(float));
+    if (rc) return rc;
+    rc = ensure_stage(ctx, 1, out_bytes);
+    if (rc) return rc;
+    rc = ensure_stage(ctx, 2, win_len * sizeof(float));
+    if (rc) return rc;
+    if (span)
+        KOFFT_HIP_TRY(ctx, hipMemcpyAsync(ctx->stage[0], signal + lo, span * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    KOFFT_HIP_TRY(ctx, hipMemcpyAsync(ctx->stage[2], window, win_len * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    // positions are relative to `lo`; a start past the end of the signal leaves every sample zero
+    rc = stft_dev(ctx, static_cast<const float *>(ctx->stage[0]), span, static_cast<const float *>(ctx->stage[2]),
+                  win_len, start0 - lo, hop, static_cast<float *>(ctx->stage[1]), count);
+    if (rc) return rc;
+    KOFFT_HIP_TRY(ctx, hipMemcpyAsync(out, ctx->stage[1], out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    KOFFT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return KOFFT_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------
+// extern "C"
+// ---------------------------------------------------------------------------------
+extern "C" {
+
+const char *kofft_hip_strerror(int status)
+{
+    switch (status) {
+    case KOFFT_OK: return "Ok";
+    case KOFFT_ERR_EMPTY_INPUT: return "FftError::EmptyInput";
+    case KOFFT_ERR_NON_POWER_OF_TWO_NO_STD: return "FftError::NonPowerOfTwoNoStd";
+    case KOFFT_ERR_MISMATCHED_LENGTHS: return "FftError::MismatchedLengths";
+    case KOFFT_ERR_INVALID_STRIDE: return "FftError::InvalidStride";
+    case KOFFT_ERR_INVALID_HOP_SIZE: return "FftError::InvalidHopSize";
+    case KOFFT_ERR_INVALID_VALUE: return "FftError::InvalidValue";
+    case KOFFT_ERR_HIP: return "HIP runtime error (see kofft_hip_last_error)";
+    case KOFFT_ERR_UNSUPPORTED: return "length not supported by the device path";
+    case KOFFT_ERR_NULL: return "null context or pointer";
+    case KOFFT_ERR_ALLOC: return "allocation failed";
+    default: return "unknown status";
+    }
+}
+
+const char *kofft_hip_last_error(const kofft_hip_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+const char *kofft_hip_version(void) { return "kofft-hip 0.1.0 (gfx950)"; }
+
+int kofft_hip_device_count(int *count)
+{
+    if (!count) return KOFFT_ERR_NULL;
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    *count = (e == hipSuccess) ? c : 0;
+    return e == hipSuccess ? KOFFT_OK : KOFFT_ERR_HIP;
+}
+
+int kofft_hip_create(int device, kofft_hip_ctx **out)
+{
+    if (!out) return KOFFT_ERR_NULL;
+    *out = nullptr;
+    if (hipSetDevice(device) != hipSuccess) return KOFFT_ERR_HIP;
+    kofft_hip_ctx *ctx = new (std::nothrow) kofft_hip_ctx();
+    if (!ctx) return KOFFT_ERR_ALLOC;
+    ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return KOFFT_ERR_HIP;
+    }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return KOFFT_OK;
+}
+
+int kofft_hip_destroy(kofft_hip_ctx *ctx)
+{
+    if (!ctx) return KOFFT_ERR_NULL;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->tables) (void)hipFree(kv.second);
+    for (int i = 0; i < 3; ++i)
+        if (ctx->stage[i]) (void)hipFree(ctx->stage[i]);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return KOFFT_OK;
+}
+
+int kofft_hip_set_stream(kofft_hip_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return KOFFT_ERR_NULL;
+    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return KOFFT_OK;
+}
+
+int kofft_hip_synchronize(kofft_hip_ctx *ctx)
+{
+    if (!ctx) return KOFFT_ERR_NULL;
+    KOFFT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return KOFFT_OK;
+}
+
+int kofft_hip_twiddles_f32(size_t n, float *out)
+{
+    if (!out && n >= 2) return KOFFT_ERR_NULL;
+    kofft_tables::twiddles_f32(n, out);
+    return KOFFT_OK;
+}
+int kofft_hip_twiddles_f64(size_t n, double *out)
+{
+    if (!out && n >= 2) return KOFFT_ERR_NULL;
+    kofft_tables::twiddles_f64(n, out);
+    return KOFFT_OK;
+}
+int kofft_hip_rfft_table_f32(size_t m, float *out)
+{
+    if (!out && m) return KOFFT_ERR_NULL;
+    kofft_tables::rfft_table_f32(m, out);
+    return KOFFT_OK;
+}
+int kofft_hip_rfft_table_f64(size_t m, double *out)
+{
+    if (!out && m) return KOFFT_ERR_NULL;
+    kofft_tables::rfft_table_f64(m, out);
+    return KOFFT_OK;
+}
+int kofft_hip_hann_f32(size_t len, float *out)
+{
+    if (!out && len) return KOFFT_ERR_NULL;
+    kofft_tables::hann_f32(len, out);
+    return KOFFT_OK;
+}
+
+int kofft_hip_fft_c32(kofft_hip_ctx *ctx, float *data, size_t n, size_t batch, int inverse)
+{
+    return fft_host<float>(ctx, data, n, batch, inverse);
+}
+int kofft_hip_fft_c64(kofft_hip_ctx *ctx, double *data, size_t n, size_t batch, int inverse)
+{
+    return fft_host<double>(ctx, data, n, batch, inverse);
+}
+int kofft_hip_fft_c32_dev(kofft_hip_ctx *ctx, float *d_data, size_t n, size_t batch, int inverse)
+{
+    return fft_dev<float>(ctx, d_data, d_data, n, batch, inverse);
+}
+int kofft_hip_fft_c64_dev(kofft_hip_ctx *ctx, double *d_data, size_t n, size_t batch, int inverse)
+{
+    return fft_dev<double>(ctx, d_data, d_data, n, batch, inverse);
+}
+int kofft_hip_fft_c32_dev_oop(kofft_hip_ctx *ctx, const float *d_in, float *d_out, size_t n, size_t batch,
+                              int inverse)
+{
+    return fft_dev<float>(ctx, d_in, d_out, n, batch, inverse);
+}
+int kofft_hip_fft_c64_dev_oop(kofft_hip_ctx *ctx, const double *d_in, double *d_out, size_t n, size_t batch,
+                              int inverse)
+{
+    return fft_dev<double>(ctx, d_in, d_out, n, batch, inverse);
+}
+int kofft_hip_fft_c32_strided(kofft_hip_ctx *ctx, float *data, size_t data_len, size_t stride, size_t n,
+                              int inverse)
+{
+    return fft_strided_host<float>(ctx, data, data_len, stride, n, inverse);
+}
+int kofft_hip_fft_c64_strided(kofft_hip_ctx *ctx, double *data, size_t data_len, size_t stride, size_t n,
+                              int inverse)
+{
+    return fft_strided_host<double>(ctx, data, data_len, stride, n, inverse);
+}
+
+int kofft_hip_rfft_f32(kofft_hip_ctx *ctx, const float *in, float *out, const float *window, size_t n,
+                       size_t batch)
+{
+    return rfft_host<float>(ctx, in, out, window, n, batch);
+}
+int kofft_hip_rfft_f32_dev(kofft_hip_ctx *ctx, const float *d_in, float *d_out, const float *d_window, size_t n,
+                           size_t batch)
+{
+    return rfft_dev<float>(ctx, d_in, d_out, d_window, n, batch);
+}
+int kofft_hip_irfft_f32(kofft_hip_ctx *ctx, const float *in, float *out, size_t n, size_t batch)
+{
+    return irfft_host<float>(ctx, in, out, n, batch);
+}
+int kofft_hip_irfft_f32_dev(kofft_hip_ctx *ctx, const float *d_in, float *d_out, size_t n, size_t batch)
+{
+    return irfft_dev<float>(ctx, d_in, d_out, n, batch);
+}
+int kofft_hip_rfft_f64(kofft_hip_ctx *ctx, const double *in, double *out, const double *window, size_t n,
+                       size_t batch)
+{
+    return rfft_host<double>(ctx, in, out, window, n, batch);
+}
+int kofft_hip_rfft_f64_dev(kofft_hip_ctx *ctx, const double *d_in, double *d_out, const double *d_window,
+                           size_t n, size_t batch)
+{
+    return rfft_dev<double>(ctx, d_in, d_out, d_window, n, batch);
+}
+int kofft_hip_irfft_f64(kofft_hip_ctx *ctx, const double *in, double *out, size_t n, size_t batch)
+{
+    return irfft_host<double>(ctx, in, out, n, batch);
+}
+int kofft_hip_irfft_f64_dev(kofft_hip_ctx *ctx, const double *d_in, double *d_out, size_t n, size_t batch)
+{
+    return irfft_dev<double>(ctx, d_in, d_out, n, batch);
+}
+
+int kofft_hip_stft_f32(kofft_hip_ctx *ctx, const float *signal, size_t len, const float *window, size_t win_len,
+                       size_t hop, float *out, size_t frames)
+{
+    if (hop == 0) return KOFFT_ERR_INVALID_HOP_SIZE;               // stft.rs:83
+    const size_t required = (len + hop - 1) / hop;                  // stft.rs:86
+    if (frames < required) return KOFFT_ERR_MISMATCHED_LENGTHS;    // stft.rs:87
+    return stft_host(ctx, signal, len, window, win_len, 0, hop, out, frames);
+}
+
+int kofft_hip_stft_parallel_f32(kofft_hip_ctx *ctx, const float *signal, size_t len, const float *window,
+                                size_t win_len, size_t hop, float *out, size_t frames)
+{
+    if (hop == 0) return KOFFT_ERR_INVALID_HOP_SIZE;  // stft.rs:242 -- the only check parallel() makes
+    return stft_host(ctx, signal, len, window, win_len, 0, hop, out, frames);
+}
+
+int kofft_hip_stft_frame_f32(kofft_hip_ctx *ctx, const float *signal, size_t len, const float *window,
+                             size_t win_len, size_t start, float *frame_out)
+{
+    return stft_host(ctx, signal, len, window, win_len, start, 1, frame_out, 1);
+}
+
+int kofft_hip_stft_f32_dev(kofft_hip_ctx *ctx, const float *d_signal, size_t len, const float *d_window,
+                           size_t win_len, size_t hop, float *d_out, size_t first_frame, size_t count)
+{
+    if (hop == 0) return KOFFT_ERR_INVALID_HOP_SIZE;  // stft.rs:83 / 242
+    return stft_dev(ctx, d_signal, len, d_window, win_len, first_frame * hop, hop, d_out, count);
+}
+
+}  // extern "C"

@@ -1,0 +1,75 @@
+// tables.cpp -- host-side planner recipes of the product (NOT the test oracle).
+//
+// The device never computes trigonometry: kofft's tables are produced by rounding-
+// sensitive recurrences, so they are generated here, with the reference's exact
+// order of operations, and uploaded.  Compiled with g++ -ffp-contract=off; sinf/cosf/
+// fmaf come from glibc, which is what Rust's f32::sin_cos / mul_add lower to on
+// x86_64-unknown-linux-gnu.
+#include "tables.h"
+
+#include <cmath>
+
+namespace {
+
+template <typename T> struct Num;
+template <> struct Num<float> {
+    static float pi() { return 3.14159265358979323846f; }  // core::f32::consts::PI
+    static float sin(float x) { return sinf(x); }
+    static float cos(float x) { return cosf(x); }
+    static float fma(float a, float b, float c) { return fmaf(a, b, c); }
+};
+template <> struct Num<double> {
+    static double pi() { return 3.14159265358979323846; }  // core::f64::consts::PI
+    static double sin(double x) { return ::sin(x); }
+    static double cos(double x) { return ::cos(x); }
+    static double fma(double a, double b, double c) { return ::fma(a, b, c); }
+};
+
+// FftPlanner::get_twiddles (fft.rs:391-405)
+template <typename T>
+void twiddles(size_t n, T *out)
+{
+    const size_t half = n / 2;
+    const T angle = (-(T)2.0f * Num<T>::pi()) / (T)(float)n;
+    const T s = Num<T>::sin(angle), c = Num<T>::cos(angle);
+    T w_re = (T)1, w_im = (T)0;
+    for (size_t k = 0; k < half; ++k) {
+        out[2 * k] = w_re;
+        out[2 * k + 1] = w_im;
+        const T prev_re = w_re;
+        w_re = Num<T>::fma(w_re, c, -(w_im * s));
+        w_im = Num<T>::fma(w_im, c, prev_re * s);
+    }
+}
+
+// build_twiddle_table (rfft.rs:172-183): cur <- cur.mul(w), un-fused complex product
+template <typename T>
+void rfft_table(size_t m, T *out)
+{
+    const T angle = -Num<T>::pi() / (T)(float)m;
+    const T s = Num<T>::sin(angle), c = Num<T>::cos(angle);
+    T re = (T)1, im = (T)0;
+    for (size_t k = 0; k < m; ++k) {
+        out[2 * k] = re;
+        out[2 * k + 1] = im;
+        const T nre = re * c - im * s;
+        const T nim = re * s + im * c;
+        re = nre;
+        im = nim;
+    }
+}
+
+}  // namespace
+
+namespace kofft_tables {
+void twiddles_f32(size_t n, float *out) { twiddles<float>(n, out); }
+void twiddles_f64(size_t n, double *out) { twiddles<double>(n, out); }
+void rfft_table_f32(size_t m, float *out) { rfft_table<float>(m, out); }
+void rfft_table_f64(size_t m, double *out) { rfft_table<double>(m, out); }
+// window::hann (window.rs:24-28), all arithmetic in f32
+void hann_f32(size_t len, float *out)
+{
+    const float pi = 3.14159265358979323846f;
+    for (size_t i = 0; i < len; ++i) out[i] = 0.5f - 0.5f * cosf(2.0f * pi * (float)i / (float)len);
+}
+}  // namespace kofft_tables

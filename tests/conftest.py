@@ -1,0 +1,65 @@
+"""Shared fixtures.  `-m "not gpu"` runs here (no GPU): oracle, golden vectors, host logic, ABI symbols.
+`-m gpu` runs on a real MI355X: parity of the HIP path against the oracle, through the C ABI."""
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU oracle (oracle/pyoracle.py): test infrastructure only."""
+    from oracle import pyoracle
+
+    pyoracle.build()
+    return pyoracle
+
+
+@pytest.fixture(scope="session")
+def hiplib():
+    from kofft_amd import _lib
+
+    return _lib.load()
+
+
+@pytest.fixture(scope="session")
+def fft32():
+    """A HipFftImpl<f32> on device 0 (GPU tests only)."""
+    from kofft_amd import HipFftImpl
+
+    return HipFftImpl(np.float32)
+
+
+@pytest.fixture(scope="session")
+def fft64():
+    from kofft_amd import HipFftImpl
+
+    return HipFftImpl(np.float64)
+
+
+GOLDEN = ROOT / "tests" / "golden"
+
+
+def seeded(seed: int):
+    return np.random.default_rng(seed)
+
+
+def rand_c(rng, shape, dtype=np.complex64):
+    real = np.float32 if dtype == np.complex64 else np.float64
+    return (rng.uniform(-1, 1, shape).astype(real) + 1j * rng.uniform(-1, 1, shape).astype(real)).astype(dtype)
+
+
+def bits_equal(a: np.ndarray, b: np.ndarray) -> bool:
+    """Bitwise equality (so -0.0 != 0.0 and NaN payloads count)."""
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    return a.shape == b.shape and a.dtype == b.dtype and a.tobytes() == b.tobytes()

@@ -1,0 +1,92 @@
+"""The C-ABI library loads without a GPU and exports exactly what include/kofft_hip.h declares."""
+import ctypes as C
+
+import numpy as np
+
+from conftest import bits_equal
+
+
+def test_library_loads_and_exports_every_declared_symbol(hiplib):
+    from kofft_amd import _lib
+
+    declared = _lib.header_symbols()
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(hiplib, name), f"{name} declared in include/kofft_hip.h but not exported"
+    assert sorted(_lib.SIGNATURES) == declared, "python prototypes out of step with the header"
+    assert b"gfx950" in hiplib.kofft_hip_version()
+
+
+def test_library_contains_gfx950_code_object():
+    from kofft_amd import _lib
+
+    blob = _lib.LIB_PATH.read_bytes()
+    assert b"gfx950" in blob and b"fft_wg_kernel" in blob
+
+
+def test_strerror_names_follow_ffterror_order(hiplib):
+    # fft.rs:447-454 declaration order
+    names = [b"EmptyInput", b"NonPowerOfTwoNoStd", b"MismatchedLengths", b"InvalidStride", b"InvalidHopSize",
+             b"InvalidValue"]
+    for code, name in enumerate(names, start=1):
+        assert name in hiplib.kofft_hip_strerror(code)
+    assert hiplib.kofft_hip_strerror(0) == b"Ok"
+
+
+def test_host_table_recipes_match_oracle_bit_for_bit(hiplib, oracle):
+    """The product's planner recipes (kofft_amd/csrc/tables.cpp) against the oracle's restatement."""
+    import kofft_amd
+
+    for n in (2, 8, 32, 1024, 4096, 65536):
+        assert bits_equal(kofft_amd.FftPlanner(np.float32).get_twiddles(n), oracle.get_twiddles(n, np.float32)), n
+        assert bits_equal(kofft_amd.FftPlanner(np.float64).get_twiddles(n), oracle.get_twiddles(n, np.float64)), n
+    for m in (1, 2, 16, 256, 1024, 2048):
+        assert bits_equal(kofft_amd.RfftPlanner(np.float32).get_twiddles(m), oracle.rfft_table(m, np.float32)), m
+        assert bits_equal(kofft_amd.RfftPlanner(np.float64).get_twiddles(m), oracle.rfft_table(m, np.float64)), m
+    for length in (1, 8, 1024, 2048):
+        assert bits_equal(kofft_amd.hann(length), oracle.hann(length))
+
+
+def test_planner_strategy_and_cache():
+    import kofft_amd
+
+    p = kofft_amd.FftPlanner()
+    assert p.plan_strategy(4096) is kofft_amd.FftStrategy.SplitRadix  # fft.rs:438-444
+    assert p.plan_strategy(12) is kofft_amd.FftStrategy.Auto
+    assert p.plan_strategy(1) is kofft_amd.FftStrategy.Auto
+    assert p.get_twiddles(8) is p.get_twiddles(8)  # tests/rfft_twiddles.rs:12-15: cached table reused
+
+
+def test_argument_validation_needs_no_device(hiplib):
+    """The reference's error order, checked through the C ABI with a null context (no GPU touched).
+    Every FftError variant the hot path can produce is covered; a valid request then reports the null context."""
+    null = C.c_void_p(None)
+    buf = np.zeros(64, np.float32)
+    p = C.c_void_p(buf.ctypes.data)
+    sz = C.c_size_t
+    # fft.rs:1056 / 1136
+    assert hiplib.kofft_hip_fft_c32(null, p, sz(0), sz(1), 0) == 1
+    assert hiplib.kofft_hip_fft_c64(null, p, sz(0), sz(1), 1) == 1
+    assert hiplib.kofft_hip_fft_c32(null, p, sz(0), sz(0), 0) == 0       # batch() over no slices
+    assert hiplib.kofft_hip_fft_c32(null, p, sz(1), sz(1), 0) == 0       # n == 1: Ok, nothing to do
+    assert hiplib.kofft_hip_fft_c32(null, p, sz(12), sz(1), 0) == -2     # Bluestein arm: unsupported
+    assert hiplib.kofft_hip_fft_c32(null, p, sz(1 << 20), sz(1), 0) == -2
+    assert hiplib.kofft_hip_fft_c32(null, p, sz(8), sz(1), 0) == -3      # valid request, null context
+    # fft.rs:1181-1190
+    assert hiplib.kofft_hip_fft_c32_strided(null, p, sz(8), sz(0), sz(4), 0) == 4
+    assert hiplib.kofft_hip_fft_c32_strided(null, p, sz(8), sz(2), sz(0), 0) == 0
+    assert hiplib.kofft_hip_fft_c32_strided(null, p, sz(6), sz(2), sz(4), 0) == 3
+    # rfft.rs:433-443 / 476-486
+    assert hiplib.kofft_hip_rfft_f32(null, p, p, None, sz(0), sz(1)) == 1
+    assert hiplib.kofft_hip_rfft_f32(null, p, p, None, sz(7), sz(1)) == 6
+    assert hiplib.kofft_hip_irfft_f32(null, p, p, sz(0), sz(1)) == 1
+    assert hiplib.kofft_hip_irfft_f64(null, p, p, sz(9), sz(1)) == 6
+    assert hiplib.kofft_hip_rfft_f32(null, p, p, None, sz(8), sz(1)) == -3
+    # stft.rs:83-89
+    assert hiplib.kofft_hip_stft_f32(null, p, sz(10), p, sz(4), sz(0), p, sz(3)) == 5
+    assert hiplib.kofft_hip_stft_f32(null, p, sz(10), p, sz(4), sz(4), p, sz(2)) == 3   # tests/stft.rs:6-14
+    assert hiplib.kofft_hip_stft_f32(null, p, sz(0), p, sz(4), sz(2), p, sz(0)) == 0
+    assert hiplib.kofft_hip_stft_f32(null, p, sz(10), p, sz(0), sz(4), p, sz(3)) == 1   # empty window -> fft(&mut [])
+    assert hiplib.kofft_hip_stft_parallel_f32(null, p, sz(10), p, sz(4), sz(0), p, sz(1)) == 5
+    assert hiplib.kofft_hip_stft_parallel_f32(null, p, sz(10), p, sz(4), sz(4), p, sz(2)) == -3  # no frames check
+    assert hiplib.kofft_hip_stft_f32_dev(null, p, sz(10), p, sz(4), sz(0), p, sz(0), sz(1)) == 5

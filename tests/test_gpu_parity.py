@@ -1,0 +1,300 @@
+"""Parity of the HIP path with the CPU oracle, through the C ABI (libkofft_hip.so), on a real MI355X.
+
+The bar (task section 3 / BASELINE north_star): <= 1e-5 relative f32 vs ScalarFftImpl's arithmetic.
+Because every butterfly performs the reference's un-fused operations on the reference's tables, the
+tests assert the stronger property: BIT-EXACT equality with the oracle (and with the committed
+golden vectors).  The tolerance constant is kept, written out, as the contractual fallback bar.
+"""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, bits_equal, rand_c, seeded
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL_F32 = 1e-5   # north_star: "within 1e-5 relative f32"
+REL_TOL_F64 = 1e-12
+
+
+def rel_err(a, b):
+    a = np.asarray(a).astype(np.complex128)
+    b = np.asarray(b).astype(np.complex128)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def assert_parity(got, want, what, tol):
+    if bits_equal(got, want):
+        return
+    err = rel_err(got, want)
+    nbad = int(np.sum(np.asarray(got).view(np.uint8) != np.asarray(want).view(np.uint8)))
+    raise AssertionError(f"{what}: not bit-exact ({nbad} differing bytes), rel L2 err {err:.3e} (contract bar {tol:g})")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    z = np.load(GOLDEN / "hotpath_golden.npz")
+    cases = {}
+    for key in z.files:
+        name, field = key.split("/")
+        cases.setdefault(name, {})[field] = z[key]
+    return cases
+
+
+# ---- complex FFT ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384])
+def test_fft_c32_matches_oracle(fft32, oracle, n):
+    rng = seeded(100 + n)
+    batch = 7 if n <= 4096 else 3  # not a multiple of the transforms-per-workgroup count
+    x = rand_c(rng, (batch, n))
+    y = x.copy()
+    fft32.fft_batch(y)
+    assert_parity(y, oracle.fft(x), f"fft c32 n={n}", REL_TOL_F32)
+    z = x.copy()
+    fft32.fft_batch(z, inverse=True)
+    assert_parity(z, oracle.ifft(x), f"ifft c32 n={n}", REL_TOL_F32)
+
+
+@pytest.mark.parametrize("n", [1, 2, 4, 8, 16, 32, 64, 256, 1024, 4096, 8192])
+def test_fft_c64_matches_oracle(fft64, oracle, n):
+    rng = seeded(200 + n)
+    x = rand_c(rng, (5, n), np.complex128)
+    y = x.copy()
+    fft64.fft_batch(y)
+    assert_parity(y, oracle.fft(x), f"fft c64 n={n}", REL_TOL_F64)
+    z = x.copy()
+    fft64.fft_batch(z, inverse=True)
+    assert_parity(z, oracle.ifft(x), f"ifft c64 n={n}", REL_TOL_F64)
+
+
+def test_golden_complex_vectors(fft32, fft64, gold):
+    for name, g in gold.items():
+        if not name.startswith(("c32_", "c64_")):
+            continue
+        impl = fft32 if name.startswith("c32_") else fft64
+        y = g["x"].copy()
+        impl.fft(y)
+        assert_parity(y, g["y"], name, REL_TOL_F32)
+        z = g["x"].copy()
+        impl.ifft(z)
+        assert_parity(z, g["y_inv"], name + " (ifft)", REL_TOL_F32)
+
+
+def test_reference_style_single_transforms(fft32, oracle):
+    """The reference's own test inputs, through the trait-shaped API (one slice at a time)."""
+    # tests/stockham_parity.rs:6-9
+    for n in (32, 64, 128, 256):
+        i = np.arange(n, dtype=np.float32)
+        data = (i - 1j * (i * np.float32(0.25))).astype(np.complex64)
+        expected = oracle.fft(data)
+        fft32.stockham_fft(data)
+        assert np.all(np.abs(data.real - expected.real) < 1e-3) and np.all(np.abs(data.imag - expected.imag) < 1e-3)
+        assert bits_equal(data, expected)
+    # tests/parallel_stockham.rs:7-10 (n = 4096)
+    i = np.arange(4096, dtype=np.float32)
+    data = (i + 1j * (2 * i)).astype(np.complex64)
+    expected = oracle.fft(data)
+    fft32.fft(data)
+    assert bits_equal(data, expected)
+    # lib.rs:178-199 impulse -> ones -> impulse
+    d = np.array([1, 0, 0, 0], np.complex64)
+    fft32.fft(d)
+    assert np.all(np.abs(d - 1) < 1e-6)
+    fft32.ifft(d)
+    assert abs(d[0] - 1) < 1e-6 and np.all(np.abs(d[1:]) < 1e-6)
+    # examples/basic_usage.rs:232-241 (BASELINE config #1): 1024-pt FFT of sin(0.1 i)
+    sig = np.sin(np.float32(0.1) * np.arange(1024, dtype=np.float32)).astype(np.complex64)
+    want = oracle.fft(sig)
+    fft32.fft(sig)
+    assert bits_equal(sig, want)
+
+
+def test_special_values_follow_ieee(fft32, oracle):
+    """Signed zeros, denormals and huge values take the same path as on the CPU (no flush, no shortcuts)."""
+    x = np.zeros((4, 64), np.complex64)
+    x[0, :] = -0.0
+    x[1, 3] = np.float32(1e-42) + 1j * np.float32(-3e-43)   # subnormal
+    x[2, :] = np.float32(3e37)                              # overflows to inf in the sum
+    x[3, 5] = np.float32(-0.0) + 1j * np.float32(2.5)
+    y = x.copy()
+    fft32.fft_batch(y)
+    want = oracle.fft(x)
+    assert y.tobytes() == want.tobytes()
+
+
+# ---- real FFT -------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [2, 4, 8, 16, 32, 64, 256, 2048, 8192, 32768])
+def test_rfft_f32_matches_oracle(fft32, oracle, n):
+    rng = seeded(300 + n)
+    x = rng.uniform(-1, 1, (6, n)).astype(np.float32)
+    got = fft32.rfft_batch(x)
+    want = oracle.rfft(x)
+    assert_parity(got, want, f"rfft f32 n={n}", REL_TOL_F32)
+    win = oracle.hann(n)
+    assert_parity(fft32.rfft_batch(x, win), oracle.rfft(x, win), f"rfft+hann f32 n={n}", REL_TOL_F32)
+    assert_parity(fft32.irfft_batch(want, n), oracle.irfft(want, n), f"irfft f32 n={n}", REL_TOL_F32)
+
+
+@pytest.mark.parametrize("n", [2, 8, 64, 1024, 16384])
+def test_rfft_f64_matches_oracle(fft64, oracle, n):
+    rng = seeded(400 + n)
+    x = rng.uniform(-1, 1, (3, n))
+    want = oracle.rfft(x)
+    assert_parity(fft64.rfft_batch(x), want, f"rfft f64 n={n}", REL_TOL_F64)
+    assert_parity(fft64.irfft_batch(want, n), oracle.irfft(want, n), f"irfft f64 n={n}", REL_TOL_F64)
+
+
+def test_golden_rfft_vectors(fft32, fft64, gold):
+    for name, g in gold.items():
+        if not name.startswith(("rfft32_", "rfft64_")):
+            continue
+        impl = fft32 if name.startswith("rfft32_") else fft64
+        x = g["x"][None, :]
+        got = impl.rfft_batch(np.ascontiguousarray(x), g.get("window"))
+        assert_parity(got[0], g["y"], name, REL_TOL_F32)
+        back = impl.irfft_batch(np.ascontiguousarray(g["y"][None, :]), g["x"].size)
+        assert_parity(back[0], g["x_back"], name + " (irfft)", REL_TOL_F32)
+
+
+def test_realfftimpl_trait_surface(fft32, fft64, oracle):
+    """rfft.rs:892-936 and tests/rfft_arch_parity.rs:11-27 through rfft_with_scratch / irfft_with_scratch."""
+    x = np.arange(1, 9, dtype=np.float32)
+    freq = np.zeros(5, np.complex64)
+    scratch = np.zeros(4, np.complex64)
+    fft32.rfft_with_scratch(x.copy(), freq, scratch)
+    assert bits_equal(freq, oracle.rfft(x))
+    out = np.zeros(8, np.float32)
+    fft32.irfft_with_scratch(freq, out, scratch)
+    assert np.all(np.abs(out - x) < 1e-5)
+    assert abs(freq[0].imag) < 1e-6 and abs(freq[-1].imag) < 1e-6  # lib.rs:451-467
+    # rfft_arch_parity: sin(i), size 32
+    s = np.sin(np.arange(32, dtype=np.float32)).astype(np.float32)
+    f32 = np.zeros(17, np.complex64)
+    fft32.rfft(s.copy(), f32)
+    want = oracle.rfft(s)
+    assert np.all(np.abs(f32.real - want.real) < 1e-5) and np.all(np.abs(f32.imag - want.imag) < 1e-5)
+    assert bits_equal(f32, want)
+    # f64 round trip (rfft.rs:921-936)
+    x64 = np.arange(1, 9, dtype=np.float64)
+    f64 = np.zeros(5, np.complex128)
+    fft64.rfft(x64.copy(), f64)
+    o64 = np.zeros(8)
+    fft64.irfft(f64, o64)
+    assert np.all(np.abs(o64 - x64) < 1e-10)
+
+
+# ---- STFT ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("win_len,hop,length", [(2, 1, 4), (4, 2, 8), (16, 4, 50), (64, 16, 1000), (256, 64, 3000),
+                                                (1024, 256, 10000), (1024, 256, 4096), (4096, 1024, 20000)])
+def test_stft_matches_oracle(fft32, oracle, win_len, hop, length):
+    rng = seeded(500 + win_len)
+    signal = rng.uniform(-1, 1, length).astype(np.float32)
+    window = oracle.hann(win_len)
+    frames = -(-length // hop) + 2  # two extra, fully/partly zero-padded frames (every provided frame is computed)
+    got = fft32.stft_into(signal, window, hop, frames)
+    want = oracle.stft(signal, window, hop, frames)
+    assert_parity(got, want, f"stft win={win_len} hop={hop} len={length}", REL_TOL_F32)
+
+
+def test_golden_stft_vectors(fft32, gold):
+    g = gold["stft32_4096_w1024_h256"]
+    got = fft32.stft_into(g["signal"], g["window"], int(g["hop"]), g["frames"].shape[0])
+    assert_parity(got, g["frames"], "golden stft", REL_TOL_F32)
+
+
+def test_stft_api_variants(fft32, oracle):
+    import kofft_amd as K
+
+    signal = np.arange(1, 9, dtype=np.float32)
+    window = np.ones(4, np.float32)
+    frames = [np.zeros(0, np.complex64) for _ in range(4)]  # vec![vec![]; 4]
+    K.stft(signal, window, 2, frames, fft32)
+    want = oracle.stft(signal, window, 2, 4)
+    assert all(bits_equal(f, w) for f, w in zip(frames, want))
+    # parallel(): same frames, and it accepts fewer frames than stft() demands (stft.rs:232-263)
+    few = [np.zeros(0, np.complex64) for _ in range(2)]
+    K.parallel(signal, window, 2, few, fft32)
+    assert all(bits_equal(f, w) for f, w in zip(few, want[:2]))
+    # frame() / StftStream (stft.rs:355-372, 160-206)
+    buf = np.zeros(4, np.complex64)
+    K.frame(signal, window, 6, buf, fft32)
+    assert bits_equal(buf, want[3])
+    stream = K.StftStream(signal, window, 2, fft32)
+    seen = []
+    while stream.next_frame(buf):
+        seen.append(buf.copy())
+    assert len(seen) == 4 and all(bits_equal(a, b) for a, b in zip(seen, want))
+    # all-zero window -> exact zeros (stft.rs:700-720)
+    z = fft32.stft_into(np.arange(1, 5, dtype=np.float32), np.zeros(2, np.float32), 1, 4)
+    assert np.all(z == 0)
+
+
+# ---- error behaviour through the mirrored API -------------------------------------------------------------
+def test_error_variants_match_reference(fft32):
+    import kofft_amd as K
+    from kofft_amd import FftError
+
+    def raises(variant, fn, *a):
+        with pytest.raises(FftError) as e:
+            fn(*a)
+        assert e.value.code == variant, (e.value, variant)
+
+    raises(FftError.EmptyInput, fft32.fft, np.zeros(0, np.complex64))                       # lib.rs:322-326
+    raises(FftError.EmptyInput, fft32.ifft, np.zeros(0, np.complex64))
+    raises(FftError.MismatchedLengths, fft32.fft_out_of_place, np.zeros(2, np.complex64), np.zeros(3, np.complex64))
+    raises(FftError.InvalidStride, fft32.fft_strided, np.zeros(8, np.complex64), 0, np.zeros(4, np.complex64))
+    raises(FftError.MismatchedLengths, fft32.fft_strided, np.zeros(6, np.complex64), 2, np.zeros(4, np.complex64))
+    raises(FftError.MismatchedLengths, fft32.rfft, np.zeros(4, np.float32), np.zeros(4, np.complex64))  # lib.rs:470
+    raises(FftError.EmptyInput, fft32.rfft, np.zeros(0, np.float32), np.zeros(1, np.complex64))
+    raises(FftError.InvalidValue, fft32.rfft, np.zeros(3, np.float32), np.zeros(2, np.complex64))
+    raises(FftError.MismatchedLengths, fft32.fft_split, np.zeros(4, np.float32), np.zeros(3, np.float32))
+    raises(FftError.InvalidHopSize, K.stft, np.ones(4, np.float32), np.ones(2, np.float32), 0, [None] * 4, fft32)
+    raises(FftError.MismatchedLengths, K.stft, np.zeros(10, np.float32), K.hann(4), 4, [None] * 2, fft32)  # tests/stft.rs
+    with pytest.raises(FftError):
+        K.StftStream(np.ones(4, np.float32), np.ones(2, np.float32), 0, fft32)
+    s = K.StftStream(np.ones(4, np.float32), np.ones(2, np.float32), 1, fft32)
+    raises(FftError.MismatchedLengths, s.next_frame, np.zeros(3, np.complex64))               # stft.rs:861-870
+    # single element / strategy plumbing
+    one = np.array([1 + 0j], np.complex64)
+    fft32.fft(one)
+    assert one[0] == 1 + 0j                                                                   # lib.rs:352-358
+    d = np.arange(8).astype(np.complex64)
+    e = d.copy()
+    fft32.fft_with_strategy(d, K.FftStrategy.SplitRadix)
+    fft32.fft(e)
+    assert bits_equal(d, e)
+    # non-power-of-two: outside the device path, reported (not silently mis-computed)
+    with pytest.raises(K.DeviceError):
+        fft32.fft(np.zeros(12, np.complex64))
+
+
+def test_strided_split_and_batch_helpers(fft32, fft64, oracle):
+    import kofft_amd as K
+
+    rng = seeded(9)
+    # fft_strided (fft.rs:1175-1199): every 3rd element, n = 16
+    buf = rand_c(rng, 48)
+    want = buf.copy()
+    want[::3] = oracle.fft(buf[::3].copy())
+    fft32.fft_strided(buf, 3, np.zeros(16, np.complex64))
+    assert bits_equal(buf, want)
+    # out-of-place strided
+    src = rand_c(rng, 64)
+    dst = np.zeros(32, np.complex64)
+    fft32.fft_out_of_place_strided(src, 4, dst, 2)
+    assert bits_equal(dst[::2], oracle.fft(src[::4].copy()))
+    # fft_split / ifft_split (tests/split64.rs)
+    n = 32
+    re = np.arange(n, dtype=np.float64)
+    im = np.zeros(n)
+    fft64.fft_split(re, im)
+    w = oracle.fft(np.arange(n).astype(np.complex128))
+    assert np.all(np.abs(re - w.real) < 1e-10) and np.all(np.abs(im - w.imag) < 1e-10)
+    fft64.ifft_split(re, im)
+    assert np.all(np.abs(re - np.arange(n)) < 1e-8)
+    # batch()/multi_channel() over a list of slices (fft.rs:2156-2191), ragged lengths included
+    vs = [rand_c(rng, 64), rand_c(rng, 64), rand_c(rng, 256)]
+    want = [oracle.fft(v) for v in vs]
+    K.batch(fft32, vs)
+    assert all(bits_equal(a, b) for a, b in zip(vs, want))
+    K.batch_inverse(fft32, vs)
+    assert all(bits_equal(a, oracle.ifft(b)) for a, b in zip(vs, want))
