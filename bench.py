@@ -41,8 +41,11 @@ WORKLOADS = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--ramp-ms", type=float, default=300.0,
+                    help="untimed pre-warm-up: keep the GPU busy this long so DVFS has left idle clocks "
+                         "(measured: per-launch time falls 1.17 -> 0.81 ms over the first ~40 ms of load)")
     ap.add_argument("--workload", default="fft4096", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override per-GPU batch (debug only; invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -53,11 +56,23 @@ def parse():
 # ---------------------------------------------------------------------------------------------------
 # cpu_baseline: the oracle (a port of kofft's CPU algorithm) on the host cores, bounded sample
 # ---------------------------------------------------------------------------------------------------
+def host_cores() -> int:
+    """Cores this process may actually use: affinity mask, capped by the cgroup CPU quota if there is one."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()[:2]
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return cores
+
+
 def cpu_baseline_fft4096(target_seconds: float):
     from oracle import pyoracle as ko
 
     n = 4096
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     rng = np.random.default_rng(0x6B6F666674 + 2)
 
     def make(batch):
@@ -123,7 +138,11 @@ def main():
         print(f"# note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
     fft = kofft_amd.HipFftImpl(np.float32, device=local_rank)
-    stream = torch.cuda.current_stream(dev)
+    # A dedicated (non-default) torch stream: the library launches on it and the HIP events below are
+    # recorded on the same stream, so each event pair brackets exactly one launch.
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
     fft.set_stream(stream.cuda_stream)
 
     gen = torch.Generator(device=dev)
@@ -174,6 +193,12 @@ def main():
         if world > 1:
             dist.barrier(device_ids=[local_rank])
 
+    # clock ramp (untimed, not counted as warm-up steps), then the W warm-up steps of the contract
+    t_ramp = time.perf_counter()
+    while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:
+        for _ in range(8):
+            launch()
+        torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         launch()
     torch.cuda.synchronize(dev)
@@ -202,6 +227,8 @@ def main():
     total_units = float(units.item()) * args.steps
 
     if rank == 0:
+        if os.environ.get("KOFFT_BENCH_VERBOSE"):
+            print("# per-launch ms: " + " ".join(f"{m:.3f}" for m in kern_ms), file=sys.stderr)
         avg_kernel_s = float(np.mean(kern_ms)) / 1e3
         achieved = alg_bytes / avg_kernel_s / 1e9
         traffic = None

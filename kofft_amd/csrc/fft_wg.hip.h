@@ -26,6 +26,7 @@ __host__ __device__ constexpr int lds_elems(int n) { return n + (n >> 4) + 1; }
 // FftImpl::fft (fft.rs:1054) / ifft (fft.rs:1134-1174: conj, fft, conj, *scale).
 template <typename T, bool INVERSE>
 struct ComplexIO {
+    static constexpr bool kStreams = true;  // cheap load/store: eligible for the persistent prefetching kernel
     const cpx<T> *__restrict__ in;
     cpx<T> *__restrict__ out;
     int n;
@@ -49,6 +50,7 @@ struct ComplexIO {
 
 // stft.rs:91-103: frame f starts at start0 + f*hop; x = signal[start+i]*window[i] or 0.
 struct StftIO {
+    static constexpr bool kStreams = true;
     const float *__restrict__ signal;
     const float *__restrict__ window;
     cpx<float> *__restrict__ out;
@@ -71,6 +73,7 @@ struct StftIO {
 // (rfft_post), which writes the m+1 outputs.
 template <typename T>
 struct RfftIO {
+    static constexpr bool kStreams = false;
     const T *__restrict__ in;         // batch rows of 2*m reals
     const T *__restrict__ window;     // 2*m reals or nullptr
     cpx<T> *__restrict__ out;         // batch rows of m+1 complex
@@ -103,6 +106,7 @@ struct RfftIO {
 // (conj, fft, conj, *1/m); output[2i], output[2i+1] = scratch[i].re, .im.
 template <typename T>
 struct IrfftIO {
+    static constexpr bool kStreams = false;  // two loads + a table entry per element: too many live registers to prefetch
     const cpx<T> *__restrict__ in;  // batch rows of m+1 complex
     cpx<T> *__restrict__ out;       // batch rows of m complex == 2*m reals
     const cpx<T> *__restrict__ rtab;

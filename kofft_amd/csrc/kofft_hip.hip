@@ -12,6 +12,7 @@
 #include <utility>
 #include <vector>
 
+#include "fft_persist.hip.h"
 #include "fft_wg.hip.h"
 #include "tables.h"
 
@@ -24,6 +25,7 @@ struct kofft_hip_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    int num_cus = 256;
     std::string last_error;
     // planner caches: (kind, n) -> device table.  kind 0/1 = FftPlanner twiddles f32/f64,
     // 2/3 = RfftPlanner post-pass table f32/f64.
@@ -134,6 +136,26 @@ int launch_wg(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t batch)
     return KOFFT_OK;
 }
 
+// Persistent, prefetching kernel (fft_persist.hip.h): the streaming path for large batches.
+// Two workgroups per CU, each with two LDS exchange buffers; every workgroup walks the batch with a
+// stride of the grid size and keeps the next transform's loads in flight while it computes.
+template <typename T, int L, class IO>
+int launch_persist(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t batch)
+{
+    constexpr int RL = 4, NBUF = 2, WG_PER_CU = 2;
+    constexpr int BLOCK = (1 << L) >> RL;
+    constexpr size_t lds = (size_t)NBUF * lds_elems(1 << L) * sizeof(cpx<T>);
+    static_assert(lds * WG_PER_CU <= 160 * 1024, "LDS budget");
+    auto kern = fft_persist_kernel<T, L, RL, NBUF, WG_PER_CU, IO>;
+    KOFFT_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    size_t blocks = (size_t)ctx->num_cus * WG_PER_CU;
+    if (blocks > batch) blocks = batch;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BLOCK), lds, ctx->stream, io, tw, batch);
+    KOFFT_HIP_TRY(ctx, hipGetLastError());
+    return KOFFT_OK;
+}
+
 template <typename T, int N, int EPI, class IO>
 int launch_small(kofft_hip_ctx *ctx, const IO &io, size_t batch)
 {
@@ -163,6 +185,10 @@ int dispatch(kofft_hip_ctx *ctx, const IO &io, size_t n, size_t batch)
     const cpx<T> *tw = nullptr;
     int rc = get_table<T>(ctx, Kind<T>::tw, n, &tw);
     if (rc) return rc;
+    if constexpr (sizeof(T) == 4 && EPI == EPI_STORE && IO::kStreams) {
+        // streaming sizes: enough transforms to give every resident workgroup several iterations
+        if (L == 12 && batch >= (size_t)ctx->num_cus * 4) return launch_persist<T, 12>(ctx, io, tw, batch);
+    }
     switch (L) {
 #define KOFFT_CASE(LL) \
     case LL: return launch_wg<T, LL, EPI>(ctx, io, tw, batch);
@@ -433,6 +459,11 @@ int kofft_hip_create(int device, kofft_hip_ctx **out)
     kofft_hip_ctx *ctx = new (std::nothrow) kofft_hip_ctx();
     if (!ctx) return KOFFT_ERR_ALLOC;
     ctx->device = device;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+            ctx->num_cus = prop.multiProcessorCount;
+    }
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return KOFFT_ERR_HIP;
