@@ -1,0 +1,171 @@
+//! `HipFftImpl<T>`: a drop-in `kofft::fft::FftImpl<T>` backed by the MI355X library (include/kofft_hip.h).
+//!
+//! Because `RealFftImpl<T>` is a blanket impl over every `FftImpl<T>` (kofft rfft.rs:837) and `stft()`,
+//! `StftStream`, `batch()` are generic over `FftImpl` (stft.rs:76, 160; fft.rs:2156), existing callers
+//! only change the type they construct.  The added inherent methods (`fft_batch`, `rfft_batch`,
+//! `stft_contiguous`) are the contiguous entry points that escape the `Vec<Vec<_>>` layout.
+//!
+//! SOURCE ONLY: written against kofft 0.1.5's public API; not compiled in the build image (no rustc).
+use core::ffi::{c_char, c_int, c_void};
+use core::marker::PhantomData;
+use kofft::fft::{Complex, Complex32, Complex64, FftError, FftImpl, FftStrategy};
+use kofft::num::Float;
+
+#[repr(C)]
+pub struct KofftHipCtx {
+    _private: [u8; 0],
+}
+
+extern "C" {
+    fn kofft_hip_create(device: c_int, out: *mut *mut KofftHipCtx) -> c_int;
+    fn kofft_hip_destroy(ctx: *mut KofftHipCtx) -> c_int;
+    fn kofft_hip_last_error(ctx: *const KofftHipCtx) -> *const c_char;
+    fn kofft_hip_fft_c32(ctx: *mut KofftHipCtx, data: *mut f32, n: usize, batch: usize, inverse: c_int) -> c_int;
+    fn kofft_hip_fft_c64(ctx: *mut KofftHipCtx, data: *mut f64, n: usize, batch: usize, inverse: c_int) -> c_int;
+    fn kofft_hip_fft_c32_strided(ctx: *mut KofftHipCtx, data: *mut f32, len: usize, stride: usize, n: usize, inverse: c_int) -> c_int;
+    fn kofft_hip_fft_c64_strided(ctx: *mut KofftHipCtx, data: *mut f64, len: usize, stride: usize, n: usize, inverse: c_int) -> c_int;
+    fn kofft_hip_rfft_f32(ctx: *mut KofftHipCtx, input: *const f32, out: *mut f32, window: *const f32, n: usize, batch: usize) -> c_int;
+    fn kofft_hip_stft_f32(ctx: *mut KofftHipCtx, signal: *const f32, len: usize, window: *const f32, win_len: usize,
+                          hop: usize, out: *mut f32, frames: usize) -> c_int;
+}
+
+/// 0 = Ok, 1..=6 = FftError in declaration order (kofft fft.rs:447-454).  FftError has no variant for a
+/// device failure, so a negative status (HIP error, unsupported length) panics with the library's message.
+fn status(ctx: *const KofftHipCtx, rc: c_int) -> Result<(), FftError> {
+    match rc {
+        0 => Ok(()),
+        1 => Err(FftError::EmptyInput),
+        2 => Err(FftError::NonPowerOfTwoNoStd),
+        3 => Err(FftError::MismatchedLengths),
+        4 => Err(FftError::InvalidStride),
+        5 => Err(FftError::InvalidHopSize),
+        6 => Err(FftError::InvalidValue),
+        _ => {
+            let msg = unsafe { std::ffi::CStr::from_ptr(kofft_hip_last_error(ctx)) }.to_string_lossy().into_owned();
+            panic!("kofft-hip device error {rc}: {msg}");
+        }
+    }
+}
+
+/// One device context per instance; `Send` but not `Sync`, like `ScalarFftImpl` (kofft fft.rs:589-605).
+pub struct HipFftImpl<T: Float> {
+    ctx: *mut KofftHipCtx,
+    _t: PhantomData<T>,
+}
+
+unsafe impl<T: Float> Send for HipFftImpl<T> {}
+
+impl<T: Float> HipFftImpl<T> {
+    pub fn new(device: i32) -> Self {
+        let mut ctx = core::ptr::null_mut();
+        let rc = unsafe { kofft_hip_create(device as c_int, &mut ctx) };
+        assert!(rc == 0 && !ctx.is_null(), "kofft_hip_create failed: {rc}");
+        Self { ctx, _t: PhantomData }
+    }
+}
+
+impl<T: Float> Default for HipFftImpl<T> {
+    fn default() -> Self {
+        Self::new(0)
+    }
+}
+
+impl<T: Float> Drop for HipFftImpl<T> {
+    fn drop(&mut self) {
+        unsafe { kofft_hip_destroy(self.ctx) };
+    }
+}
+
+macro_rules! impl_fft {
+    ($t:ty, $cplx:ty, $fft:ident, $strided:ident) => {
+        impl FftImpl<$t> for HipFftImpl<$t> {
+            // Complex<T> is #[repr(C)] {re, im} (kofft num.rs:105-110, tests/complex_repr.rs): a slice of n
+            // complex values is 2n scalars.
+            fn fft(&self, input: &mut [$cplx]) -> Result<(), FftError> {
+                status(self.ctx, unsafe { $fft(self.ctx, input.as_mut_ptr() as *mut $t, input.len(), 1, 0) })
+            }
+            fn ifft(&self, input: &mut [$cplx]) -> Result<(), FftError> {
+                status(self.ctx, unsafe { $fft(self.ctx, input.as_mut_ptr() as *mut $t, input.len(), 1, 1) })
+            }
+            fn fft_strided(&self, input: &mut [$cplx], stride: usize, scratch: &mut [$cplx]) -> Result<(), FftError> {
+                status(self.ctx, unsafe {
+                    $strided(self.ctx, input.as_mut_ptr() as *mut $t, input.len(), stride, scratch.len(), 0)
+                })
+            }
+            fn ifft_strided(&self, input: &mut [$cplx], stride: usize, scratch: &mut [$cplx]) -> Result<(), FftError> {
+                status(self.ctx, unsafe {
+                    $strided(self.ctx, input.as_mut_ptr() as *mut $t, input.len(), stride, scratch.len(), 1)
+                })
+            }
+            fn fft_out_of_place_strided(&self, input: &[$cplx], in_stride: usize, output: &mut [$cplx],
+                                        out_stride: usize) -> Result<(), FftError> {
+                // same checks, same order as kofft fft.rs:1268-1277
+                if in_stride == 0 || out_stride == 0 { return Err(FftError::InvalidStride); }
+                if input.len() % in_stride != 0 || output.len() % out_stride != 0 { return Err(FftError::InvalidStride); }
+                let n = input.len() / in_stride;
+                if output.len() / out_stride != n { return Err(FftError::MismatchedLengths); }
+                let mut scratch: Vec<$cplx> = (0..n).map(|i| input[i * in_stride]).collect();
+                self.fft(&mut scratch)?;
+                for i in 0..n { output[i * out_stride] = scratch[i]; }
+                Ok(())
+            }
+            fn ifft_out_of_place_strided(&self, input: &[$cplx], in_stride: usize, output: &mut [$cplx],
+                                         out_stride: usize) -> Result<(), FftError> {
+                if in_stride == 0 || out_stride == 0 { return Err(FftError::InvalidStride); }
+                if input.len() % in_stride != 0 || output.len() % out_stride != 0 { return Err(FftError::InvalidStride); }
+                let n = input.len() / in_stride;
+                if output.len() / out_stride != n { return Err(FftError::MismatchedLengths); }
+                let mut scratch: Vec<$cplx> = (0..n).map(|i| input[i * in_stride]).collect();
+                self.ifft(&mut scratch)?;
+                for i in 0..n { output[i * out_stride] = scratch[i]; }
+                Ok(())
+            }
+            fn fft_with_strategy(&self, input: &mut [$cplx], _strategy: FftStrategy) -> Result<(), FftError> {
+                // kofft fft.rs:1337-1363: every strategy reaches the Stockham path for powers of two
+                if input.is_empty() { return Err(FftError::EmptyInput); }
+                if input.len() == 1 { return Ok(()); }
+                self.fft(input)
+            }
+        }
+
+        impl HipFftImpl<$t> {
+            /// `fft::batch` over one contiguous `[batch * n]` buffer (one kernel launch).
+            pub fn fft_batch(&self, data: &mut [$cplx], n: usize, inverse: bool) -> Result<(), FftError> {
+                if n != 0 && data.len() % n != 0 { return Err(FftError::MismatchedLengths); }
+                let batch = if n == 0 { 1 } else { data.len() / n };
+                status(self.ctx, unsafe { $fft(self.ctx, data.as_mut_ptr() as *mut $t, n, batch, inverse as c_int) })
+            }
+        }
+    };
+}
+
+impl_fft!(f32, Complex32, kofft_hip_fft_c32, kofft_hip_fft_c32_strided);
+impl_fft!(f64, Complex64, kofft_hip_fft_c64, kofft_hip_fft_c64_strided);
+
+impl HipFftImpl<f32> {
+    /// Batched real FFT with an optional fused window: `out` holds `batch * (n/2 + 1)` complex values.
+    pub fn rfft_batch(&self, input: &[f32], n: usize, window: Option<&[f32]>, out: &mut [Complex<f32>]) -> Result<(), FftError> {
+        if n == 0 { return Err(FftError::EmptyInput); }
+        let batch = input.len() / n;
+        if input.len() % n != 0 || out.len() != batch * (n / 2 + 1) { return Err(FftError::MismatchedLengths); }
+        if let Some(w) = window { if w.len() != n { return Err(FftError::MismatchedLengths); } }
+        let wp = window.map_or(core::ptr::null(), |w| w.as_ptr());
+        status(self.ctx, unsafe { kofft_hip_rfft_f32(self.ctx, input.as_ptr(), out.as_mut_ptr() as *mut f32, wp, n, batch) })
+    }
+
+    /// `stft::stft` into one contiguous `frames * window.len()` buffer (same checks as kofft stft.rs:83-89).
+    pub fn stft_contiguous(&self, signal: &[f32], window: &[f32], hop_size: usize, out: &mut [Complex32]) -> Result<(), FftError> {
+        let frames = if window.is_empty() { 0 } else { out.len() / window.len() };
+        status(self.ctx, unsafe {
+            kofft_hip_stft_f32(self.ctx, signal.as_ptr(), signal.len(), window.as_ptr(), window.len(), hop_size,
+                               out.as_mut_ptr() as *mut f32, frames)
+        })
+    }
+}
+
+#[allow(dead_code)]
+fn _assert_traits() {
+    fn is_fft_impl<F: FftImpl<f32>>() {}
+    is_fft_impl::<HipFftImpl<f32>>();
+    let _ = core::mem::size_of::<*mut c_void>();
+}

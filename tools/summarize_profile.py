@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Condense a tools/profile.sh output directory (gpurun_out/prof_<tag>/) into profiles/<name>.md + .json.
+
+HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md section HBM: FETCH_SIZE and WRITE_SIZE are in KiB,
+collected in separate --pmc passes; on gfx950 FETCH_SIZE reports exactly half of the bytes of a coalesced
+streaming read, so it is doubled; WRITE_SIZE is exact for streaming stores."""
+import csv
+import glob
+import json
+import sys
+from collections import defaultdict
+from pathlib import Path
+
+
+def short(name: str) -> str:
+    name = name.replace("void kofft::", "").replace("kofft::", "")
+    return name if len(name) < 160 else name[:157] + "..."
+
+
+def main():
+    src, name, workload = Path(sys.argv[1]), sys.argv[2], sys.argv[3]
+    out_dir = Path(__file__).resolve().parent.parent / "profiles"
+    out_dir.mkdir(exist_ok=True)
+    summary = {"source": str(src), "workload": workload, "kernels": [], "pmc": {}}
+    lines = [f"# rocprofv3 summary `{name}` (workload `{workload}`)", "",
+             "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline ...`",
+             "(PMC counters in separate passes: `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, `--pmc SQ_*`; tools/profile.sh)", "",
+             "## Kernel stats (--kernel-trace --stats)", "", "| kernel | calls | avg us | min us | max us | % |", "|---|---|---|---|---|---|"]
+    for f in glob.glob(str(src / "trace" / "**" / "*_kernel_stats.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = {"name": short(r["Name"]), "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
+                 "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"]), "pct": float(r["Percentage"])}
+            if "kofft" in r["Name"] or k["pct"] > 1.0:
+                summary["kernels"].append(k)
+                lines.append(f"| `{k['name']}` | {k['calls']} | {k['avg_ns'] / 1e3:.1f} | {k['min_ns'] / 1e3:.1f} | "
+                             f"{k['max_ns'] / 1e3:.1f} | {k['pct']:.2f} |")
+    # per-dispatch resources from the kernel trace
+    for f in glob.glob(str(src / "trace" / "**" / "*_kernel_trace.csv"), recursive=True):
+        seen = set()
+        for r in csv.DictReader(open(f)):
+            if "kofft" in r["Kernel_Name"] and r["Kernel_Name"] not in seen:
+                seen.add(r["Kernel_Name"])
+                lines += ["", f"Dispatch of `{short(r['Kernel_Name'])}`: grid {r.get('Grid_Size_X', r.get('Grid_Size', '?'))}, "
+                          f"workgroup {r.get('Workgroup_Size_X', r.get('Workgroup_Size', '?'))}, LDS {r.get('LDS_Block_Size', '?')} B, "
+                          f"VGPR {r.get('VGPR_Count', '?')}, SGPR {r.get('SGPR_Count', '?')}, scratch {r.get('Scratch_Size', '?')} B"]
+    agg = defaultdict(list)
+    for tag in ("pmc_fetch", "pmc_write", "pmc_sq"):
+        for f in glob.glob(str(src / tag / "**" / "*_counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if "kofft" in r["Kernel_Name"]:
+                    agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    lines += ["", "## PMC (mean per launch of the kofft kernel)", "", "| counter | launches | mean |", "|---|---|---|"]
+    for k, v in sorted(agg.items()):
+        summary["pmc"][k] = sum(v) / len(v)
+        lines.append(f"| {k} | {len(v)} | {sum(v) / len(v):.6g} |")
+    if "FETCH_SIZE" in agg and "WRITE_SIZE" in agg:
+        fetch = summary["pmc"]["FETCH_SIZE"] * 1024 * 2  # gfx950: half-counted coalesced reads (guide section HBM)
+        write = summary["pmc"]["WRITE_SIZE"] * 1024
+        summary["hbm_bytes_per_launch"] = fetch + write
+        summary["hbm_read_bytes"] = fetch
+        summary["hbm_write_bytes"] = write
+        lines += ["", f"HBM traffic per launch (guide's gfx950 correction: FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024): "
+                  f"read {fetch / 1e9:.4f} GB + write {write / 1e9:.4f} GB = **{(fetch + write) / 1e9:.4f} GB**"]
+        (out_dir / "traffic_latest.json").write_text(json.dumps(
+            {"workload": workload, "hbm_bytes_per_launch": fetch + write, "from": f"profiles/{name}.md"}) + "\n")
+    if "SQ_LDS_BANK_CONFLICT" in agg:
+        lines += ["", f"LDS bank-conflict cycles / LDS active cycles: {summary['pmc']['SQ_LDS_BANK_CONFLICT']:.0f} / "
+                  f"{summary['pmc'].get('SQ_LDS_IDX_ACTIVE', 0):.0f}"]
+    for logname in ("trace_bench.log",):
+        p = src / logname
+        if p.exists():
+            js = [ln for ln in p.read_text().splitlines() if ln.startswith("{")]
+            if js:
+                b = json.loads(js[-1])
+                summary["bench_under_profiler"] = {k: b[k] for k in ("value", "unit", "ms_per_step", "roofline")}
+                lines += ["", f"bench.py under the profiler: {b['value']:.1f} {b['unit']}, kernel avg {b['roofline']['kernel_ms_avg']:.4f} ms "
+                          f"(HIP events) -- compare with the --stats average above."]
+    (out_dir / f"{name}.md").write_text("\n".join(lines) + "\n")
+    (out_dir / f"{name}.json").write_text(json.dumps(summary, indent=1) + "\n")
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
