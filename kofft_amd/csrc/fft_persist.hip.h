@@ -3,14 +3,22 @@
 // Same arithmetic and pass structure as fft_wg_kernel (fft_wg.hip.h), re-organised around what the
 // MI355X memory system needs to stream at its copy ceiling:
 //   * the grid is sized to the chip (a few workgroups per CU) and every workgroup loops over
-//     transforms  xf = blockIdx.x, blockIdx.x + gridDim.x, ...;
+//     transforms with a stride of the whole grid;
 //   * the NEXT transform's global loads are issued into a second register set before the current
-//     transform is computed, so every resident workgroup always has a full transform (32 KiB at
-//     n = 4096) of HBM reads in flight while it works on butterflies and LDS exchanges;
-//   * the twiddles of every pass are read from the reference-recipe table ONCE per workgroup into
-//     registers (they depend on the thread, not on the transform), which removes the per-transform
-//     table traffic (30 KiB per 32 KiB transform at n = 4096) and its L2 latency from the loop.
+//     transform is computed, so every resident wave always has a full share of a transform of HBM
+//     reads in flight while it works on butterflies and LDS exchanges;
+//   * everything that depends on the thread but not on the transform is read ONCE per workgroup into
+//     registers: the twiddles of passes 1.. (pass 0's indices are compile-time constants -> scalar
+//     loads), the window samples of STFT/rfft framing, the rfft post-pass table entries;
+//   * n = 4096 (256 threads per transform): two LDS exchange buffers, 2 barriers per transform;
+//     n = 1024 (64 threads = one wavefront per transform): the exchange is wave-synchronous, no
+//     s_barrier at all -- the four waves of a workgroup free-run.
 // Results are bit-identical to fft_wg_kernel: the same butterflies consume the same table entries.
+//
+// IO policies used here split `load` into a prefetchable part and a per-thread invariant:
+//   Raw   fetch(xf, i)            -- the HBM read (kept in flight in the second register set)
+//   Inv   invariant(i)            -- transform-independent operand (window sample), read once
+//   cpx   finish(xf, i, raw, inv) -- the value the FFT sees
 #pragma once
 
 #include "fft_wg.hip.h"
@@ -61,7 +69,18 @@ struct PassGeom {
     static constexpr int Q = (P == NP - 1) ? (L - RL * (NP - 1)) : RL;
     static constexpr int G = R >> Q;
     static constexpr int JB = L - S0 - Q;
-    static constexpr int TWN = G * ((1 << Q) - 1);  // twiddles this thread needs for the pass
+    // element index handled by register u = g*2^Q + c of thread tau, as pass input / output
+    __device__ static constexpr int in_index(int tau, int u)
+    {
+        const int g = u >> Q, c = u & ((1 << Q) - 1);
+        const int m = tau + g * TPT;
+        return ((m >> JB) << (L - S0)) | (c << JB) | (m & ((1 << JB) - 1));
+    }
+    __device__ static constexpr int out_index(int tau, int u)
+    {
+        const int g = u >> Q, c = u & ((1 << Q) - 1);
+        return (bitrev(c, Q) << (L - Q)) | (tau + g * TPT);
+    }
 };
 
 template <typename T, int L, int RL, int P>
@@ -92,113 +111,221 @@ __device__ __forceinline__ void persist_compute_p0(cpx<T> *v, const cpx<T> *__re
     for (int g = 0; g < Gm::G; ++g) reg_pass<T, L, 0, Gm::Q>(v + g * (1 << Gm::Q), 0, tw);
 }
 
+// LDS / global addressing.  in_index(tau, u) and out_index(tau, u) are concatenations of disjoint bit
+// fields, one set of bits coming from the thread and the other from the register number, so
+//   index(tau, u) = index(tau, 0) + index(0, u)     and     lds_pad(a + b) = lds_pad(a) + lds_pad(b)
+// (no carry can cross bit 4).  Every access is therefore "one per-thread base (a VGPR computed once) +
+// a compile-time constant", which the hardware takes as an immediate offset.
 template <typename T, int L, int RL, int P>
-__device__ __forceinline__ void persist_lds_gather(cpx<T> *v, const cpx<T> *buf, const int tau)
+__device__ __forceinline__ void persist_lds_gather(cpx<T> *v, const cpx<T> *buf, const int gather_base)
 {
     using Gm = PassGeom<L, RL, P>;
+    const cpx<T> *p = buf + gather_base;  // gather_base = lds_pad(in_index(tau, 0))
 #pragma unroll
-    for (int g = 0; g < Gm::G; ++g) {
-        const int m = tau + g * Gm::TPT;
-        const int k = m >> Gm::JB;
-        const int j = m & ((1 << Gm::JB) - 1);
-#pragma unroll
-        for (int c = 0; c < (1 << Gm::Q); ++c) v[g * (1 << Gm::Q) + c] = buf[lds_pad((k << (L - Gm::S0)) | (c << Gm::JB) | j)];
-    }
+    for (int u = 0; u < Gm::R; ++u) v[u] = p[lds_pad(Gm::in_index(0, u))];
 }
 
 template <typename T, int L, int RL, int P>
-__device__ __forceinline__ void persist_lds_scatter(const cpx<T> *v, cpx<T> *buf, const int tau)
+__device__ __forceinline__ void persist_lds_scatter(const cpx<T> *v, cpx<T> *buf, const int scatter_base)
 {
     using Gm = PassGeom<L, RL, P>;
+    cpx<T> *p = buf + scatter_base;  // scatter_base = lds_pad(out_index(tau, 0)) = lds_pad(tau)
 #pragma unroll
-    for (int g = 0; g < Gm::G; ++g) {
-        const int m = tau + g * Gm::TPT;
-#pragma unroll
-        for (int c = 0; c < (1 << Gm::Q); ++c) buf[lds_pad((bitrev(c, Gm::Q) << (L - Gm::Q)) | m)] = v[g * (1 << Gm::Q) + c];
-    }
+    for (int u = 0; u < Gm::R; ++u) p[lds_pad(Gm::out_index(0, u))] = v[u];
 }
 
-template <typename T, int L, int RL, class IO>
-__device__ __forceinline__ void persist_global_gather(cpx<T> *v, const IO &io, const size_t xf, const int tau)
+// Exchange synchronisation: a transform owned by one wavefront needs no s_barrier -- a wave's LDS
+// instructions execute in order, so only the compiler must be kept from reordering them.
+template <bool WAVE>
+__device__ __forceinline__ void exchange_sync()
 {
-    using Gm = PassGeom<L, RL, 0>;
-#pragma unroll
-    for (int g = 0; g < Gm::G; ++g) {
-        const int m = tau + g * Gm::TPT;
-        const int k = m >> Gm::JB;
-        const int j = m & ((1 << Gm::JB) - 1);
-#pragma unroll
-        for (int c = 0; c < (1 << Gm::Q); ++c) v[g * (1 << Gm::Q) + c] = io.load(xf, (k << L) | (c << Gm::JB) | j);
+    if constexpr (WAVE) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
     }
 }
 
-template <typename T, int L, int RL, class IO>
-__device__ __forceinline__ void persist_global_scatter(const cpx<T> *v, const IO &io, const size_t xf, const int tau)
-{
-    using Gm = PassGeom<L, RL, (L + RL - 1) / RL - 1>;
-#pragma unroll
-    for (int g = 0; g < Gm::G; ++g) {
-        const int m = tau + g * Gm::TPT;
-#pragma unroll
-        for (int c = 0; c < (1 << Gm::Q); ++c) io.store(xf, (bitrev(c, Gm::Q) << (L - Gm::Q)) | m, v[g * (1 << Gm::Q) + c]);
-    }
-}
+// Everything a thread keeps across transforms.
+template <typename T, int L, int RL, int EPI, class IO>
+struct PersistState {
+    static constexpr int R = 1 << RL;
+    cpx<T> tw1[R - 1], tw2[R - 1];
+    typename IO::Inv inv[IO::kInvInLds ? 1 : R];  // window samples etc. (registers unless the policy stages them in LDS)
+    const typename IO::Inv *inv_lds;               // [N], natural order (kInvInLds)
+    const cpx<T> *rt_lds;                          // rfft post-pass table W[k], k < N (EPI_RFFT)
+    int g1, g2, sc;  // LDS bases: pass-1 gather, pass-2 gather, scatter
+};
 
-// One transform per workgroup at a time (TPT == BLOCK), 2 or 3 register passes.
-// NBUF = 1: one LDS exchange buffer, 4 barriers per 3-pass transform.
-// NBUF = 2: exchanges alternate between two buffers, 2 barriers per 3-pass transform.
-template <typename T, int L, int RL, int NBUF, int MINW, class IO>
-__global__ __launch_bounds__((1 << L) >> RL, MINW) void fft_persist_kernel(const IO io, const cpx<T> *__restrict__ tw,
-                                                                           const size_t batch)
+// One transform: raw[] holds its (already landed or still in flight) inputs.
+template <typename T, int L, int RL, int BLOCK, int NBUF, int EPI, class IO>
+__device__ __forceinline__ void persist_transform(const typename IO::Raw *raw, const PersistState<T, L, RL, EPI, IO> &st,
+                                                  const IO &io, const cpx<T> *__restrict__ tw, cpx<T> *buf0, cpx<T> *buf1,
+                                                  const size_t xf, const bool active, const int tau)
 {
     constexpr int N = 1 << L;
     constexpr int R = 1 << RL;
+    constexpr int TPT = N / R;
     constexpr int NP = (L + RL - 1) / RL;
+    constexpr bool WAVE = (TPT == 64);
+    using LastG = PassGeom<L, RL, NP - 1>;
+    using FirstG = PassGeom<L, RL, 0>;
+
+    cpx<T> cur[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+        const int i = FirstG::in_index(0, u) + tau;
+        if constexpr (IO::kInvInLds) cur[u] = io.finish(xf, i, raw[u], (st.inv_lds + tau)[FirstG::in_index(0, u)]);
+        else cur[u] = io.finish(xf, i, raw[u], st.inv[u]);
+    }
+
+    persist_compute_p0<T, L, RL>(cur, tw);
+    if (NBUF == 1) exchange_sync<WAVE>();  // the previous transform's last LDS gathers are done
+    persist_lds_scatter<T, L, RL, 0>(cur, buf0, st.sc);
+    exchange_sync<WAVE>();
+    persist_lds_gather<T, L, RL, 1>(cur, buf0, st.g1);
+    persist_compute<T, L, RL, 1>(cur, st.tw1);
+    if constexpr (NP == 3) {
+        if (NBUF == 1) exchange_sync<WAVE>();
+        persist_lds_scatter<T, L, RL, 1>(cur, buf1, st.sc);
+        exchange_sync<WAVE>();
+        persist_lds_gather<T, L, RL, 2>(cur, buf1, st.g2);
+        persist_compute<T, L, RL, 2>(cur, st.tw2);
+    }
+
+    if constexpr (EPI == EPI_RFFT) {
+        // rfft.rs:450-463: Y in natural order through LDS, then X[k] from Y[k], Y[m-k]
+        cpx<T> *ybuf = (NP == 3) ? buf0 : buf1;  // not the buffer the last gather read from (when NBUF == 2)
+        if (NBUF == 1) exchange_sync<WAVE>();
+        persist_lds_scatter<T, L, RL, NP - 1>(cur, ybuf, st.sc);
+        exchange_sync<WAVE>();
+        if (active) {
+            const rsrc_t od = io.out_desc(xf);
+            const int lane_bytes = tau * (int)sizeof(cpx<T>);
+#pragma unroll
+            for (int g = 0; g < R; ++g) {
+                const int k = tau + g * TPT;
+                if (g == 0 && tau == 0) {
+                    const cpx<T> y0 = ybuf[lds_pad(0)];
+                    io.store_d(od, 0, 0, mk<T>(y0.re + y0.im, T(0)));
+                    io.store_d(od, 0, N, mk<T>(y0.re - y0.im, T(0)));
+                } else {
+                    io.store_d(od, lane_bytes, g * TPT, io.post_w((st.rt_lds + tau)[g * TPT], ybuf[lds_pad(k)], ybuf[lds_pad(N - k)]));
+                }
+            }
+        }
+        if (NBUF == 2) exchange_sync<WAVE>();  // ybuf is the next transform's first exchange buffer
+    } else {
+        if (active) {
+            const rsrc_t od = io.out_desc(xf);
+            const int lane_bytes = tau * (int)sizeof(cpx<T>);
+#pragma unroll
+            for (int u = 0; u < R; ++u) io.store_d(od, lane_bytes, LastG::out_index(0, u), cur[u]);
+        }
+    }
+}
+
+// BLOCK threads carry XPB = BLOCK/TPT transforms at a time (TPT = N/16 threads each).
+// NBUF = 1: one LDS exchange buffer per transform slot; NBUF = 2 (block-synchronised sizes): exchanges
+// alternate between two buffers, which halves the number of barriers.
+template <typename T, int L, int RL, int BLOCK, int NBUF, int MINW, int EPI, class IO>
+__global__ __launch_bounds__(BLOCK, MINW) void fft_persist_kernel(const IO io, const cpx<T> *__restrict__ tw,
+                                                                  const size_t batch)
+{
+    constexpr int N = 1 << L;
+    constexpr int R = 1 << RL;
+    constexpr int TPT = N / R;
+    constexpr int XPB = BLOCK / TPT;
+    constexpr int NP = (L + RL - 1) / RL;
+    constexpr bool WAVE = (TPT == 64);  // one wavefront per transform
+    static_assert(TPT >= 64 && BLOCK % TPT == 0, "persistent kernel: at least one wavefront per transform");
     static_assert(NP == 2 || NP == 3, "persistent kernel is built for 2 or 3 register passes");
-    static_assert(NBUF == 1 || NBUF == 2, "NBUF");
+    static_assert(NBUF == 1 || (NBUF == 2 && !WAVE), "NBUF");
+    using FirstG = PassGeom<L, RL, 0>;
+    using Raw = typename IO::Raw;
 
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    cpx<T> *buf0 = reinterpret_cast<cpx<T> *>(smem_raw);
+    const int tid = threadIdx.x;
+    const int tau = tid % TPT;
+    // TPT is a multiple of the wavefront size, so the slot is wave-uniform: keep it in an SGPR so that the
+    // "is this transform inside the batch" tests below are scalar branches around whole groups of loads.
+    const int slot = __builtin_amdgcn_readfirstlane(tid / TPT);
+    cpx<T> *buf0 = reinterpret_cast<cpx<T> *>(smem_raw) + (size_t)slot * NBUF * lds_elems(N);
     cpx<T> *buf1 = (NBUF == 2) ? buf0 + lds_elems(N) : buf0;
 
-    const int tau = threadIdx.x;
+    // ---- per-thread invariants, fetched once
+    PersistState<T, L, RL, EPI, IO> st;
+    persist_load_tw<T, L, RL, 1>(st.tw1, tau, tw);
+    if constexpr (NP == 3) persist_load_tw<T, L, RL, 2>(st.tw2, tau, tw);
+    {
+        // transform-independent operands: registers, or (kInvInLds / rfft table) one LDS copy per workgroup
+        char *extra = smem_raw + (size_t)XPB * NBUF * lds_elems(N) * sizeof(cpx<T>);
+        typename IO::Inv *inv_lds = reinterpret_cast<typename IO::Inv *>(extra);
+        cpx<T> *rt_lds = reinterpret_cast<cpx<T> *>(extra + (IO::kInvInLds ? N * sizeof(typename IO::Inv) : 0));
+        if constexpr (IO::kInvInLds) {
+            for (int i = tid; i < N; i += BLOCK) inv_lds[i] = io.invariant(i);
+        } else {
+#pragma unroll
+            for (int u = 0; u < R; ++u) st.inv[u] = io.invariant(FirstG::in_index(0, u) + tau);
+        }
+        if constexpr (EPI == EPI_RFFT) {
+            for (int i = tid; i < N; i += BLOCK) rt_lds[i] = io.rtab[i];
+        }
+        st.inv_lds = inv_lds;
+        st.rt_lds = rt_lds;
+        if constexpr (IO::kInvInLds || EPI == EPI_RFFT) __syncthreads();
+    }
+    st.g1 = lds_pad(PassGeom<L, RL, 1>::in_index(tau, 0));
+    st.g2 = (NP == 3) ? lds_pad(PassGeom<L, RL, NP - 1>::in_index(tau, 0)) : 0;
+    st.sc = lds_pad(tau);
 
-    // per-thread twiddles of passes 1.., fetched once.  Pass 0 has k == 0: its table indices are
-    // compile-time constants, so it reads the table through scalar loads (SGPRs), not VGPRs.
-    cpx<T> tw1[R - 1], tw2[R - 1];
-    persist_load_tw<T, L, RL, 1>(tw1, tau, tw);
-    if constexpr (NP == 3) persist_load_tw<T, L, RL, 2>(tw2, tau, tw);
+    const size_t step = (size_t)gridDim.x * XPB;
+    size_t base = (size_t)blockIdx.x * XPB;
+    if (base >= batch) return;  // the whole workgroup leaves together
 
-    size_t xf = blockIdx.x;
-    if (xf >= batch) return;  // whole workgroup leaves together: no barrier is skipped by part of it
-
-    cpx<T> cur[R], nxt[R];
-    persist_global_gather<T, L, RL>(cur, io, xf, tau);
+    // Two raw register sets, A and B, swap roles every transform (no register copies): while the transform
+    // held in one set is computed, the other set receives the next transform's loads.
+    Raw ra[R], rb[R];
+    const int in_lane_bytes = tau * IO::kRawBytes;
+    {
+        const rsrc_t d = io.in_desc(base + slot, base + slot < batch);
+#pragma unroll
+        for (int u = 0; u < R; ++u) ra[u] = io.fetch_d(d, in_lane_bytes, FirstG::in_index(0, u));
+    }
 
     for (;;) {
-        const size_t nxf = xf + gridDim.x;
-        const bool more = nxf < batch;  // workgroup-uniform
-        if (more) persist_global_gather<T, L, RL>(nxt, io, nxf, tau);  // prefetch: stays in flight below
-
-        persist_compute_p0<T, L, RL>(cur, tw);
-        if (NBUF == 1) __syncthreads();  // previous transform's last LDS gathers are done
-        persist_lds_scatter<T, L, RL, 0>(cur, buf0, tau);
-        __syncthreads();
-        persist_lds_gather<T, L, RL, 1>(cur, buf0, tau);
-        persist_compute<T, L, RL, 1>(cur, tw1);
-        if constexpr (NP == 3) {
-            if (NBUF == 1) __syncthreads();
-            persist_lds_scatter<T, L, RL, 1>(cur, buf1, tau);
-            __syncthreads();
-            persist_lds_gather<T, L, RL, 2>(cur, buf1, tau);
-            persist_compute<T, L, RL, 2>(cur, tw2);
-        }
-        persist_global_scatter<T, L, RL>(cur, io, xf, tau);
-
-        if (!more) break;
+        {   // ---- transform in A, prefetch into B
+            const size_t nbase = base + step;
+            const bool more = nbase < batch;  // workgroup-uniform
+            {
+                // Unconditional loads through a descriptor that is EMPTY when there is no next transform: the
+                // bounds check then returns zeros without touching memory.  No branch, so the loads carry no
+                // register shuffles behind them and stay in flight until their first use one transform later.
+                const rsrc_t d = io.in_desc(nbase + slot, nbase + slot < batch);
 #pragma unroll
-        for (int i = 0; i < R; ++i) cur[i] = nxt[i];
-        xf = nxf;
+                for (int u = 0; u < R; ++u) rb[u] = io.fetch_d(d, in_lane_bytes, FirstG::in_index(0, u));
+            }
+            persist_transform<T, L, RL, BLOCK, NBUF, EPI>(ra, st, io, tw, buf0, buf1, base + slot, base + slot < batch, tau);
+            if (!more) break;
+            base = nbase;
+        }
+        {   // ---- transform in B, prefetch into A
+            const size_t nbase = base + step;
+            const bool more = nbase < batch;
+            {
+                // Unconditional loads through a descriptor that is EMPTY when there is no next transform: the
+                // bounds check then returns zeros without touching memory.  No branch, so the loads carry no
+                // register shuffles behind them and stay in flight until their first use one transform later.
+                const rsrc_t d = io.in_desc(nbase + slot, nbase + slot < batch);
+#pragma unroll
+                for (int u = 0; u < R; ++u) ra[u] = io.fetch_d(d, in_lane_bytes, FirstG::in_index(0, u));
+            }
+            persist_transform<T, L, RL, BLOCK, NBUF, EPI>(rb, st, io, tw, buf0, buf1, base + slot, base + slot < batch, tau);
+            if (!more) break;
+            base = nbase;
+        }
     }
 }
 

@@ -23,20 +23,47 @@ __host__ __device__ constexpr int lds_elems(int n) { return n + (n >> 4) + 1; }
 // load(xf, i)  : element i of transform xf as the FFT must see it.
 // store(xf, o, v): element o of the finished transform.
 
+struct NoInv {};
+
 // FftImpl::fft (fft.rs:1054) / ifft (fft.rs:1134-1174: conj, fft, conj, *scale).
 template <typename T, bool INVERSE>
 struct ComplexIO {
     static constexpr bool kStreams = true;  // cheap load/store: eligible for the persistent prefetching kernel
+    static constexpr bool kInvInLds = false;
+    using Raw = cpx<T>;
+    using Inv = NoInv;
     const cpx<T> *__restrict__ in;
     cpx<T> *__restrict__ out;
     int n;
     T scale;  // 1 / (n as f32 as T), fft.rs:1167
-    __device__ __forceinline__ cpx<T> load(size_t xf, int i) const
+    __device__ __forceinline__ Raw fetch(size_t xf, int i) const { return ld_stream(in + xf * (size_t)n + i); }
+    // descriptor forms (xf wave-uniform): element iu + lane of transform xf, iu a compile-time constant
+    static constexpr int kRawBytes = sizeof(cpx<T>);
+    __device__ __forceinline__ rsrc_t in_desc(size_t xf, bool valid) const
     {
-        cpx<T> v = in[xf * (size_t)n + i];
+        return make_rsrc(in + (valid ? xf : 0) * (size_t)n, valid ? (unsigned)n * sizeof(cpx<T>) : 0u);
+    }
+    __device__ __forceinline__ rsrc_t out_desc(size_t xf) const { return make_rsrc(out + xf * (size_t)n, (unsigned)n * sizeof(cpx<T>)); }
+    __device__ __forceinline__ Raw fetch_d(rsrc_t d, int lane_bytes, int iu) const
+    {
+        return buf_load_cpx<T, AUX_NT>(d, lane_bytes, iu * (int)sizeof(cpx<T>));
+    }
+    __device__ __forceinline__ void store_d(rsrc_t d, int lane_bytes, int ou, cpx<T> v) const
+    {
+        if (INVERSE) {
+            const T im = -v.im;
+            v.re = v.re * scale;
+            v.im = im * scale;
+        }
+        buf_store_cpx<T>(v, d, lane_bytes, ou * (int)sizeof(cpx<T>));
+    }
+    __device__ __forceinline__ Inv invariant(int) const { return {}; }
+    __device__ __forceinline__ cpx<T> finish(size_t, int, Raw v, Inv) const
+    {
         if (INVERSE) v.im = -v.im;
         return v;
     }
+    __device__ __forceinline__ cpx<T> load(size_t xf, int i) const { return finish(xf, i, fetch(xf, i), {}); }
     __device__ __forceinline__ void store(size_t xf, int o, cpx<T> v) const
     {
         if (INVERSE) {
@@ -51,17 +78,40 @@ struct ComplexIO {
 // stft.rs:91-103: frame f starts at start0 + f*hop; x = signal[start+i]*window[i] or 0.
 struct StftIO {
     static constexpr bool kStreams = true;
+    static constexpr bool kInvInLds = false;  // 16 window samples per thread: registers
+    using Raw = float;
+    using Inv = float;
     const float *__restrict__ signal;
     const float *__restrict__ window;
     cpx<float> *__restrict__ out;
     size_t len, hop, start0;
     int n;
-    __device__ __forceinline__ cpx<float> load(size_t xf, int i) const
+    __device__ __forceinline__ bool in_range(size_t xf, int i) const { return start0 + xf * hop + (size_t)i < len; }
+    __device__ __forceinline__ Raw fetch(size_t xf, int i) const
     {
-        const size_t pos = start0 + xf * hop + (size_t)i;
-        const float x = (pos < len) ? signal[pos] * window[i] : 0.0f;
-        return mk<float>(x, 0.0f);
+        return in_range(xf, i) ? signal[start0 + xf * hop + (size_t)i] : 0.0f;
     }
+    // descriptor forms: the frame's descriptor covers only the samples that exist, so a frame that runs off the
+    // end of the signal reads zeros from the bounds check (stft.rs:95-99) without a per-lane address test.
+    static constexpr int kRawBytes = sizeof(float);
+    __device__ __forceinline__ rsrc_t in_desc(size_t xf, bool valid) const
+    {
+        const size_t start = start0 + xf * hop;
+        const size_t avail = (valid && start < len) ? len - start : 0;
+        return make_rsrc(signal + (avail ? start : 0), (unsigned)(avail < (size_t)n ? avail : (size_t)n) * 4u);
+    }
+    __device__ __forceinline__ rsrc_t out_desc(size_t xf) const { return make_rsrc(out + xf * (size_t)n, (unsigned)n * 8u); }
+    __device__ __forceinline__ Raw fetch_d(rsrc_t d, int lane_bytes, int iu) const { return buf_load_f32<AUX_DEFAULT>(d, lane_bytes, iu * 4); }
+    __device__ __forceinline__ void store_d(rsrc_t d, int lane_bytes, int ou, cpx<float> v) const
+    {
+        buf_store_cpx<float>(v, d, lane_bytes, ou * 8);
+    }
+    __device__ __forceinline__ Inv invariant(int i) const { return window[i]; }
+    __device__ __forceinline__ cpx<float> finish(size_t xf, int i, Raw x, Inv w) const
+    {
+        return mk<float>(in_range(xf, i) ? x * w : 0.0f, 0.0f);  // past the end: exactly +0, whatever the window holds
+    }
+    __device__ __forceinline__ cpx<float> load(size_t xf, int i) const { return finish(xf, i, fetch(xf, i), invariant(i)); }
     __device__ __forceinline__ void store(size_t xf, int o, cpx<float> v) const
     {
         out[xf * (size_t)n + o] = v;
@@ -69,37 +119,58 @@ struct StftIO {
 };
 
 // rfft.rs:444-446 pack z[i] = (x[2i], x[2i+1]) (with the optional row window of the
-// batched entry point); the post-pass of rfft.rs:450-463 runs in the kernel epilogue
-// (rfft_post), which writes the m+1 outputs.
+// batched entry point); the post-pass of rfft.rs:450-463 runs in the kernel epilogue,
+// which writes the m+1 outputs.
 template <typename T>
 struct RfftIO {
-    static constexpr bool kStreams = false;
+    static constexpr bool kStreams = true;
+    static constexpr bool kInvInLds = true;  // window pairs + post-pass table: staged in LDS once per workgroup
+    using Raw = cpx<T>;
+    using Inv = cpx<T>;
     const T *__restrict__ in;         // batch rows of 2*m reals
     const T *__restrict__ window;     // 2*m reals or nullptr
     cpx<T> *__restrict__ out;         // batch rows of m+1 complex
     const cpx<T> *__restrict__ rtab;  // build_twiddle_table(m), rfft.rs:172-183
     int m;
-    __device__ __forceinline__ cpx<T> load(size_t xf, int i) const
+    __device__ __forceinline__ Raw fetch(size_t xf, int i) const
     {
-        const cpx<T> *row = reinterpret_cast<const cpx<T> *>(in + xf * (size_t)(2 * m));
-        cpx<T> v = row[i];
-        if (window) {
-            const cpx<T> w = reinterpret_cast<const cpx<T> *>(window)[i];
-            v.re = v.re * w.re;
-            v.im = v.im * w.im;
-        }
-        return v;
+        return ld_stream(reinterpret_cast<const cpx<T> *>(in + xf * (size_t)(2 * m)) + i);
     }
-    // X[k] for 1 <= k < m from Y[k], Y[m-k]  (rfft.rs:454-463)
-    __device__ __forceinline__ cpx<T> post(int k, cpx<T> a, cpx<T> ymk) const
+    static constexpr int kRawBytes = sizeof(cpx<T>);
+    __device__ __forceinline__ rsrc_t in_desc(size_t xf, bool valid) const
+    {
+        return make_rsrc(in + (valid ? xf : 0) * (size_t)(2 * m), valid ? (unsigned)m * sizeof(cpx<T>) : 0u);
+    }
+    __device__ __forceinline__ rsrc_t out_desc(size_t xf) const
+    {
+        return make_rsrc(out + xf * (size_t)(m + 1), (unsigned)(m + 1) * sizeof(cpx<T>));
+    }
+    __device__ __forceinline__ Raw fetch_d(rsrc_t d, int lane_bytes, int iu) const
+    {
+        return buf_load_cpx<T, AUX_NT>(d, lane_bytes, iu * (int)sizeof(cpx<T>));
+    }
+    __device__ __forceinline__ void store_d(rsrc_t d, int lane_bytes, int ou, cpx<T> v) const
+    {
+        buf_store_cpx<T>(v, d, lane_bytes, ou * (int)sizeof(cpx<T>));
+    }
+    // no window: multiply by exactly 1, which leaves every value unchanged bit for bit
+    __device__ __forceinline__ Inv invariant(int i) const
+    {
+        return window ? reinterpret_cast<const cpx<T> *>(window)[i] : mk<T>(T(1), T(1));
+    }
+    __device__ __forceinline__ cpx<T> finish(size_t, int, Raw v, Inv w) const { return mk<T>(v.re * w.re, v.im * w.im); }
+    __device__ __forceinline__ cpx<T> load(size_t xf, int i) const { return finish(xf, i, fetch(xf, i), invariant(i)); }
+    // X[k] for 1 <= k < m from Y[k], Y[m-k] and W[k]  (rfft.rs:454-463)
+    __device__ __forceinline__ cpx<T> post_w(cpx<T> w, cpx<T> a, cpx<T> ymk) const
     {
         const T half = T(0.5f);
         const cpx<T> b = mk<T>(ymk.re, -ymk.im);
         const cpx<T> sum = cadd(a, b), diff = csub(a, b);
-        const cpx<T> t = cmul(rtab[k], diff);
+        const cpx<T> t = cmul(w, diff);
         const cpx<T> temp = cadd(sum, mk<T>(t.im, -t.re));
         return mk<T>(temp.re * half, temp.im * half);
     }
+    __device__ __forceinline__ cpx<T> post(int k, cpx<T> a, cpx<T> ymk) const { return post_w(rtab[k], a, ymk); }
 };
 
 // irfft_direct (rfft.rs:487-506): scratch[k] from input[k], input[m-k]; then fft.ifft

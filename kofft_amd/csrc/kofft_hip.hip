@@ -136,22 +136,32 @@ int launch_wg(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t batch)
     return KOFFT_OK;
 }
 
-// Persistent, prefetching kernel (fft_persist.hip.h): the streaming path for large batches.
-// Two workgroups per CU, each with two LDS exchange buffers; every workgroup walks the batch with a
-// stride of the grid size and keeps the next transform's loads in flight while it computes.
-template <typename T, int L, class IO>
+// Persistent, prefetching kernels (fft_persist.hip.h): the streaming path for large batches.
+// n = 4096: 256 threads per transform, two workgroups per CU, two LDS exchange buffers each.
+// n = 1024: one wavefront per transform (wave-synchronous exchanges), four per workgroup.
+// Every workgroup walks the batch with a stride of the grid size and keeps the next transform's
+// loads in flight while it computes.
+template <int L> struct PersistCfg;
+template <> struct PersistCfg<12> { static constexpr int BLOCK = 256, NBUF = 1, MINW = 2, WG_PER_CU = 2; };
+template <> struct PersistCfg<10> { static constexpr int BLOCK = 256, NBUF = 1, MINW = 2, WG_PER_CU = 2; };
+
+template <typename T, int L, int EPI, class IO>
 int launch_persist(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t batch)
 {
-    constexpr int RL = 4, NBUF = 2, WG_PER_CU = 2;
-    constexpr int BLOCK = (1 << L) >> RL;
-    constexpr size_t lds = (size_t)NBUF * lds_elems(1 << L) * sizeof(cpx<T>);
-    static_assert(lds * WG_PER_CU <= 160 * 1024, "LDS budget");
-    auto kern = fft_persist_kernel<T, L, RL, NBUF, WG_PER_CU, IO>;
+    using Cfg = PersistCfg<L>;
+    constexpr int RL = 4;
+    constexpr int XPB = Cfg::BLOCK / ((1 << L) >> RL);
+    constexpr size_t lds = (size_t)XPB * Cfg::NBUF * lds_elems(1 << L) * sizeof(cpx<T>) +
+                           (IO::kInvInLds ? (size_t)(1 << L) * sizeof(typename IO::Inv) : 0) +
+                           (EPI == EPI_RFFT ? (size_t)(1 << L) * sizeof(cpx<T>) : 0);
+    static_assert(lds * Cfg::WG_PER_CU <= 160 * 1024, "LDS budget");
+    auto kern = fft_persist_kernel<T, L, RL, Cfg::BLOCK, Cfg::NBUF, Cfg::MINW, EPI, IO>;
     KOFFT_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    size_t blocks = (size_t)ctx->num_cus * WG_PER_CU;
-    if (blocks > batch) blocks = batch;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BLOCK), lds, ctx->stream, io, tw, batch);
+    size_t blocks = (size_t)ctx->num_cus * Cfg::WG_PER_CU;
+    const size_t need = (batch + XPB - 1) / XPB;
+    if (blocks > need) blocks = need;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Cfg::BLOCK), lds, ctx->stream, io, tw, batch);
     KOFFT_HIP_TRY(ctx, hipGetLastError());
     return KOFFT_OK;
 }
@@ -185,9 +195,12 @@ int dispatch(kofft_hip_ctx *ctx, const IO &io, size_t n, size_t batch)
     const cpx<T> *tw = nullptr;
     int rc = get_table<T>(ctx, Kind<T>::tw, n, &tw);
     if (rc) return rc;
-    if constexpr (sizeof(T) == 4 && EPI == EPI_STORE && IO::kStreams) {
+    if constexpr (sizeof(T) == 4 && IO::kStreams) {
         // streaming sizes: enough transforms to give every resident workgroup several iterations
-        if (L == 12 && batch >= (size_t)ctx->num_cus * 4) return launch_persist<T, 12>(ctx, io, tw, batch);
+        if constexpr (EPI == EPI_STORE) {
+            if (L == 12 && batch >= (size_t)ctx->num_cus * 4) return launch_persist<T, 12, EPI>(ctx, io, tw, batch);
+        }
+        if (L == 10 && batch >= (size_t)ctx->num_cus * 32) return launch_persist<T, 10, EPI>(ctx, io, tw, batch);
     }
     switch (L) {
 #define KOFFT_CASE(LL) \

@@ -1,0 +1,123 @@
+"""BASELINE.json's full-size configurations on the device-pointer path (torch = device memory only).
+The oracle cannot chew through 2 GiB in seconds, so these use size-independent properties plus
+oracle spot checks on a sample of the transforms."""
+import numpy as np
+import pytest
+
+from conftest import bits_equal, seeded
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def dev_fft():
+    import kofft_amd
+
+    assert torch.cuda.is_available()
+    f = kofft_amd.HipFftImpl(np.float32, device=0)
+    s = torch.cuda.Stream()
+    f.set_stream(s.cuda_stream)
+    return f, s
+
+
+def test_cfg2_65536x4096_c32(dev_fft, oracle):
+    """config #2: 65 536 x 4096 c32 forward, in place on the device."""
+    fft, stream = dev_fft
+    n, batch = 4096, 65536
+    with torch.cuda.stream(stream):
+        g = torch.Generator(device="cuda")
+        g.manual_seed(1234)
+        x = torch.empty((batch, n, 2), dtype=torch.float32, device="cuda").uniform_(-1, 1, generator=g)
+        # plant known-answer rows: an impulse at position p transforms to exp(-2 pi i k p / n) (|.| == 1 exactly at p = 0)
+        x[7] = 0
+        x[7, 0, 0] = 1.0
+        x[batch - 1] = 0
+        x[batch - 1, 0, 1] = -2.0
+        keep_idx = torch.tensor([0, 1, 7, 255, 256, 511, 512, 4097, 32768, 65534, 65535], device="cuda")
+        keep = x[keep_idx].clone()
+        y = x.clone()
+        fft.fft_dev(y.data_ptr(), n, batch, False)
+        stream.synchronize()
+        # (1) oracle spot check, bit for bit, on rows spread over the grid-stride schedule
+        got = y[keep_idx].cpu().numpy().view(np.complex64).reshape(len(keep_idx), n)
+        want = oracle.fft(keep.cpu().numpy().view(np.complex64).reshape(len(keep_idx), n))
+        assert bits_equal(got, want)
+        # (2) impulse rows: exactly constant spectra (lib.rs:178-199 at full scale)
+        assert torch.all(y[7, :, 0] == 1.0) and torch.all(y[7, :, 1] == 0.0)
+        assert torch.all(y[batch - 1, :, 0] == 0.0) and torch.all(y[batch - 1, :, 1] == -2.0)
+        # (3) Parseval on every transform: sum |X|^2 = n * sum |x|^2 within the drift budget (8.5e-5 relative)
+        ex = (x.double() ** 2).sum(dim=(1, 2))
+        ey = (y.double() ** 2).sum(dim=(1, 2))
+        rel = ((ey / n - ex).abs() / ex.clamp_min(1e-30)).max().item()
+        assert rel < 5e-4, rel
+        # (4) round trip: ifft(fft(x)) == x within f32 round-off + table drift, every element
+        fft.fft_dev(y.data_ptr(), n, batch, True)
+        stream.synchronize()
+        err = (y - x).abs().max().item()
+        assert err < 2e-3, err
+
+
+def test_cfg3_rfft_2048_hann_device(dev_fft, oracle):
+    """config #3 shape on the device path (2^18 rows here: 2 GiB in + 2 GiB out would not leave room for the checks)."""
+    import kofft_amd
+
+    fft, stream = dev_fft
+    n, batch = 2048, 1 << 18
+    with torch.cuda.stream(stream):
+        g = torch.Generator(device="cuda")
+        g.manual_seed(77)
+        x = torch.empty((batch, n), dtype=torch.float32, device="cuda").uniform_(-1, 1, generator=g)
+        win_h = kofft_amd.hann(n)
+        win = torch.from_numpy(win_h).cuda()
+        out = torch.empty((batch, n // 2 + 1, 2), dtype=torch.float32, device="cuda")
+        fft.rfft_dev(x.data_ptr(), out.data_ptr(), win.data_ptr(), n, batch)
+        stream.synchronize()
+        idx = [0, 1, 3, 1023, 1024, 4095, 4096, 131071, batch - 2, batch - 1]
+        got = out[idx].cpu().numpy().view(np.complex64).reshape(len(idx), n // 2 + 1)
+        want = oracle.rfft(x[idx].cpu().numpy(), win_h)
+        assert bits_equal(got, want)
+        # DC and Nyquist bins are exactly real for every row (rfft.rs:451-452)
+        assert torch.all(out[:, 0, 1] == 0) and torch.all(out[:, n // 2, 1] == 0)
+        # DC bin = windowed sum, every row, within f32 accumulation error
+        dc = (x.double() * win.double()).sum(dim=1)
+        assert ((out[:, 0, 0].double() - dc).abs().max().item()) < 5e-3
+
+
+def test_cfg4_stft_10min_48k(dev_fft, oracle):
+    """config #4: 28.8 M samples, 1024-pt Hann, hop 256 -> 112 500 frames (single GPU here; shards in test_dist)."""
+    import kofft_amd
+
+    fft, stream = dev_fft
+    total, win_len, hop = 28_800_000, 1024, 256
+    frames = -(-total // hop)
+    assert frames == 112_500
+    with torch.cuda.stream(stream):
+        t = torch.arange(total, dtype=torch.float32, device="cuda")
+        g = torch.Generator(device="cuda")
+        g.manual_seed(5)
+        sig = 0.5 * torch.sin(2 * np.pi * 440.0 * t / 48000.0) + 0.25 * torch.empty_like(t).uniform_(-1, 1, generator=g)
+        del t
+        win_h = kofft_amd.hann(win_len)
+        win = torch.from_numpy(win_h).cuda()
+        out = torch.empty((frames, win_len, 2), dtype=torch.float32, device="cuda")
+        fft.stft_dev(sig.data_ptr(), total, win.data_ptr(), win_len, hop, out.data_ptr(), 0, frames)
+        stream.synchronize()
+        # oracle spot checks: head, middle, and the last 4 frames (the last 3 are partly zero-padded)
+        sig_h = sig.cpu().numpy()
+        for first, count in ((0, 3), (56_250, 2), (frames - 4, 4)):
+            want = oracle.stft_range(sig_h, win_h, hop, first, count)
+            got = out[first:first + count].cpu().numpy().view(np.complex64).reshape(count, win_len)
+            assert bits_equal(got, want), (first, count)
+        # real input: Hermitian symmetry X[k] = conj(X[n-k]) holds to round-off on every frame
+        a = out[:, 1:win_len // 2, :]
+        b = out[:, win_len // 2 + 1:, :].flip(1)
+        assert (a[..., 0] - b[..., 0]).abs().max().item() < 1e-2
+        assert (a[..., 1] + b[..., 1]).abs().max().item() < 1e-2
+        # sharded evaluation == whole evaluation, bit for bit (frames [f0, f1) of rank 3 of 8)
+        per = -(-frames // 8)
+        f0, f1 = 3 * per, min(4 * per, frames)
+        part = torch.empty((f1 - f0, win_len, 2), dtype=torch.float32, device="cuda")
+        fft.stft_dev(sig.data_ptr(), total, win.data_ptr(), win_len, hop, part.data_ptr(), f0, f1 - f0)
+        stream.synchronize()
+        assert torch.equal(part, out[f0:f1])

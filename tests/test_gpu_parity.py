@@ -318,3 +318,42 @@ def test_strided_split_and_batch_helpers(fft32, fft64, oracle):
     assert all(bits_equal(a, b) for a, b in zip(vs, want))
     K.batch_inverse(fft32, vs)
     assert all(bits_equal(a, oracle.ifft(b)) for a, b in zip(vs, want))
+
+
+# ---- streaming (persistent, prefetching) kernels: large batches ----------------------------------------------
+@pytest.mark.parametrize("batch", [8192, 9001])
+def test_fft_c32_1024_streaming_path(fft32, oracle, batch):
+    """n = 1024 with >= 8192 transforms runs the wave-synchronous persistent kernel (one wavefront per transform)."""
+    rng = seeded(800 + batch)
+    x = rand_c(rng, (batch, 1024))
+    y = x.copy()
+    fft32.fft_batch(y)
+    want = oracle.fft(x)
+    assert_parity(y, want, f"streaming fft c32 n=1024 batch={batch}", REL_TOL_F32)
+    fft32.fft_batch(y, inverse=True)
+    assert_parity(y, oracle.ifft(want), f"streaming ifft c32 n=1024 batch={batch}", REL_TOL_F32)
+
+
+@pytest.mark.parametrize("batch,windowed", [(8192, True), (8200, False), (10001, True)])
+def test_rfft_2048_streaming_path(fft32, oracle, batch, windowed):
+    """BASELINE config #3 shape (2048-pt rfft + Hann) at a batch that takes the persistent kernel with the window and
+    the post-pass table staged in LDS; 10001 rows exercise the tail (rows are 8200 B: only 8-byte aligned)."""
+    rng = seeded(900 + batch)
+    x = rng.uniform(-1, 1, (batch, 2048)).astype(np.float32)
+    win = oracle.hann(2048) if windowed else None
+    got = fft32.rfft_batch(x, win)
+    assert_parity(got, oracle.rfft(x, win), f"streaming rfft n=2048 batch={batch} windowed={windowed}", REL_TOL_F32)
+
+
+@pytest.mark.parametrize("length,hop", [(2_200_000, 256), (1_100_003, 128)])
+def test_stft_1024_streaming_path(fft32, oracle, length, hop):
+    """BASELINE config #4 shape (1024-pt Hann, hop 256) with > 8192 frames: persistent kernel, frames that run off the
+    end of the signal are zero-filled by the buffer bounds check; two extra frames lie entirely past the end."""
+    rng = seeded(1000 + hop)
+    signal = rng.uniform(-1, 1, length).astype(np.float32)
+    window = oracle.hann(1024)
+    frames = -(-length // hop) + 2
+    got = fft32.stft_into(signal, window, hop, frames)
+    want = oracle.stft(signal, window, hop, frames)
+    assert_parity(got, want, f"streaming stft len={length} hop={hop}", REL_TOL_F32)
+    assert np.all(got[-1] == 0)
