@@ -112,9 +112,12 @@ __device__ __forceinline__ cpx<T> cmul(cpx<T> a, cpx<T> b)
     return mk<T>(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re);
 }
 
-// One Stockham butterfly, in place on (e, o).  fft.rs:881-893.
+// One Stockham butterfly, in place on (e, o).  fft.rs:881-893:
+//   t_re = o.re*w.re - o.im*w.im ; t_im = o.re*w.im + o.im*w.re   (4 mul, 1 sub, 1 add, un-fused)
+//   e' = e + t ; o' = e - t
+// Generic form (f64, and f32 when KOFFT_BFLY_NOASM is defined):
 template <typename T>
-__device__ __forceinline__ void bfly(cpx<T> &e, cpx<T> &o, const cpx<T> w)
+__device__ __forceinline__ void bfly_generic(cpx<T> &e, cpx<T> &o, const cpx<T> w)
 {
     const T t_re = o.re * w.re - o.im * w.im;
     const T t_im = o.re * w.im + o.im * w.re;
@@ -123,6 +126,54 @@ __device__ __forceinline__ void bfly(cpx<T> &e, cpx<T> &o, const cpx<T> w)
     e.im = e_im + t_im;
     o.re = e_re - t_re;
     o.im = e_im - t_im;
+}
+
+// f32 form: five packed instructions on aligned {re, im} register pairs, operand swizzles and sign modifiers
+// doing the shuffling that hipcc otherwise spends v_mov's and splatted twiddle copies on (7 instructions and
+// 4 registers per twiddle when left to the SLP vectoriser):
+//   p1 = (o.re*w.re, o.im*w.re)            v_pk_mul  op_sel:[0,0] op_sel_hi:[1,0]
+//   p2 = (o.im*w.im, o.re*w.im)            v_pk_mul  op_sel:[1,1] op_sel_hi:[0,1]
+//   t  = (p1.x - p2.x, p1.y + p2.y)        v_pk_add  neg_lo:[0,1]
+//   o' = e - t ; e' = e + t                v_pk_add  (neg_lo/neg_hi on t), v_pk_add
+// Each instruction is IEEE mul/add/sub on f32 with round-to-nearest-even: the same operations, in the same
+// order per output value, as the reference (a + (-b) is a - b exactly; t_im's operands commute).
+// One asm statement per instruction, no "volatile": the scheduler stays free to interleave butterflies.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <bool W_IN_SGPR>
+__device__ __forceinline__ void bfly_f32_pk(v2f &e, v2f &o, const v2f w)
+{
+    v2f p1, p2, t, d, s;
+    if constexpr (W_IN_SGPR) {
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(p1) : "v"(o), "s"(w));
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1]" : "=v"(p2) : "v"(o), "s"(w));
+    } else {
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(p1) : "v"(o), "v"(w));
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1]" : "=v"(p2) : "v"(o), "v"(w));
+    }
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(t) : "v"(p1), "v"(p2));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(e), "v"(t));
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(s) : "v"(e), "v"(t));
+    e = s;
+    o = d;
+}
+
+template <typename T, bool W_UNIFORM = false>
+__device__ __forceinline__ void bfly(cpx<T> &e, cpx<T> &o, const cpx<T> w)
+{
+#ifndef KOFFT_BFLY_NOASM
+    if constexpr (sizeof(T) == 4) {
+        v2f ev = {e.re, e.im}, ov = {o.re, o.im};
+        const v2f wv = {w.re, w.im};
+        bfly_f32_pk<W_UNIFORM>(ev, ov, wv);
+        e.re = ev.x;
+        e.im = ev.y;
+        o.re = ov.x;
+        o.im = ov.y;
+        return;
+    }
+#endif
+    bfly_generic(e, o, w);
 }
 
 __host__ __device__ constexpr int bitrev(int x, int bits)
@@ -137,7 +188,9 @@ __host__ __device__ constexpr int bitrev(int x, int bits)
 // Register index bit (Q-1-t) is the bit consumed (and replaced by b') at local stage t.
 // Twiddle for local stage t, prefix bits h (register bits Q-1..Q-t):
 //   kk = k + 2^S0 * rev_t(h),  index = kk * 2^(L-1-S0-t).
-template <typename T, int L, int S0, int Q>
+// UNIFORM: the caller guarantees k is the same in every lane of the wave AND that the compiler can see it
+// (k == 0 in pass 0): the twiddles then come from scalar loads and are used straight from SGPRs.
+template <typename T, int L, int S0, int Q, bool UNIFORM = false>
 __device__ __forceinline__ void reg_pass(cpx<T> *v, const int k, const cpx<T> *__restrict__ tw)
 {
 #pragma unroll
@@ -150,7 +203,7 @@ __device__ __forceinline__ void reg_pass(cpx<T> *v, const int k, const cpx<T> *_
 #pragma unroll
             for (int lo = 0; lo < (1 << pos); ++lo) {
                 const int c = (h << (pos + 1)) | lo;
-                bfly(v[c], v[c | (1 << pos)], w);
+                bfly<T, UNIFORM>(v[c], v[c | (1 << pos)], w);
             }
         }
     }

@@ -108,7 +108,7 @@ __device__ __forceinline__ void persist_compute_p0(cpx<T> *v, const cpx<T> *__re
 {
     using Gm = PassGeom<L, RL, 0>;
 #pragma unroll
-    for (int g = 0; g < Gm::G; ++g) reg_pass<T, L, 0, Gm::Q>(v + g * (1 << Gm::Q), 0, tw);
+    for (int g = 0; g < Gm::G; ++g) reg_pass<T, L, 0, Gm::Q, true>(v + g * (1 << Gm::Q), 0, tw);
 }
 
 // LDS / global addressing.  in_index(tau, u) and out_index(tau, u) are concatenations of disjoint bit

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
@@ -26,6 +27,7 @@ struct kofft_hip_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     int num_cus = 256;
+    bool use_persist = true;  // KOFFT_HIP_NO_PERSIST=1 forces the generic kernels (A/B measurements, tests)
     std::string last_error;
     // planner caches: (kind, n) -> device table.  kind 0/1 = FftPlanner twiddles f32/f64,
     // 2/3 = RfftPlanner post-pass table f32/f64.
@@ -195,7 +197,7 @@ int dispatch(kofft_hip_ctx *ctx, const IO &io, size_t n, size_t batch)
     const cpx<T> *tw = nullptr;
     int rc = get_table<T>(ctx, Kind<T>::tw, n, &tw);
     if (rc) return rc;
-    if constexpr (sizeof(T) == 4 && IO::kStreams) {
+    if constexpr (sizeof(T) == 4 && IO::kStreams) if (ctx->use_persist) {
         // streaming sizes: enough transforms to give every resident workgroup several iterations
         if constexpr (EPI == EPI_STORE) {
             if (L == 12 && batch >= (size_t)ctx->num_cus * 4) return launch_persist<T, 12, EPI>(ctx, io, tw, batch);
@@ -472,6 +474,7 @@ int kofft_hip_create(int device, kofft_hip_ctx **out)
     kofft_hip_ctx *ctx = new (std::nothrow) kofft_hip_ctx();
     if (!ctx) return KOFFT_ERR_ALLOC;
     ctx->device = device;
+    if (const char *e = getenv("KOFFT_HIP_NO_PERSIST")) ctx->use_persist = !(e[0] == '1');
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)

@@ -13,6 +13,27 @@ using namespace kofft;
 using IO = ComplexIO<float, false>;
 struct Var { std::string name; std::function<void()> launch; std::vector<float> ms; bool ok = true; };
 
+// same-bytes streaming reference: persistent copy with prefetch and non-temporal loads (the measured ceiling)
+typedef float f2v __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void copy_ref(const f2v* __restrict__ in, f2v* __restrict__ out, int nchunks) {
+    const int t = threadIdx.x; f2v cur[16], nxt[16];
+    int ch = blockIdx.x;
+    if (ch >= nchunks) return;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) cur[c] = __builtin_nontemporal_load(&in[(size_t)ch * 4096 + t + 256 * c]);
+    for (; ch < nchunks; ch += gridDim.x) {
+        const int nch = ch + gridDim.x;
+        if (nch < nchunks) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) nxt[c] = __builtin_nontemporal_load(&in[(size_t)nch * 4096 + t + 256 * c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) out[(size_t)ch * 4096 + t + 256 * c] = cur[c];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) cur[c] = nxt[c];
+    }
+}
+
 template <int L, int BLOCK, int NBUF, int MINW>
 void add_persist(std::vector<Var>& vars, IO io, const cpx<float>* dtw, size_t batch, int wg_per_cu) {
     constexpr int N = 1 << L, XPB = BLOCK / (N >> 4);
@@ -47,11 +68,15 @@ int run(size_t batch) {
     std::vector<char> href(std::min<size_t>(bytes, 64u << 20)), hout(href.size());
     CK(hipMemcpy(href.data(), ref, href.size(), hipMemcpyDeviceToHost));
     std::vector<Var> vars;
+    {
+        const int nchunks = (int)(bytes / 32768);
+        vars.push_back({"copy reference (nt loads, prefetch) x2", [=]{ hipLaunchKernelGGL(copy_ref, dim3(512), dim3(256), 0, 0, (const f2v*)src, (f2v*)out, nchunks); }});
+    }
     vars.push_back({"generic wg", [=]{ hipLaunchKernelGGL(k_gen, dim3(gridg), dim3(BLKg), ldsg, 0, io, dtw, batch); }});
     if constexpr (L == 12) {
         add_persist<12, 256, 2, 2>(vars, io, dtw, batch, 2);
         add_persist<12, 256, 1, 2>(vars, io, dtw, batch, 2);
-        add_persist<12, 256, 1, 2>(vars, io, dtw, batch, 3);
+        add_persist<12, 256, 1, 3>(vars, io, dtw, batch, 3);
     } else {
         add_persist<10, 256, 1, 2>(vars, io, dtw, batch, 2);
         add_persist<10, 256, 1, 3>(vars, io, dtw, batch, 3);
@@ -64,11 +89,11 @@ int run(size_t batch) {
         CK(hipMemset(out, 0xff, bytes));
         v.launch(); CK(hipDeviceSynchronize());
         CK(hipMemcpy(hout.data(), out, hout.size(), hipMemcpyDeviceToHost));
-        v.ok = memcmp(hout.data(), href.data(), href.size()) == 0;
+        v.ok = memcmp(hout.data(), href.data(), href.size()) == 0 || v.name.rfind("copy", 0) == 0;
         std::vector<char> t1(N * 8 * 4), t2(N * 8 * 4);
         CK(hipMemcpy(t1.data(), out + (batch - 4) * N, t1.size(), hipMemcpyDeviceToHost));
         CK(hipMemcpy(t2.data(), ref + (batch - 4) * N, t2.size(), hipMemcpyDeviceToHost));
-        v.ok = v.ok && memcmp(t1.data(), t2.data(), t1.size()) == 0;
+        v.ok = (v.ok && memcmp(t1.data(), t2.data(), t1.size()) == 0) || v.name.rfind("copy", 0) == 0;
     }
     for (int round = 0; round < 12; ++round)
         for (auto& v : vars) {
