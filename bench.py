@@ -35,6 +35,7 @@ WORKLOADS = {
     "fft4096": "batched 65536 x 4096-pt Complex32 forward FFT (BASELINE config #2)",
     "rfft2048": "batched 2^20 x 2048-pt f32 rfft + Hann (BASELINE config #3)",
     "stft1024": "STFT 28.8M-sample f32 stream, 1024-pt Hann, hop 256 (BASELINE config #4, frames sharded)",
+    "c64_2p20": "batched 1024 x 2^20-pt Complex64 forward FFT (BASELINE config #5)",
 }
 
 
@@ -170,11 +171,25 @@ def main():
         metric = "batched 2048-pt f32 rfft + Hann throughput"
         launch = lambda: fft.rfft_dev(src.data_ptr(), dst.data_ptr(), win.data_ptr(), n, batch)  # noqa: E731
         cfg = {"workload": WORKLOADS["rfft2048"], "n": n, "batch_per_gpu": batch, "sharding": f"batch x{world}, no collective"}
+    elif args.workload == "c64_2p20":
+        n, batch = 1 << 20, args.batch or 1024
+        fft64 = kofft_amd.HipFftImpl(np.float64, device=local_rank)
+        fft64.set_stream(stream.cuda_stream)
+        src = torch.empty((batch, n, 2), dtype=torch.float64, device=dev).uniform_(-1.0, 1.0, generator=gen)
+        dst = torch.empty_like(src)
+        units_per_step = batch * n
+        alg_bytes = 32 * units_per_step                 # 16 B read + 16 B written per point
+        unit = "GPoints/s"
+        metric = "batched 2^20-pt Complex64 forward FFT throughput"
+        launch = lambda: fft64.fft_dev_oop(src.data_ptr(), dst.data_ptr(), n, batch, False)  # noqa: E731
+        cfg = {"workload": WORKLOADS["c64_2p20"], "n": n, "batch_per_gpu": batch, "sharding": f"batch x{world}, no collective",
+               "passes_over_hbm": 2}
     else:
         total_len, win_len, hop = 28_800_000, 1024, 256
-        frames_total = -(-total_len // hop)
-        per = -(-frames_total // world)
-        f0, f1 = rank * per, min((rank + 1) * per, frames_total)
+        from kofft_amd.dist import frames_required, shard_range
+
+        frames_total = frames_required(total_len, hop)
+        f0, f1 = shard_range(frames_total, rank, world)
         t = torch.arange(total_len, dtype=torch.float32, device=dev)
         sig = 0.5 * torch.sin(2 * np.pi * 440.0 * t / 48000.0) + 0.25 * torch.empty_like(t).uniform_(-1, 1, generator=gen)
         del t
@@ -218,6 +233,24 @@ def main():
     elapsed = time.perf_counter() - t0
 
     kern_ms = [s.elapsed_time(e) for s, e in zip(starts, ends)]
+
+    # BASELINE config #4's exchange step, timed apart from the compute (it dominates: SURVEY 8e)
+    allgather_ms = None
+    if args.workload == "stft1024" and world > 1:
+        per = -(-frames_total // world)
+        slot = torch.zeros((per, win_len, 2), dtype=torch.float32, device=dev)
+        slot[:count] = dst
+        full = torch.empty((world * per, win_len, 2), dtype=torch.float32, device=dev)
+        for _ in range(3):
+            dist.all_gather_into_tensor(full, slot)
+        torch.cuda.synchronize(dev)
+        barrier()
+        tg = time.perf_counter()
+        for _ in range(10):
+            dist.all_gather_into_tensor(full, slot)
+        torch.cuda.synchronize(dev)
+        barrier()
+        allgather_ms = (time.perf_counter() - tg) / 10 * 1e3
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     units = torch.tensor([float(units_per_step)], dtype=torch.float64, device=dev)
     if world > 1:
@@ -251,7 +284,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if args.workload == "stft1024" else "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f64" if args.workload == "c64_2p20" else "f32",
             "data": "synthetic",
             "config": cfg,
             "roofline": {
@@ -266,6 +299,9 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes,
             },
         }
+        if allgather_ms is not None:
+            out["allgather"] = {"ms_per_step": allgather_ms, "bytes_gathered_per_rank": int(full.numel() * 4),
+                                "backend": "nccl (RCCL over xGMI), all_gather_into_tensor"}
         if args.workload == "fft4096" and not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline_fft4096(args.cpu_seconds)
         elif args.workload == "fft4096" and world > 1:

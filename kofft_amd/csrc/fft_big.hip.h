@@ -1,0 +1,85 @@
+// fft_big.hip.h -- power-of-two transforms too large for one workgroup's LDS (n > 16384 f32 / 8192 f64),
+// e.g. BASELINE config #5: 2^20-point Complex64.
+//
+// The reference runs L = log2(n) radix-2 Stockham stages over the whole array (fft.rs:834-898).  In index bits,
+// stage s maps [k : s bits][b][j] -> [b'][k][j], so the stages split cleanly into two factors, L = LA + LB:
+//
+//   factor A = stages 0 .. LA-1.  No frequency prefix yet (k empty); the LB low bits j are untouched.
+//       For each j it is a complete 2^LA-point Stockham transform of the column  x_c = in[c * 2^LB + j]
+//       whose result q (natural order) lands at  q * 2^LB + j.
+//   factor B = stages LA .. L-1.  The prefix K (LA bits) is fixed per row; no j bits remain.
+//       For each K it is a 2^LB-point Stockham transform of the contiguous row  x_c = mid[K * 2^LB + c]
+//       whose result q lands at  q * 2^LA + K   -- natural order of the full transform.
+//
+// Every butterfly is the reference's butterfly with the reference's table entry: global stage s, group kk uses
+// T_n[kk * 2^(L-1-s)].  For a sub-transform that handles global stages S_off + s_local with local group index
+// kk_local, kk = K + 2^S_off * kk_local, hence
+//   index = (K << (L-1-S_off-s_local)) + (idx_local << (L - L_sub)),   idx_local = kk_local << (L_sub-1-s_local)
+// (TwSub in fft_device.hip.h).  T_n != a subsampling of T_{2^L_sub} bitwise (each table is its own recurrence),
+// so both factors index the ONE table T_n.  Only the order of independent butterflies changes: results are
+// bit-identical to the reference's 20 sweeps, with 2 passes over HBM instead of 20.
+//
+// The two factors run as the generic workgroup kernel (fft_wg.hip.h) with these IO policies; the intermediate
+// lives in a scratch buffer of `chunk` transforms so that factor B reads it back from the Infinity Cache.
+#pragma once
+
+#include "fft_wg.hip.h"
+
+namespace kofft {
+
+// factor A: unit xf = (b, j) with j in [0, 2^LB): column j of transform b.  Adjacent units are adjacent columns,
+// so lanes run over units first (kSlotMinor) and a wave touches whole 128-byte lines.
+template <typename T, bool INVERSE>
+struct BigColsIO {
+    static constexpr bool kStreams = false;
+    static constexpr bool kSlotMinor = true;
+    const cpx<T> *__restrict__ in;
+    cpx<T> *__restrict__ out;
+    int LB;     // log2 of the column count
+    int shift;  // L - LA
+    size_t n;   // full transform length
+    __device__ __forceinline__ TwSubFirst tw_map(size_t) const { return TwSubFirst{shift}; }
+    __device__ __forceinline__ cpx<T> load(size_t xf, int c) const
+    {
+        const size_t b = xf >> LB, j = xf & ((size_t(1) << LB) - 1);
+        cpx<T> v = in[b * n + ((size_t)c << LB) + j];
+        if (INVERSE) v.im = -v.im;  // ifft: conj on the way in (fft.rs:1163-1165)
+        return v;
+    }
+    __device__ __forceinline__ void store(size_t xf, int q, cpx<T> v) const
+    {
+        const size_t b = xf >> LB, j = xf & ((size_t(1) << LB) - 1);
+        out[b * n + ((size_t)q << LB) + j] = v;
+    }
+};
+
+// factor B: unit xf = (b, K) with K in [0, 2^LA): row K of transform b (contiguous), output transposed.
+template <typename T, bool INVERSE>
+struct BigRowsIO {
+    static constexpr bool kStreams = false;
+    static constexpr bool kSlotMinor = false;
+    const cpx<T> *__restrict__ in;
+    cpx<T> *__restrict__ out;
+    int LA, LB;
+    int shift;  // L - LB
+    int kbase;  // L - 1 - LA
+    size_t n;
+    T scale;    // 1 / (n as f32 as T), fft.rs:1167
+    __device__ __forceinline__ TwSub tw_map(size_t xf) const { return TwSub{shift, (int)(xf & ((size_t(1) << LA) - 1)), kbase}; }
+    __device__ __forceinline__ cpx<T> load(size_t xf, int c) const
+    {
+        const size_t b = xf >> LA, K = xf & ((size_t(1) << LA) - 1);
+        return in[b * n + (K << LB) + (size_t)c];
+    }
+    __device__ __forceinline__ void store(size_t xf, int q, cpx<T> v) const
+    {
+        const size_t b = xf >> LA, K = xf & ((size_t(1) << LA) - 1);
+        if (INVERSE) {  // conj, then scale (fft.rs:1168-1172)
+            const T im = -v.im;
+            v = mk<T>(v.re * scale, im * scale);
+        }
+        out[b * n + ((size_t)q << LA) + K] = v;
+    }
+};
+
+}  // namespace kofft

@@ -188,10 +188,33 @@ __host__ __device__ constexpr int bitrev(int x, int bits)
 // Register index bit (Q-1-t) is the bit consumed (and replaced by b') at local stage t.
 // Twiddle for local stage t, prefix bits h (register bits Q-1..Q-t):
 //   kk = k + 2^S0 * rev_t(h),  index = kk * 2^(L-1-S0-t).
+// Where a sub-transform's twiddles live when it is one factor of a larger 2^LT-point transform (fft_big.hip.h).
+// A sub-transform that performs global stages S_off .. S_off+L-1 for the outer frequency prefix K reads
+//   T_{2^LT}[ (idx_local << (LT - L)) + (K << (LT - 1 - S_off - s_local)) ]
+// where idx_local is the index the same butterfly would use in a stand-alone 2^L-point transform and s_local its
+// stage there (derivation: fft_big.hip.h).  Stand-alone transforms use TwPlain (shift 0, no K term).
+struct TwPlain {
+    __device__ __forceinline__ int operator()(int idx_local, int) const { return idx_local; }
+};
+struct TwSub {
+    int shift;  // LT - L
+    int K;      // outer prefix
+    int kbase;  // LT - 1 - S_off  (>= every s_local of the sub-transform)
+    __device__ __forceinline__ int operator()(int idx_local, int s_local) const
+    {
+        return (idx_local << shift) + (K << (kbase - s_local));
+    }
+};
+// first factor: no prefix yet (S_off = 0, K = 0) -- a separate type so that no shift by (0 - s_local) is ever formed
+struct TwSubFirst {
+    int shift;  // LT - L
+    __device__ __forceinline__ int operator()(int idx_local, int) const { return idx_local << shift; }
+};
+
 // UNIFORM: the caller guarantees k is the same in every lane of the wave AND that the compiler can see it
 // (k == 0 in pass 0): the twiddles then come from scalar loads and are used straight from SGPRs.
-template <typename T, int L, int S0, int Q, bool UNIFORM = false>
-__device__ __forceinline__ void reg_pass(cpx<T> *v, const int k, const cpx<T> *__restrict__ tw)
+template <typename T, int L, int S0, int Q, bool UNIFORM = false, class TwMap = TwPlain>
+__device__ __forceinline__ void reg_pass(cpx<T> *v, const int k, const cpx<T> *__restrict__ tw, const TwMap map = TwMap{})
 {
 #pragma unroll
     for (int t = 0; t < Q; ++t) {
@@ -199,7 +222,7 @@ __device__ __forceinline__ void reg_pass(cpx<T> *v, const int k, const cpx<T> *_
 #pragma unroll
         for (int h = 0; h < (1 << t); ++h) {
             const int idx = (k << (L - 1 - S0 - t)) + (bitrev(h, t) << (L - 1 - t));
-            const cpx<T> w = tw[idx];
+            const cpx<T> w = tw[map(idx, S0 + t)];
 #pragma unroll
             for (int lo = 0; lo < (1 << pos); ++lo) {
                 const int c = (h << (pos + 1)) | lo;

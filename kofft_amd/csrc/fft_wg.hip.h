@@ -25,9 +25,15 @@ __host__ __device__ constexpr int lds_elems(int n) { return n + (n >> 4) + 1; }
 
 struct NoInv {};
 
+// Default for every IO policy of a stand-alone transform: plain table indexing, threads of a transform contiguous.
+struct PlainTw {
+    static constexpr bool kSlotMinor = false;
+    __device__ __forceinline__ TwPlain tw_map(size_t) const { return {}; }
+};
+
 // FftImpl::fft (fft.rs:1054) / ifft (fft.rs:1134-1174: conj, fft, conj, *scale).
 template <typename T, bool INVERSE>
-struct ComplexIO {
+struct ComplexIO : PlainTw {
     static constexpr bool kStreams = true;  // cheap load/store: eligible for the persistent prefetching kernel
     static constexpr bool kInvInLds = false;
     using Raw = cpx<T>;
@@ -76,7 +82,7 @@ struct ComplexIO {
 };
 
 // stft.rs:91-103: frame f starts at start0 + f*hop; x = signal[start+i]*window[i] or 0.
-struct StftIO {
+struct StftIO : PlainTw {
     static constexpr bool kStreams = true;
     static constexpr bool kInvInLds = false;  // 16 window samples per thread: registers
     using Raw = float;
@@ -122,7 +128,7 @@ struct StftIO {
 // batched entry point); the post-pass of rfft.rs:450-463 runs in the kernel epilogue,
 // which writes the m+1 outputs.
 template <typename T>
-struct RfftIO {
+struct RfftIO : PlainTw {
     static constexpr bool kStreams = true;
     static constexpr bool kInvInLds = true;  // window pairs + post-pass table: staged in LDS once per workgroup
     using Raw = cpx<T>;
@@ -176,7 +182,7 @@ struct RfftIO {
 // irfft_direct (rfft.rs:487-506): scratch[k] from input[k], input[m-k]; then fft.ifft
 // (conj, fft, conj, *1/m); output[2i], output[2i+1] = scratch[i].re, .im.
 template <typename T>
-struct IrfftIO {
+struct IrfftIO : PlainTw {
     static constexpr bool kStreams = false;  // two loads + a table entry per element: too many live registers to prefetch
     const cpx<T> *__restrict__ in;  // batch rows of m+1 complex
     cpx<T> *__restrict__ out;       // batch rows of m complex == 2*m reals
@@ -251,7 +257,7 @@ __device__ __forceinline__ void wg_pass(cpx<T> *v, cpx<T> *buf, const IO &io, co
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const int m = tau + g * TPT;
-        reg_pass<T, L, S0, Q>(&v[g * (1 << Q)], m >> JB, tw);
+        reg_pass<T, L, S0, Q, false>(&v[g * (1 << Q)], m >> JB, tw, io.tw_map(xf));
     }
     // ---- scatter the pass outputs
     constexpr bool to_lds = (P < NP - 1) || (EPI == EPI_RFFT);
@@ -286,8 +292,10 @@ __global__ __launch_bounds__(BLOCK) void fft_wg_kernel(const IO io, const cpx<T>
     cpx<T> *lds = reinterpret_cast<cpx<T> *>(smem_raw);
 
     const int tid = threadIdx.x;
-    const int tau = tid % TPT;
-    const int slot = tid / TPT;
+    // kSlotMinor: consecutive lanes belong to consecutive transforms (used when adjacent transforms are adjacent
+    // in memory, e.g. the columns of fft_big's first factor), otherwise to consecutive threads of one transform.
+    const int tau = IO::kSlotMinor ? tid / XPB : tid % TPT;
+    const int slot = IO::kSlotMinor ? tid % XPB : tid / TPT;
     const size_t xf = (size_t)blockIdx.x * XPB + slot;
     const bool active = xf < batch;
     cpx<T> *buf = lds + slot * lds_elems(N);

@@ -13,6 +13,7 @@
 #include <utility>
 #include <vector>
 
+#include "fft_big.hip.h"
 #include "fft_persist.hip.h"
 #include "fft_wg.hip.h"
 #include "tables.h"
@@ -35,6 +36,10 @@ struct kofft_hip_ctx {
     // staging for the host-pointer entry points
     void *stage[3] = {nullptr, nullptr, nullptr};
     size_t stage_bytes[3] = {0, 0, 0};
+    // intermediate of the two-factor large-n path (fft_big.hip.h): `big_chunk` transforms at a time
+    void *big_tmp = nullptr;
+    size_t big_tmp_bytes = 0;
+    size_t big_chunk_bytes = 128u << 20;  // KOFFT_HIP_BIG_CHUNK_MB: keep the intermediate inside the 256 MiB Infinity Cache
 };
 
 namespace {
@@ -225,6 +230,65 @@ int dispatch(kofft_hip_ctx *ctx, const IO &io, size_t n, size_t batch)
 }
 
 // ---------------------------------------------------------------------------------
+// large n: two factors (fft_big.hip.h)
+// ---------------------------------------------------------------------------------
+template <typename T> constexpr int max_log2_big() { return 26; }
+
+// Launch the generic kernel for a sub-transform of log2 size LS with an arbitrary IO policy.
+template <typename T, class IO>
+int launch_sub(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, int LS, size_t units)
+{
+    switch (LS) {
+#define KOFFT_CASE(LL) \
+    case LL: return launch_wg<T, LL, EPI_STORE>(ctx, io, tw, units);
+        KOFFT_CASE(7)
+        KOFFT_CASE(8)
+        KOFFT_CASE(9)
+        KOFFT_CASE(10)
+        KOFFT_CASE(11)
+        KOFFT_CASE(12)
+        KOFFT_CASE(13)
+#undef KOFFT_CASE
+    default: return KOFFT_ERR_UNSUPPORTED;
+    }
+}
+
+template <typename T, bool INVERSE>
+int fft_big_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t batch)
+{
+    const int L = ilog2(n);
+    const int LA = L / 2, LB = L - LA;  // both in 7..13 for L in 15..26
+    const cpx<T> *tw = nullptr;
+    int rc = get_table<T>(ctx, Kind<T>::tw, n, &tw);
+    if (rc) return rc;
+    const size_t xf_bytes = n * sizeof(cpx<T>);
+    size_t chunk = ctx->big_chunk_bytes / xf_bytes;
+    if (chunk < 1) chunk = 1;
+    if (chunk > batch) chunk = batch;
+    if (ctx->big_tmp_bytes < chunk * xf_bytes) {
+        if (ctx->big_tmp) KOFFT_HIP_TRY(ctx, hipFree(ctx->big_tmp));
+        ctx->big_tmp = nullptr;
+        ctx->big_tmp_bytes = 0;
+        KOFFT_HIP_TRY(ctx, hipMalloc(&ctx->big_tmp, chunk * xf_bytes));
+        ctx->big_tmp_bytes = chunk * xf_bytes;
+    }
+    cpx<T> *mid = static_cast<cpx<T> *>(ctx->big_tmp);
+    const T scale = (T)1 / (T)(float)n;
+    for (size_t b0 = 0; b0 < batch; b0 += chunk) {
+        const size_t nb = (batch - b0 < chunk) ? batch - b0 : chunk;
+        const cpx<T> *src = reinterpret_cast<const cpx<T> *>(d_in) + b0 * n;
+        cpx<T> *dst = reinterpret_cast<cpx<T> *>(d_out) + b0 * n;
+        BigColsIO<T, INVERSE> a{src, mid, LB, L - LA, n};
+        rc = launch_sub<T>(ctx, a, tw, LA, nb << LB);
+        if (rc) return rc;
+        BigRowsIO<T, INVERSE> b{mid, dst, LA, LB, L - LB, L - 1 - LA, n, scale};
+        rc = launch_sub<T>(ctx, b, tw, LB, nb << LA);
+        if (rc) return rc;
+    }
+    return KOFFT_OK;
+}
+
+// ---------------------------------------------------------------------------------
 // typed entry points behind the C ABI
 // ---------------------------------------------------------------------------------
 template <typename T>
@@ -234,9 +298,11 @@ int fft_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t batch,
     if (batch == 0) return KOFFT_OK;
     if (n == 0) return KOFFT_ERR_EMPTY_INPUT;  // fft.rs:1056 / 1136
     if (!is_pow2(n)) return KOFFT_ERR_UNSUPPORTED;  // Bluestein arm (fft.rs:1088-1132) not on the device path
-    if (n > (size_t(1) << max_log2<T>())) return KOFFT_ERR_UNSUPPORTED;
+    if (n > (size_t(1) << max_log2_big<T>())) return KOFFT_ERR_UNSUPPORTED;
     if (!ctx || !d_in || !d_out) return KOFFT_ERR_NULL;
     KOFFT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (n > (size_t(1) << max_log2<T>()))
+        return inverse ? fft_big_dev<T, true>(ctx, d_in, d_out, n, batch) : fft_big_dev<T, false>(ctx, d_in, d_out, n, batch);
     if (n == 1) {  // fft.rs:1059 / 1139: nothing to do
         if (d_in != d_out)
             KOFFT_HIP_TRY(ctx, hipMemcpyAsync(d_out, d_in, batch * 2 * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
@@ -244,10 +310,10 @@ int fft_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t batch,
     }
     const T scale = (T)1 / (T)(float)n;  // fft.rs:1167
     if (inverse) {
-        ComplexIO<T, true> io{reinterpret_cast<const cpx<T> *>(d_in), reinterpret_cast<cpx<T> *>(d_out), (int)n, scale};
+        ComplexIO<T, true> io{{}, reinterpret_cast<const cpx<T> *>(d_in), reinterpret_cast<cpx<T> *>(d_out), (int)n, scale};
         return dispatch<T, EPI_STORE>(ctx, io, n, batch);
     }
-    ComplexIO<T, false> io{reinterpret_cast<const cpx<T> *>(d_in), reinterpret_cast<cpx<T> *>(d_out), (int)n, scale};
+    ComplexIO<T, false> io{{}, reinterpret_cast<const cpx<T> *>(d_in), reinterpret_cast<cpx<T> *>(d_out), (int)n, scale};
     return dispatch<T, EPI_STORE>(ctx, io, n, batch);
 }
 
@@ -256,7 +322,7 @@ int fft_host(kofft_hip_ctx *ctx, T *data, size_t n, size_t batch, int inverse)
 {
     if (batch == 0) return KOFFT_OK;
     if (n == 0) return KOFFT_ERR_EMPTY_INPUT;
-    if (!is_pow2(n) || n > (size_t(1) << max_log2<T>())) return KOFFT_ERR_UNSUPPORTED;
+    if (!is_pow2(n) || n > (size_t(1) << max_log2_big<T>())) return KOFFT_ERR_UNSUPPORTED;
     if (n == 1) return KOFFT_OK;
     if (!ctx || !data) return KOFFT_ERR_NULL;
     KOFFT_HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -307,7 +373,7 @@ int rfft_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, const T *d_window, siz
     const cpx<T> *rtab = nullptr;
     int rc = get_table<T>(ctx, Kind<T>::rt, m, &rtab);
     if (rc) return rc;
-    RfftIO<T> io{d_in, d_window, reinterpret_cast<cpx<T> *>(d_out), rtab, (int)m};
+    RfftIO<T> io{{}, d_in, d_window, reinterpret_cast<cpx<T> *>(d_out), rtab, (int)m};
     return dispatch<T, EPI_RFFT>(ctx, io, m, batch);
 }
 
@@ -324,7 +390,7 @@ int irfft_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t batc
     const cpx<T> *rtab = nullptr;
     int rc = get_table<T>(ctx, Kind<T>::rt, m, &rtab);
     if (rc) return rc;
-    IrfftIO<T> io{reinterpret_cast<const cpx<T> *>(d_in), reinterpret_cast<cpx<T> *>(d_out), rtab, (int)m,
+    IrfftIO<T> io{{}, reinterpret_cast<const cpx<T> *>(d_in), reinterpret_cast<cpx<T> *>(d_out), rtab, (int)m,
                   (T)1 / (T)(float)m};
     return dispatch<T, EPI_STORE>(ctx, io, m, batch);
 }
@@ -390,7 +456,7 @@ int stft_dev(kofft_hip_ctx *ctx, const float *d_signal, size_t len, const float 
     if (!is_pow2(win_len) || win_len > (size_t(1) << max_log2<float>())) return KOFFT_ERR_UNSUPPORTED;
     if (!ctx || (!d_signal && len) || !d_window || !d_out) return KOFFT_ERR_NULL;
     KOFFT_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    StftIO io{d_signal, d_window, reinterpret_cast<cpx<float> *>(d_out), len, hop, start0, (int)win_len};
+    StftIO io{{}, d_signal, d_window, reinterpret_cast<cpx<float> *>(d_out), len, hop, start0, (int)win_len};
     return dispatch<float, EPI_STORE>(ctx, io, win_len, count);
 }
 
@@ -475,6 +541,10 @@ int kofft_hip_create(int device, kofft_hip_ctx **out)
     if (!ctx) return KOFFT_ERR_ALLOC;
     ctx->device = device;
     if (const char *e = getenv("KOFFT_HIP_NO_PERSIST")) ctx->use_persist = !(e[0] == '1');
+    if (const char *e = getenv("KOFFT_HIP_BIG_CHUNK_MB")) {
+        const long mb = atol(e);
+        if (mb > 0) ctx->big_chunk_bytes = (size_t)mb << 20;
+    }
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -497,6 +567,7 @@ int kofft_hip_destroy(kofft_hip_ctx *ctx)
     for (auto &kv : ctx->tables) (void)hipFree(kv.second);
     for (int i = 0; i < 3; ++i)
         if (ctx->stage[i]) (void)hipFree(ctx->stage[i]);
+    if (ctx->big_tmp) (void)hipFree(ctx->big_tmp);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return KOFFT_OK;

@@ -357,3 +357,35 @@ def test_stft_1024_streaming_path(fft32, oracle, length, hop):
     want = oracle.stft(signal, window, hop, frames)
     assert_parity(got, want, f"streaming stft len={length} hop={hop}", REL_TOL_F32)
     assert np.all(got[-1] == 0)
+
+
+# ---- large n: two-factor path (fft_big.hip.h) ------------------------------------------------------------------
+@pytest.mark.parametrize("log2n,batch", [(15, 3), (16, 2), (17, 2), (20, 2)])
+def test_fft_c32_large_n(fft32, oracle, log2n, batch):
+    """n > 16384 runs as two factors over HBM with the ONE reference table T_n; still the reference's butterflies."""
+    n = 1 << log2n
+    rng = seeded(1100 + log2n)
+    x = rand_c(rng, (batch, n))
+    y = x.copy()
+    fft32.fft_batch(y)
+    want = oracle.fft(x)
+    assert_parity(y, want, f"large fft c32 n=2^{log2n}", REL_TOL_F32)
+    fft32.fft_batch(y, inverse=True)
+    assert_parity(y, oracle.ifft(want), f"large ifft c32 n=2^{log2n}", REL_TOL_F32)
+
+
+@pytest.mark.parametrize("log2n,batch", [(14, 3), (15, 2), (18, 2), (20, 3)])
+def test_fft_c64_large_n(fft64, oracle, log2n, batch):
+    """BASELINE config #5's transform (2^20-point Complex64) and smaller two-factor sizes, bit for bit."""
+    n = 1 << log2n
+    rng = seeded(1200 + log2n)
+    x = rand_c(rng, (batch, n), np.complex128)
+    y = x.copy()
+    fft64.fft_batch(y)
+    want = oracle.fft(x)
+    assert_parity(y, want, f"large fft c64 n=2^{log2n}", REL_TOL_F64)
+    fft64.fft_batch(y, inverse=True)
+    assert_parity(y, oracle.ifft(want), f"large ifft c64 n=2^{log2n}", REL_TOL_F64)
+    if log2n == 20:  # tests/split64.rs-style truth check at cfg5's size: f64 drift budget 2.3e-11
+        ref = np.fft.fft(x[0])
+        assert rel_err(want[0], ref) < 1e-9

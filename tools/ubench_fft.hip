@@ -58,7 +58,7 @@ int run(size_t batch) {
         for (auto& x : h) { s = s * 6364136223846793005ull + 1442695040888963407ull; x = (float)((s >> 40) & 0xFFFFFF) / 8388608.0f - 1.0f; }
         for (size_t off = 0; off < batch * N; off += chunk) CK(hipMemcpy(src + off, h.data(), std::min(chunk, batch * N - off) * sizeof(cpx<float>), hipMemcpyHostToDevice));
     }
-    IO io_ref{src, ref, N, 1.0f / N}, io{src, out, N, 1.0f / N};
+    IO io_ref{{}, src, ref, N, 1.0f / N}, io{{}, src, out, N, 1.0f / N};
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     constexpr int RLg = 4, BLKg = 256, XPBg = BLKg / (N >> RLg);
     const size_t ldsg = (size_t)XPBg * lds_elems(N) * sizeof(cpx<float>);
