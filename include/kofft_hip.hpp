@@ -1,0 +1,391 @@
+// kofft_hip.hpp -- C++17 host mirror of kofft's operator interface for the hot path, on top of the C ABI
+// (kofft_hip.h).  The reference is a Rust crate and the build image has no Rust toolchain, so this header plays
+// the role the Rust shim (integration/rust/kofft-hip) plays for Rust callers: same names, same argument meaning,
+// same error variants and validation order, so that tests read like the reference's own.
+//
+//   kofft::FftError, FftStrategy                 fft.rs:447-463
+//   kofft::Complex<T>, Complex32, Complex64      num.rs:105-110, 232-233   (#[repr(C)] {re, im})
+//   kofft::FftImpl<T>  (abstract)                fft.rs:466-587
+//   kofft::HipFftImpl<T>  ~ ScalarFftImpl<T>     fft.rs:600-613 + RealFftImpl blanket methods (rfft.rs:775-837)
+//   kofft::FftPlanner<T>, RfftPlanner<T>         fft.rs:332-445, rfft.rs:194-338
+//   kofft::batch / batch_inverse / multi_channel fft.rs:2156-2191
+//   kofft::stft / parallel / frame / StftStream  stft.rs:76-105, 232-263, 355-372, 160-206
+//   kofft::hann                                  window.rs:24-28
+//
+// Result<(), FftError> becomes kofft::Result (is_ok / is_err / unwrap / unwrap_err).  A negative C-ABI status
+// (HIP failure, unsupported length) has no FftError variant: it throws kofft::DeviceError, the C++ analogue of
+// the Rust shim's panic.
+#pragma once
+
+#include <cstddef>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "kofft_hip.h"
+
+namespace kofft {
+
+enum class FftError : int {  // fft.rs:447-454, discriminant + 1 == C ABI status
+    EmptyInput = 1,
+    NonPowerOfTwoNoStd = 2,
+    MismatchedLengths = 3,
+    InvalidStride = 4,
+    InvalidHopSize = 5,
+    InvalidValue = 6,
+};
+
+enum class FftStrategy { Radix2, Radix4, SplitRadix, Auto };  // fft.rs:456-463
+
+struct DeviceError : std::runtime_error {
+    int status;
+    DeviceError(int s, const std::string &detail)
+        : std::runtime_error(std::string("kofft_hip status ") + std::to_string(s) + ": " + kofft_hip_strerror(s) +
+                             (detail.empty() ? "" : " [" + detail + "]")),
+          status(s)
+    {
+    }
+};
+
+class Result {
+public:
+    Result() : code_(0) {}
+    explicit Result(FftError e) : code_(static_cast<int>(e)) {}
+    static Result Ok() { return Result(); }
+    static Result Err(FftError e) { return Result(e); }
+    bool is_ok() const { return code_ == 0; }
+    bool is_err() const { return code_ != 0; }
+    void unwrap() const
+    {
+        if (code_ != 0) throw std::logic_error(std::string("called unwrap() on Err(") + kofft_hip_strerror(code_) + ")");
+    }
+    FftError unwrap_err() const
+    {
+        if (code_ == 0) throw std::logic_error("called unwrap_err() on Ok");
+        return static_cast<FftError>(code_);
+    }
+    bool operator==(const Result &o) const { return code_ == o.code_; }
+
+private:
+    int code_;
+};
+
+template <typename T>
+struct Complex {  // layout-compatible with T[2] (tests/complex_repr.rs)
+    T re, im;
+    Complex() : re(0), im(0) {}
+    Complex(T r, T i) : re(r), im(i) {}
+    static Complex zero() { return Complex(0, 0); }
+    Complex add(Complex o) const { return Complex(re + o.re, im + o.im); }
+    Complex sub(Complex o) const { return Complex(re - o.re, im - o.im); }
+    Complex mul(Complex o) const { return Complex(re * o.re - im * o.im, re * o.im + im * o.re); }  // num.rs:161-166
+    bool operator==(const Complex &o) const { return re == o.re && im == o.im; }
+};
+using Complex32 = Complex<float>;
+using Complex64 = Complex<double>;
+static_assert(sizeof(Complex32) == 2 * sizeof(float) && sizeof(Complex64) == 2 * sizeof(double), "repr(C) layout");
+
+namespace detail {
+template <typename T> struct Abi;
+template <> struct Abi<float> {
+    static int fft(kofft_hip_ctx *c, float *d, size_t n, size_t b, int inv) { return kofft_hip_fft_c32(c, d, n, b, inv); }
+    static int strided(kofft_hip_ctx *c, float *d, size_t len, size_t st, size_t n, int inv) { return kofft_hip_fft_c32_strided(c, d, len, st, n, inv); }
+    static int rfft(kofft_hip_ctx *c, const float *i, float *o, const float *w, size_t n, size_t b) { return kofft_hip_rfft_f32(c, i, o, w, n, b); }
+    static int irfft(kofft_hip_ctx *c, const float *i, float *o, size_t n, size_t b) { return kofft_hip_irfft_f32(c, i, o, n, b); }
+    static int twiddles(size_t n, float *o) { return kofft_hip_twiddles_f32(n, o); }
+    static int rfft_table(size_t m, float *o) { return kofft_hip_rfft_table_f32(m, o); }
+};
+template <> struct Abi<double> {
+    static int fft(kofft_hip_ctx *c, double *d, size_t n, size_t b, int inv) { return kofft_hip_fft_c64(c, d, n, b, inv); }
+    static int strided(kofft_hip_ctx *c, double *d, size_t len, size_t st, size_t n, int inv) { return kofft_hip_fft_c64_strided(c, d, len, st, n, inv); }
+    static int rfft(kofft_hip_ctx *c, const double *i, double *o, const double *w, size_t n, size_t b) { return kofft_hip_rfft_f64(c, i, o, w, n, b); }
+    static int irfft(kofft_hip_ctx *c, const double *i, double *o, size_t n, size_t b) { return kofft_hip_irfft_f64(c, i, o, n, b); }
+    static int twiddles(size_t n, double *o) { return kofft_hip_twiddles_f64(n, o); }
+    static int rfft_table(size_t m, double *o) { return kofft_hip_rfft_table_f64(m, o); }
+};
+}  // namespace detail
+
+// trait FftImpl<T> (fft.rs:466-587): the required methods are pure virtual, the provided ones have the
+// reference's default bodies.
+template <typename T>
+class FftImpl {
+public:
+    using C = Complex<T>;
+    virtual ~FftImpl() = default;
+    virtual Result fft(std::vector<C> &input) const = 0;
+    virtual Result ifft(std::vector<C> &input) const = 0;
+    virtual Result fft_strided(std::vector<C> &input, size_t stride, std::vector<C> &scratch) const = 0;
+    virtual Result ifft_strided(std::vector<C> &input, size_t stride, std::vector<C> &scratch) const = 0;
+    virtual Result fft_out_of_place_strided(const std::vector<C> &input, size_t in_stride, std::vector<C> &output,
+                                            size_t out_stride) const = 0;
+    virtual Result ifft_out_of_place_strided(const std::vector<C> &input, size_t in_stride, std::vector<C> &output,
+                                             size_t out_stride) const = 0;
+    virtual Result fft_with_strategy(std::vector<C> &input, FftStrategy strategy) const = 0;
+
+    Result fft_out_of_place(const std::vector<C> &input, std::vector<C> &output) const  // fft.rs:469-479
+    {
+        if (input.size() != output.size()) return Result::Err(FftError::MismatchedLengths);
+        output = input;
+        return fft(output);
+    }
+    Result ifft_out_of_place(const std::vector<C> &input, std::vector<C> &output) const  // fft.rs:480-490
+    {
+        if (input.size() != output.size()) return Result::Err(FftError::MismatchedLengths);
+        output = input;
+        return ifft(output);
+    }
+    Result fft_split(std::vector<T> &re, std::vector<T> &im) const  // fft.rs:556-570
+    {
+        if (re.size() != im.size()) return Result::Err(FftError::MismatchedLengths);
+        std::vector<C> buf(re.size());
+        for (size_t i = 0; i < re.size(); ++i) buf[i] = C(re[i], im[i]);
+        Result r = fft(buf);
+        if (r.is_err()) return r;
+        for (size_t i = 0; i < re.size(); ++i) { re[i] = buf[i].re; im[i] = buf[i].im; }
+        return Result::Ok();
+    }
+    Result ifft_split(std::vector<T> &re, std::vector<T> &im) const  // fft.rs:572-586
+    {
+        if (re.size() != im.size()) return Result::Err(FftError::MismatchedLengths);
+        std::vector<C> buf(re.size());
+        for (size_t i = 0; i < re.size(); ++i) buf[i] = C(re[i], im[i]);
+        Result r = ifft(buf);
+        if (r.is_err()) return r;
+        for (size_t i = 0; i < re.size(); ++i) { re[i] = buf[i].re; im[i] = buf[i].im; }
+        return Result::Ok();
+    }
+};
+
+// Drop-in for ScalarFftImpl<T>: one device context per instance, not shared between threads (fft.rs:589-605).
+template <typename T>
+class HipFftImpl : public FftImpl<T> {
+public:
+    using C = Complex<T>;
+    explicit HipFftImpl(int device = 0)
+    {
+        int rc = kofft_hip_create(device, &ctx_);
+        if (rc != 0) throw DeviceError(rc, "kofft_hip_create");
+    }
+    static HipFftImpl default_() { return HipFftImpl(0); }
+    ~HipFftImpl() override { if (ctx_) kofft_hip_destroy(ctx_); }
+    HipFftImpl(const HipFftImpl &) = delete;
+    HipFftImpl &operator=(const HipFftImpl &) = delete;
+    HipFftImpl(HipFftImpl &&o) noexcept : ctx_(o.ctx_) { o.ctx_ = nullptr; }
+    kofft_hip_ctx *raw() const { return ctx_; }
+
+    Result fft(std::vector<C> &input) const override { return st(detail::Abi<T>::fft(ctx_, fp(input), input.size(), 1, 0)); }
+    Result ifft(std::vector<C> &input) const override { return st(detail::Abi<T>::fft(ctx_, fp(input), input.size(), 1, 1)); }
+    Result stockham_fft(std::vector<C> &input) const { return fft(input); }  // fft.rs:634-640
+    Result fft_strided(std::vector<C> &input, size_t stride, std::vector<C> &scratch) const override
+    {
+        return st(detail::Abi<T>::strided(ctx_, fp(input), input.size(), stride, scratch.size(), 0));
+    }
+    Result ifft_strided(std::vector<C> &input, size_t stride, std::vector<C> &scratch) const override
+    {
+        return st(detail::Abi<T>::strided(ctx_, fp(input), input.size(), stride, scratch.size(), 1));
+    }
+    Result fft_out_of_place_strided(const std::vector<C> &input, size_t in_stride, std::vector<C> &output,
+                                    size_t out_stride) const override
+    {
+        return oop_strided(input, in_stride, output, out_stride, false);
+    }
+    Result ifft_out_of_place_strided(const std::vector<C> &input, size_t in_stride, std::vector<C> &output,
+                                     size_t out_stride) const override
+    {
+        return oop_strided(input, in_stride, output, out_stride, true);
+    }
+    Result fft_with_strategy(std::vector<C> &input, FftStrategy) const override  // fft.rs:1337-1363
+    {
+        if (input.empty()) return Result::Err(FftError::EmptyInput);
+        if (input.size() == 1) return Result::Ok();
+        return fft(input);
+    }
+
+    // RealFftImpl<T> blanket methods (rfft.rs:780-833); checks in rfft_direct's order (rfft.rs:433-443)
+    Result rfft_with_scratch(std::vector<T> &input, std::vector<C> &output, std::vector<C> &scratch) const
+    {
+        const size_t n = input.size();
+        if (n == 0) return Result::Err(FftError::EmptyInput);
+        if (n % 2 != 0) return Result::Err(FftError::InvalidValue);
+        if (output.size() != n / 2 + 1 || scratch.size() < n / 2) return Result::Err(FftError::MismatchedLengths);
+        return st(detail::Abi<T>::rfft(ctx_, input.data(), fp(output), nullptr, n, 1));
+    }
+    Result rfft(std::vector<T> &input, std::vector<C> &output) const
+    {
+        std::vector<C> scratch(input.size() / 2);
+        return rfft_with_scratch(input, output, scratch);
+    }
+    Result irfft_with_scratch(std::vector<C> &input, std::vector<T> &output, std::vector<C> &scratch) const
+    {
+        const size_t n = output.size();
+        if (n == 0) return Result::Err(FftError::EmptyInput);
+        if (n % 2 != 0) return Result::Err(FftError::InvalidValue);
+        if (input.size() != n / 2 + 1 || scratch.size() < n / 2) return Result::Err(FftError::MismatchedLengths);
+        return st(detail::Abi<T>::irfft(ctx_, reinterpret_cast<const T *>(input.data()), output.data(), n, 1));
+    }
+    Result irfft(std::vector<C> &input, std::vector<T> &output) const
+    {
+        std::vector<C> scratch(output.size() / 2);
+        return irfft_with_scratch(input, output, scratch);
+    }
+
+    // added: contiguous batch (fft::batch over one buffer)
+    Result fft_batch(std::vector<C> &data, size_t n, bool inverse = false) const
+    {
+        if (n != 0 && data.size() % n != 0) return Result::Err(FftError::MismatchedLengths);
+        return st(detail::Abi<T>::fft(ctx_, fp(data), n, n ? data.size() / n : 1, inverse ? 1 : 0));
+    }
+
+    Result st(int rc) const
+    {
+        if (rc == 0) return Result::Ok();
+        if (rc > 0) return Result::Err(static_cast<FftError>(rc));
+        throw DeviceError(rc, kofft_hip_last_error(ctx_));
+    }
+
+private:
+    static T *fp(std::vector<C> &v) { return reinterpret_cast<T *>(v.data()); }
+    Result oop_strided(const std::vector<C> &input, size_t in_stride, std::vector<C> &output, size_t out_stride,
+                       bool inverse) const  // fft.rs:1261-1336
+    {
+        if (in_stride == 0 || out_stride == 0) return Result::Err(FftError::InvalidStride);
+        if (input.size() % in_stride != 0 || output.size() % out_stride != 0) return Result::Err(FftError::InvalidStride);
+        const size_t n = input.size() / in_stride;
+        if (output.size() / out_stride != n) return Result::Err(FftError::MismatchedLengths);
+        std::vector<C> scratch(n);
+        for (size_t i = 0; i < n; ++i) scratch[i] = input[i * in_stride];
+        Result r = inverse ? ifft(scratch) : fft(scratch);
+        if (r.is_err()) return r;
+        for (size_t i = 0; i < n; ++i) output[i * out_stride] = scratch[i];
+        return Result::Ok();
+    }
+    kofft_hip_ctx *ctx_ = nullptr;
+};
+
+template <typename T>
+class FftPlanner {  // fft.rs:332-445
+public:
+    std::vector<Complex<T>> get_twiddles(size_t n) const
+    {
+        std::vector<Complex<T>> t(n / 2);
+        detail::Abi<T>::twiddles(n, reinterpret_cast<T *>(t.data()));
+        return t;
+    }
+    FftStrategy plan_strategy(size_t n) const { return (n > 1 && (n & (n - 1)) == 0) ? FftStrategy::SplitRadix : FftStrategy::Auto; }
+};
+
+template <typename T>
+class RfftPlanner {  // rfft.rs:194-338
+public:
+    std::vector<Complex<T>> get_twiddles(size_t m) const
+    {
+        std::vector<Complex<T>> t(m);
+        detail::Abi<T>::rfft_table(m, reinterpret_cast<T *>(t.data()));
+        return t;
+    }
+    Result rfft_with_scratch(const HipFftImpl<T> &fft, std::vector<T> &input, std::vector<Complex<T>> &output,
+                             std::vector<Complex<T>> &scratch) const
+    {
+        return fft.rfft_with_scratch(input, output, scratch);
+    }
+    Result irfft_with_scratch(const HipFftImpl<T> &fft, std::vector<Complex<T>> &input, std::vector<T> &output,
+                              std::vector<Complex<T>> &scratch) const
+    {
+        return fft.irfft_with_scratch(input, output, scratch);
+    }
+};
+
+// fft::batch / batch_inverse / multi_channel (fft.rs:2156-2191): serial semantics, first error wins
+template <typename T>
+Result batch(const FftImpl<T> &fft, std::vector<std::vector<Complex<T>>> &batches)
+{
+    for (auto &b : batches) {
+        Result r = fft.fft(b);
+        if (r.is_err()) return r;
+    }
+    return Result::Ok();
+}
+template <typename T>
+Result batch_inverse(const FftImpl<T> &fft, std::vector<std::vector<Complex<T>>> &batches)
+{
+    for (auto &b : batches) {
+        Result r = fft.ifft(b);
+        if (r.is_err()) return r;
+    }
+    return Result::Ok();
+}
+template <typename T>
+Result multi_channel(const FftImpl<T> &fft, std::vector<std::vector<Complex<T>>> &channels) { return batch(fft, channels); }
+
+inline std::vector<float> hann(size_t len)  // window.rs:24-28
+{
+    std::vector<float> w(len);
+    kofft_hip_hann_f32(len, w.data());
+    return w;
+}
+
+// stft::stft (stft.rs:76-105): output frames are resized to the window length and overwritten
+inline Result stft(const std::vector<float> &signal, const std::vector<float> &window, size_t hop_size,
+                   std::vector<std::vector<Complex32>> &output, const HipFftImpl<float> &fft, bool check_frames = true)
+{
+    const size_t frames = output.size(), wl = window.size();
+    std::vector<Complex32> flat(frames * wl);
+    int rc = check_frames
+                 ? kofft_hip_stft_f32(fft.raw(), signal.data(), signal.size(), window.data(), wl, hop_size,
+                                      reinterpret_cast<float *>(flat.data()), frames)
+                 : kofft_hip_stft_parallel_f32(fft.raw(), signal.data(), signal.size(), window.data(), wl, hop_size,
+                                               reinterpret_cast<float *>(flat.data()), frames);
+    Result r = fft.st(rc);
+    if (r.is_err()) return r;
+    for (size_t f = 0; f < frames; ++f) output[f].assign(flat.begin() + f * wl, flat.begin() + (f + 1) * wl);
+    return Result::Ok();
+}
+// stft::parallel (stft.rs:232-263): only hop == 0 is rejected
+inline Result parallel(const std::vector<float> &signal, const std::vector<float> &window, size_t hop_size,
+                       std::vector<std::vector<Complex32>> &output, const HipFftImpl<float> &fft)
+{
+    return stft(signal, window, hop_size, output, fft, false);
+}
+// stft::frame (stft.rs:355-372)
+inline Result frame(const std::vector<float> &signal, const std::vector<float> &window, size_t start,
+                    std::vector<Complex32> &frame_out, const HipFftImpl<float> &fft)
+{
+    if (frame_out.size() < window.size()) throw std::out_of_range("frame_out shorter than the window (the reference panics)");
+    return fft.st(kofft_hip_stft_frame_f32(fft.raw(), signal.data(), signal.size(), window.data(), window.size(), start,
+                                           reinterpret_cast<float *>(frame_out.data())));
+}
+
+class StftStream {  // stft.rs:160-206
+public:
+    static Result create(const std::vector<float> &signal, const std::vector<float> &window, size_t hop_size,
+                         const HipFftImpl<float> &fft, StftStream *&out)
+    {
+        if (hop_size == 0) return Result::Err(FftError::InvalidHopSize);
+        out = new StftStream(signal, window, hop_size, fft);
+        return Result::Ok();
+    }
+    // Ok(true) -> *more = true
+    Result next_frame(std::vector<Complex32> &out, bool &more)
+    {
+        more = false;
+        if (out.size() != window_.size()) return Result::Err(FftError::MismatchedLengths);
+        if (pos_ >= signal_.size()) return Result::Ok();
+        Result r = frame(signal_, window_, pos_, out, fft_);
+        if (r.is_err()) return r;
+        pos_ += hop_;
+        more = true;
+        return Result::Ok();
+    }
+
+private:
+    StftStream(const std::vector<float> &s, const std::vector<float> &w, size_t hop, const HipFftImpl<float> &f)
+        : signal_(s), window_(w), hop_(hop), pos_(0), fft_(f)
+    {
+    }
+    const std::vector<float> &signal_;
+    const std::vector<float> &window_;
+    size_t hop_, pos_;
+    const HipFftImpl<float> &fft_;
+};
+
+}  // namespace kofft

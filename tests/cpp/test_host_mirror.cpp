@@ -1,0 +1,170 @@
+// C++ restatement of the reference's own tests for the hot path, against the C++ host mirror
+// (include/kofft_hip.hpp) of kofft's interface.  Each block cites the reference test it mirrors.
+// The oracle (oracle/kofft_oracle.h) is linked as the checker only.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/kofft_hip.hpp"
+#include "../../oracle/kofft_oracle.h"
+
+using namespace kofft;
+static int g_fail = 0, g_checks = 0;
+#define CHECK(cond)                                                                  \
+    do {                                                                             \
+        ++g_checks;                                                                  \
+        if (!(cond)) { ++g_fail; std::printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #cond); } \
+    } while (0)
+
+static std::vector<Complex32> oracle_fft(std::vector<Complex32> x, bool inverse = false)
+{
+    ko_fft_batch_f32(reinterpret_cast<float *>(x.data()), x.size(), 1, inverse ? 1 : 0);
+    return x;
+}
+static bool same_bits(const std::vector<Complex32> &a, const std::vector<Complex32> &b)
+{
+    return a.size() == b.size() && std::memcmp(a.data(), b.data(), a.size() * sizeof(Complex32)) == 0;
+}
+
+int main()
+{
+    HipFftImpl<float> fft;  // ScalarFftImpl::<f32>::default()
+    HipFftImpl<double> fft64;
+
+    {   // lib.rs:178-199 test_fft_ifft_f32
+        std::vector<Complex32> data = {{1, 0}, {0, 0}, {0, 0}, {0, 0}};
+        fft.fft(data).unwrap();
+        for (auto &c : data) { CHECK(std::fabs(c.re - 1.0f) < 1e-6f); CHECK(std::fabs(c.im) < 1e-6f); }
+        fft.ifft(data).unwrap();
+        CHECK(std::fabs(data[0].re - 1.0f) < 1e-6f);
+        for (size_t i = 1; i < 4; ++i) { CHECK(std::fabs(data[i].re) < 1e-6f); CHECK(std::fabs(data[i].im) < 1e-6f); }
+    }
+    {   // lib.rs:254-264 test_fft_all_ones
+        std::vector<Complex32> data(8, Complex32(1, 0));
+        fft.fft(data).unwrap();
+        CHECK(std::fabs(data[0].re - 8.0f) < 1e-6f);
+        for (size_t i = 1; i < 8; ++i) { CHECK(std::fabs(data[i].re) < 1e-6f); CHECK(std::fabs(data[i].im) < 1e-6f); }
+    }
+    {   // lib.rs:322-326 test_fft_empty ; lib.rs:352-358 single element
+        std::vector<Complex32> empty;
+        CHECK(fft.fft(empty) == Result::Err(FftError::EmptyInput));
+        CHECK(fft.ifft(empty).unwrap_err() == FftError::EmptyInput);
+        std::vector<Complex32> one = {{1, 0}};
+        fft.fft(one).unwrap();
+        CHECK(one[0].re == 1.0f && one[0].im == 0.0f);
+    }
+    {   // lib.rs:329-338 test_fft_out_of_place_mismatched_lengths
+        std::vector<Complex32> in = {{1, 0}, {2, 0}}, out(3);
+        CHECK(fft.fft_out_of_place(in, out) == Result::Err(FftError::MismatchedLengths));
+    }
+    {   // tests/stockham_parity.rs + tests/stockham_large.rs + tests/parallel_stockham.rs inputs, vs the oracle, bit for bit
+        for (size_t n : {32u, 64u, 128u, 256u, 512u, 1024u, 4096u}) {
+            std::vector<Complex32> data(n);
+            for (size_t i = 0; i < n; ++i) data[i] = Complex32((float)i, -(float)i * 0.25f);
+            auto expected = oracle_fft(data);
+            fft.stockham_fft(data).unwrap();
+            CHECK(same_bits(data, expected));
+        }
+    }
+    {   // examples/basic_usage.rs:232-241 (BASELINE config #1): 1024-pt FFT of sin(0.1 i)
+        std::vector<Complex32> sig(1024);
+        for (size_t i = 0; i < 1024; ++i) sig[i] = Complex32(std::sin(0.1f * (float)i), 0.0f);
+        auto expected = oracle_fft(sig);
+        fft.fft(sig).unwrap();
+        CHECK(same_bits(sig, expected));
+    }
+    {   // fft_strided error order (fft.rs:1181-1190) and result
+        std::vector<Complex32> buf(8), scratch(4), none;
+        CHECK(fft.fft_strided(buf, 0, scratch) == Result::Err(FftError::InvalidStride));
+        std::vector<Complex32> small(6);
+        CHECK(fft.fft_strided(small, 2, scratch) == Result::Err(FftError::MismatchedLengths));
+        CHECK(fft.fft_strided(buf, 2, none).is_ok());
+        for (size_t i = 0; i < 8; ++i) buf[i] = Complex32((float)i, 1.0f);
+        std::vector<Complex32> picked = {buf[0], buf[2], buf[4], buf[6]};
+        auto want = oracle_fft(picked);
+        fft.fft_strided(buf, 2, scratch).unwrap();
+        CHECK(buf[0] == want[0] && buf[2] == want[1] && buf[4] == want[2] && buf[6] == want[3]);
+        CHECK(buf[1] == Complex32(1, 1));
+    }
+    {   // rfft.rs:892-907 rfft_irfft_roundtrip + lib.rs:470-478 mismatched lengths + rfft.rs:433-443 order
+        std::vector<float> input = {1, 2, 3, 4, 5, 6, 7, 8}, orig = input, out(8);
+        std::vector<Complex32> freq(5), scratch(4);
+        fft.rfft_with_scratch(input, freq, scratch).unwrap();
+        fft.irfft_with_scratch(freq, out, scratch).unwrap();
+        for (size_t i = 0; i < 8; ++i) CHECK(std::fabs(orig[i] - out[i]) < 1e-5f);
+        CHECK(std::fabs(freq[0].im) < 1e-6f && std::fabs(freq[4].im) < 1e-6f);  // lib.rs:451-467
+        std::vector<float> four = {1, 2, 3, 4}, none, odd = {1, 2, 3};
+        std::vector<Complex32> wrong(4), two(2);
+        CHECK(fft.rfft(four, wrong) == Result::Err(FftError::MismatchedLengths));
+        CHECK(fft.rfft(none, two) == Result::Err(FftError::EmptyInput));
+        CHECK(fft.rfft(odd, two) == Result::Err(FftError::InvalidValue));
+        // f64 (rfft.rs:921-936)
+        std::vector<double> in64 = {1, 2, 3, 4, 5, 6, 7, 8}, o64(8);
+        std::vector<Complex64> f64(5), s64(4);
+        fft64.rfft_with_scratch(in64, f64, s64).unwrap();
+        fft64.irfft_with_scratch(f64, o64, s64).unwrap();
+        for (size_t i = 0; i < 8; ++i) CHECK(std::fabs(o64[i] - (double)(i + 1)) < 1e-10);
+    }
+    {   // tests/rfft_twiddles.rs + tests/twiddle.rs table entries
+        auto tw = RfftPlanner<float>().get_twiddles(8);
+        CHECK(tw.size() == 8);
+        CHECK(std::fabs(tw[1].re - std::cos(-3.14159274f / 8.0f)) < 1e-6f && std::fabs(tw[1].im - std::sin(-3.14159274f / 8.0f)) < 1e-6f);
+        auto t32 = FftPlanner<float>().get_twiddles(8);
+        CHECK(std::fabs(t32[1].re - std::cos(-2.0f * 3.14159274f / 8.0f)) < 1e-6f);
+        CHECK(FftPlanner<float>().plan_strategy(4096) == FftStrategy::SplitRadix);
+    }
+    {   // tests/stft.rs:6-14 + stft.rs:560-580 batch round-trip shape + stft.rs:690-697 zero hop + window.rs:104-109
+        auto w = hann(8);
+        CHECK(std::fabs(w[0]) < 1e-6f && std::fabs(w[4] - 1.0f) < 1e-6f);
+        std::vector<float> signal(10, 0.0f);
+        auto window = hann(4);
+        std::vector<std::vector<Complex32>> frames(2);
+        CHECK(stft(signal, window, 4, frames, fft) == Result::Err(FftError::MismatchedLengths));
+        std::vector<std::vector<Complex32>> four(4);
+        CHECK(stft(signal, window, 0, four, fft) == Result::Err(FftError::InvalidHopSize));
+        std::vector<float> sig = {1, 2, 3, 4, 5, 6, 7, 8}, ones(4, 1.0f);
+        stft(sig, ones, 2, four, fft).unwrap();
+        std::vector<float> want(4 * 4 * 2);
+        ko_stft_f32(sig.data(), 8, ones.data(), 4, 2, want.data(), 4);
+        for (size_t f = 0; f < 4; ++f) CHECK(four[f].size() == 4 && std::memcmp(four[f].data(), &want[f * 8], 32) == 0);
+        std::vector<std::vector<Complex32>> two(2);
+        parallel(sig, ones, 2, two, fft).unwrap();  // fewer frames than stft() demands: parallel() does not check
+        CHECK(std::memcmp(two[1].data(), &want[8], 32) == 0);
+        StftStream *stream = nullptr;
+        CHECK(StftStream::create(sig, ones, 0, fft, stream) == Result::Err(FftError::InvalidHopSize));
+        StftStream::create(sig, ones, 2, fft, stream).unwrap();
+        std::vector<Complex32> buf(4), bad(3);
+        bool more = false;
+        CHECK(stream->next_frame(bad, more) == Result::Err(FftError::MismatchedLengths));
+        size_t count = 0;
+        while (stream->next_frame(buf, more).is_ok() && more) {
+            CHECK(std::memcmp(buf.data(), &want[count * 8], 32) == 0);
+            ++count;
+        }
+        CHECK(count == 4);
+        delete stream;
+    }
+    {   // fft::batch over ragged slices (fft.rs:2156-2164) + contiguous batch entry
+        std::vector<std::vector<Complex32>> vs(3);
+        vs[0].assign(64, Complex32(1, -1)); vs[1].assign(64, Complex32(0.5f, 2)); vs[2].assign(256, Complex32(3, 0));
+        vs[0][3] = Complex32(7, 7);
+        auto w0 = oracle_fft(vs[0]), w2 = oracle_fft(vs[2]);
+        batch<float>(fft, vs).unwrap();
+        CHECK(same_bits(vs[0], w0) && same_bits(vs[2], w2));
+        std::vector<Complex32> flat(4 * 4096);
+        for (size_t i = 0; i < flat.size(); ++i) flat[i] = Complex32(std::sin((float)i), std::cos((float)i));
+        std::vector<Complex32> row(flat.begin() + 2 * 4096, flat.begin() + 3 * 4096);
+        auto wr = oracle_fft(row);
+        fft.fft_batch(flat, 4096).unwrap();
+        CHECK(std::memcmp(&flat[2 * 4096], wr.data(), 4096 * 8) == 0);
+    }
+    {   // non-power-of-two: the device path reports it (DeviceError), it does not mis-compute
+        std::vector<Complex32> twelve(12);
+        bool threw = false;
+        try { fft.fft(twelve); } catch (const DeviceError &e) { threw = e.status == KOFFT_ERR_UNSUPPORTED; }
+        CHECK(threw);
+    }
+    std::printf("%d checks, %d failed\n", g_checks, g_fail);
+    return g_fail == 0 ? 0 : 1;
+}
