@@ -265,7 +265,7 @@ def main():
         avg_kernel_s = float(np.mean(kern_ms)) / 1e3
         achieved = alg_bytes / avg_kernel_s / 1e9
         traffic = None
-        tfile = ROOT / "profiles" / "traffic_latest.json"
+        tfile = ROOT / "profiles" / f"traffic_{args.workload}.json"
         if tfile.exists():
             try:
                 tj = json.loads(tfile.read_text())

@@ -57,7 +57,7 @@ struct BigColsIO {
 template <typename T, bool INVERSE>
 struct BigRowsIO {
     static constexpr bool kStreams = false;
-    static constexpr bool kSlotMinor = false;
+    static constexpr bool kSlotMinor = true;  // lanes run over adjacent rows K: 64-byte segments for loads and stores
     const cpx<T> *__restrict__ in;
     cpx<T> *__restrict__ out;
     int LA, LB;

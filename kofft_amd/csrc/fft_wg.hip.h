@@ -36,6 +36,7 @@ template <typename T, bool INVERSE>
 struct ComplexIO : PlainTw {
     static constexpr bool kStreams = true;  // cheap load/store: eligible for the persistent prefetching kernel
     static constexpr bool kInvInLds = false;
+    static constexpr bool kLeanRegisters = true;
     using Raw = cpx<T>;
     using Inv = NoInv;
     const cpx<T> *__restrict__ in;
@@ -85,6 +86,7 @@ struct ComplexIO : PlainTw {
 struct StftIO : PlainTw {
     static constexpr bool kStreams = true;
     static constexpr bool kInvInLds = false;  // 16 window samples per thread: registers
+    static constexpr bool kLeanRegisters = false;
     using Raw = float;
     using Inv = float;
     const float *__restrict__ signal;
@@ -131,6 +133,7 @@ template <typename T>
 struct RfftIO : PlainTw {
     static constexpr bool kStreams = true;
     static constexpr bool kInvInLds = true;  // window pairs + post-pass table: staged in LDS once per workgroup
+    static constexpr bool kLeanRegisters = false;
     using Raw = cpx<T>;
     using Inv = cpx<T>;
     const T *__restrict__ in;         // batch rows of 2*m reals

@@ -148,14 +148,18 @@ int launch_wg(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t batch)
 // n = 1024: one wavefront per transform (wave-synchronous exchanges), four per workgroup.
 // Every workgroup walks the batch with a stride of the grid size and keeps the next transform's
 // loads in flight while it computes.
-template <int L> struct PersistCfg;
-template <> struct PersistCfg<12> { static constexpr int BLOCK = 256, NBUF = 1, MINW = 2, WG_PER_CU = 2; };
-template <> struct PersistCfg<10> { static constexpr int BLOCK = 256, NBUF = 1, MINW = 2, WG_PER_CU = 2; };
+// Waves per SIMD are set per IO policy: the plain complex n = 1024 kernel fits 3 waves/SIMD (156 VGPRs); the STFT
+// and rfft variants carry window / post-pass operands and spill at 168, so they run 2 waves/SIMD.
+template <int L, class IO> struct PersistCfg;
+template <class IO> struct PersistCfg<12, IO> { static constexpr int BLOCK = 256, NBUF = 1, MINW = 2, WG_PER_CU = 2; };
+template <class IO> struct PersistCfg<10, IO> {
+    static constexpr int BLOCK = 256, NBUF = 1, MINW = IO::kLeanRegisters ? 3 : 2, WG_PER_CU = MINW;
+};
 
 template <typename T, int L, int EPI, class IO>
 int launch_persist(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t batch)
 {
-    using Cfg = PersistCfg<L>;
+    using Cfg = PersistCfg<L, IO>;
     constexpr int RL = 4;
     constexpr int XPB = Cfg::BLOCK / ((1 << L) >> RL);
     constexpr size_t lds = (size_t)XPB * Cfg::NBUF * lds_elems(1 << L) * sizeof(cpx<T>) +
