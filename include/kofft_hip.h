@@ -155,6 +155,20 @@ int kofft_hip_stft_f32_dev(kofft_hip_ctx *ctx, const float *d_signal, size_t len
                            const float *d_window, size_t win_len, size_t hop, float *d_out,
                            size_t first_frame, size_t count);
 
+/* ---- ISTFT (SURVEY 8f "next" row 1) --------------------------------------------
+ * stft::istft (stft.rs:117-156): every frame is inverse-transformed IN PLACE (frames_data:
+ * frames * win_len complex, contiguous), then overlap-added into `output` (accumulated:
+ * the reference does not clear it) with window-square normalisation where the sum exceeds
+ * 1e-8; `scratch` receives the window-square sums.  hop == 0 -> INVALID_HOP_SIZE;
+ * scratch_len != out_len -> MISMATCHED_LENGTHS.  The per-sample sums run in frame order,
+ * exactly as the reference's loop nest does (no atomics). */
+int kofft_hip_istft_f32(kofft_hip_ctx *ctx, float *frames_data, size_t frames, const float *window,
+                        size_t win_len, size_t hop, float *output, size_t out_len, float *scratch,
+                        size_t scratch_len);
+int kofft_hip_istft_f32_dev(kofft_hip_ctx *ctx, float *d_frames, size_t frames, const float *d_window,
+                            size_t win_len, size_t hop, float *d_output, size_t out_len,
+                            float *d_scratch, size_t scratch_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,7 +9,7 @@
 //   kofft::HipFftImpl<T>  ~ ScalarFftImpl<T>     fft.rs:600-613 + RealFftImpl blanket methods (rfft.rs:775-837)
 //   kofft::FftPlanner<T>, RfftPlanner<T>         fft.rs:332-445, rfft.rs:194-338
 //   kofft::batch / batch_inverse / multi_channel fft.rs:2156-2191
-//   kofft::stft / parallel / frame / StftStream  stft.rs:76-105, 232-263, 355-372, 160-206
+//   kofft::stft / istft / parallel / frame / StftStream  stft.rs:76-156, 232-263, 355-372, 160-206
 //   kofft::hann                                  window.rs:24-28
 //
 // Result<(), FftError> becomes kofft::Result (is_ok / is_err / unwrap / unwrap_err).  A negative C-ABI status
@@ -17,6 +17,7 @@
 // the Rust shim's panic.
 #pragma once
 
+#include <algorithm>
 #include <cstddef>
 #include <stdexcept>
 #include <string>
@@ -338,6 +339,23 @@ inline Result stft(const std::vector<float> &signal, const std::vector<float> &w
     Result r = fft.st(rc);
     if (r.is_err()) return r;
     for (size_t f = 0; f < frames; ++f) output[f].assign(flat.begin() + f * wl, flat.begin() + (f + 1) * wl);
+    return Result::Ok();
+}
+// stft::istft (stft.rs:117-156): frames are inverse-transformed in place; output is accumulated into and normalised
+inline Result istft(std::vector<std::vector<Complex32>> &frames, const std::vector<float> &window, size_t hop_size,
+                    std::vector<float> &output, std::vector<float> &scratch, const HipFftImpl<float> &fft)
+{
+    if (hop_size == 0) return Result::Err(FftError::InvalidHopSize);
+    if (scratch.size() != output.size()) return Result::Err(FftError::MismatchedLengths);
+    const size_t wl = window.size();
+    for (auto &f : frames)
+        if (f.size() != wl) return Result::Err(FftError::MismatchedLengths);
+    std::vector<Complex32> flat(frames.size() * wl);
+    for (size_t f = 0; f < frames.size(); ++f) std::copy(frames[f].begin(), frames[f].end(), flat.begin() + f * wl);
+    Result r = fft.st(kofft_hip_istft_f32(fft.raw(), reinterpret_cast<float *>(flat.data()), frames.size(), window.data(), wl,
+                                          hop_size, output.data(), output.size(), scratch.data(), scratch.size()));
+    if (r.is_err()) return r;
+    for (size_t f = 0; f < frames.size(); ++f) frames[f].assign(flat.begin() + f * wl, flat.begin() + (f + 1) * wl);
     return Result::Ok();
 }
 // stft::parallel (stft.rs:232-263): only hop == 0 is rejected

@@ -330,6 +330,36 @@ __global__ __launch_bounds__(BLOCK) void fft_wg_kernel(const IO io, const cpx<T>
     }
 }
 
+// ---- ISTFT overlap-add (stft.rs:135-154) --------------------------------------------------------------------------
+// The reference adds frame f's contribution to output[f*hop + i] for f = 0, 1, 2, ... in order.  One thread per output
+// sample s replays exactly that order for its own sample: frames f_lo .. f_hi (those with f*hop <= s < f*hop + win_len),
+// increasing f, acc += frame[f][s - f*hop].re * window[i]; norm += window[i]*window[i]; then the > 1e-8 normalisation.
+// No atomics, so the f32 sums are the reference's sums bit for bit.  `frames` holds the already inverse-transformed
+// frames (the reference transforms them in place too).
+__global__ __launch_bounds__(256) void istft_ola_kernel(const cpx<float> *__restrict__ frames, const float *__restrict__ window,
+                                                        float *__restrict__ output, float *__restrict__ scratch,
+                                                        const size_t nframes, const size_t win_len, const size_t hop,
+                                                        const size_t out_len)
+{
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= out_len) return;
+    float acc = output[s];  // istft accumulates into the caller's buffer (stft.rs:144)
+    float norm = 0.0f;      // scratch is cleared first (stft.rs:132-134)
+    if (nframes > 0 && win_len > 0) {
+        size_t f_hi = s / hop;
+        if (f_hi > nframes - 1) f_hi = nframes - 1;
+        const size_t f_lo = (s >= win_len) ? (s - win_len) / hop + 1 : 0;
+        for (size_t f = f_lo; f <= f_hi; ++f) {
+            const size_t i = s - f * hop;
+            const float w = window[i];
+            acc = acc + frames[f * win_len + i].re * w;
+            norm = norm + w * w;
+        }
+    }
+    scratch[s] = norm;
+    output[s] = (norm > 1e-8f) ? acc / norm : acc;  // stft.rs:150-154
+}
+
 // ---- n = 1, 2, 4, 8, 16: one thread per transform, straight-line kernels ---------
 // (fft.rs:1059-1071 dispatch; ifft wraps them with conj / conj*scale via the IO policy)
 template <typename T, int N, int EPI, class IO>

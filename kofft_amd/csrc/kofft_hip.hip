@@ -498,6 +498,31 @@ int stft_host(kofft_hip_ctx *ctx, const float *signal, size_t len, const float *
     return KOFFT_OK;
 }
 
+// stft::istft (stft.rs:117-156): ifft every frame in place, overlap-add, normalise.
+int istft_dev(kofft_hip_ctx *ctx, float *d_frames, size_t frames, const float *d_window, size_t win_len, size_t hop,
+              float *d_output, size_t out_len, float *d_scratch, size_t scratch_len)
+{
+    if (hop == 0) return KOFFT_ERR_INVALID_HOP_SIZE;                  // stft.rs:125
+    if (scratch_len != out_len) return KOFFT_ERR_MISMATCHED_LENGTHS;  // stft.rs:128
+    if (frames > 0 && win_len == 0) return KOFFT_ERR_EMPTY_INPUT;     // fft.ifft(&mut []) -> fft.rs:1136
+    if (frames > 0 && (!is_pow2(win_len) || win_len > (size_t(1) << max_log2<float>()))) return KOFFT_ERR_UNSUPPORTED;
+    if (!ctx || (frames && (!d_frames || !d_window)) || (out_len && (!d_output || !d_scratch))) return KOFFT_ERR_NULL;
+    KOFFT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (frames > 0) {
+        int rc = fft_dev<float>(ctx, d_frames, d_frames, win_len, frames, 1);
+        if (rc) return rc;
+    }
+    if (out_len > 0) {
+        const size_t blocks = (out_len + 255) / 256;
+        if (blocks > 0x7fffffffULL) return KOFFT_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(istft_ola_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
+                           reinterpret_cast<const cpx<float> *>(d_frames), d_window, d_output, d_scratch, frames, win_len, hop,
+                           out_len);
+        KOFFT_HIP_TRY(ctx, hipGetLastError());
+    }
+    return KOFFT_OK;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------
@@ -723,6 +748,44 @@ int kofft_hip_stft_f32_dev(kofft_hip_ctx *ctx, const float *d_signal, size_t len
 {
     if (hop == 0) return KOFFT_ERR_INVALID_HOP_SIZE;  // stft.rs:83 / 242
     return stft_dev(ctx, d_signal, len, d_window, win_len, first_frame * hop, hop, d_out, count);
+}
+
+int kofft_hip_istft_f32_dev(kofft_hip_ctx *ctx, float *d_frames, size_t frames, const float *d_window, size_t win_len,
+                            size_t hop, float *d_output, size_t out_len, float *d_scratch, size_t scratch_len)
+{
+    return istft_dev(ctx, d_frames, frames, d_window, win_len, hop, d_output, out_len, d_scratch, scratch_len);
+}
+
+int kofft_hip_istft_f32(kofft_hip_ctx *ctx, float *frames_data, size_t frames, const float *window, size_t win_len,
+                        size_t hop, float *output, size_t out_len, float *scratch, size_t scratch_len)
+{
+    if (hop == 0) return KOFFT_ERR_INVALID_HOP_SIZE;
+    if (scratch_len != out_len) return KOFFT_ERR_MISMATCHED_LENGTHS;
+    if (frames > 0 && win_len == 0) return KOFFT_ERR_EMPTY_INPUT;
+    if (frames > 0 && (!is_pow2(win_len) || win_len > (size_t(1) << max_log2<float>()))) return KOFFT_ERR_UNSUPPORTED;
+    if (!ctx || (frames && (!frames_data || !window)) || (out_len && (!output || !scratch))) return KOFFT_ERR_NULL;
+    KOFFT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t fr_bytes = frames * win_len * 2 * sizeof(float);
+    const size_t o_bytes = out_len * sizeof(float);
+    // one staging allocation: [frames | output | scratch | window]
+    const size_t a0 = 0, a1 = (fr_bytes + 255) & ~size_t(255), a2 = a1 + ((o_bytes + 255) & ~size_t(255)),
+                 a3 = a2 + ((o_bytes + 255) & ~size_t(255)), total = a3 + win_len * sizeof(float) + 256;
+    int rc = ensure_stage(ctx, 0, total);
+    if (rc) return rc;
+    char *base = static_cast<char *>(ctx->stage[0]);
+    if (fr_bytes) KOFFT_HIP_TRY(ctx, hipMemcpyAsync(base + a0, frames_data, fr_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (o_bytes) KOFFT_HIP_TRY(ctx, hipMemcpyAsync(base + a1, output, o_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (win_len) KOFFT_HIP_TRY(ctx, hipMemcpyAsync(base + a3, window, win_len * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    rc = istft_dev(ctx, reinterpret_cast<float *>(base + a0), frames, reinterpret_cast<const float *>(base + a3), win_len, hop,
+                   reinterpret_cast<float *>(base + a1), out_len, reinterpret_cast<float *>(base + a2), scratch_len);
+    if (rc) return rc;
+    if (fr_bytes) KOFFT_HIP_TRY(ctx, hipMemcpyAsync(frames_data, base + a0, fr_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (o_bytes) {
+        KOFFT_HIP_TRY(ctx, hipMemcpyAsync(output, base + a1, o_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        KOFFT_HIP_TRY(ctx, hipMemcpyAsync(scratch, base + a2, o_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    KOFFT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return KOFFT_OK;
 }
 
 }  // extern "C"

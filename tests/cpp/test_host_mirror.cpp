@@ -128,6 +128,14 @@ int main()
         std::vector<float> want(4 * 4 * 2);
         ko_stft_f32(sig.data(), 8, ones.data(), 4, 2, want.data(), 4);
         for (size_t f = 0; f < 4; ++f) CHECK(four[f].size() == 4 && std::memcmp(four[f].data(), &want[f * 8], 32) == 0);
+        {   // stft.rs:560-580 test_stft_istft_batch_roundtrip
+            auto fr = four;
+            std::vector<float> output(8, 0.0f), scr(8, 0.0f), bad(7);
+            istft(fr, ones, 2, output, scr, fft).unwrap();
+            for (size_t i = 0; i < 8; ++i) CHECK(std::fabs(output[i] - sig[i]) < 1e-4f);
+            CHECK(istft(fr, ones, 0, output, scr, fft) == Result::Err(FftError::InvalidHopSize));
+            CHECK(istft(fr, ones, 2, output, bad, fft) == Result::Err(FftError::MismatchedLengths));
+        }
         std::vector<std::vector<Complex32>> two(2);
         parallel(sig, ones, 2, two, fft).unwrap();  // fewer frames than stft() demands: parallel() does not check
         CHECK(std::memcmp(two[1].data(), &want[8], 32) == 0);
