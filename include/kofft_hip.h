@@ -169,6 +169,19 @@ int kofft_hip_istft_f32_dev(kofft_hip_ctx *ctx, float *d_frames, size_t frames, 
                             size_t win_len, size_t hop, float *d_output, size_t out_len,
                             float *d_scratch, size_t scratch_len);
 
+/* ---- STFT magnitudes (SURVEY 8f "next" row 2) --------------------------------------
+ * visual::spectrogram::stft_magnitudes (visual/spectrogram.rs:52-76): STFT with a Hann window of
+ * win_len (window::hann), keeping bins 0 .. win_len/2-1 of every frame as f32 magnitudes
+ * sqrt(re*re + im*im), plus the maximum magnitude (0.0 if there are none; NaN never selected).
+ * mags: frames * (win_len/2) floats, frames >= ceil(len/hop) (the reference allocates exactly that
+ * many).  hop == 0 -> INVALID_HOP_SIZE (the reference would panic dividing by it).  The magnitude
+ * is fused into the transform's store: 4x fewer output bytes than stft + a second pass. */
+int kofft_hip_stft_magnitudes_f32(kofft_hip_ctx *ctx, const float *samples, size_t len, size_t win_len,
+                                  size_t hop, float *mags, size_t frames, float *max_mag);
+int kofft_hip_stft_magnitudes_f32_dev(kofft_hip_ctx *ctx, const float *d_samples, size_t len,
+                                      size_t win_len, size_t hop, float *d_mags, size_t frames,
+                                      float *d_max);
+
 #ifdef __cplusplus
 }
 #endif

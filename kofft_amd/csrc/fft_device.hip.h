@@ -95,6 +95,11 @@ __device__ __forceinline__ void buf_store_cpx(cpx<T> c, rsrc_t r, int voff, int 
     }
 }
 
+__device__ __forceinline__ void buf_store_f32(float v, rsrc_t r, int voff, int coff)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, coff, AUX_DEFAULT);
+}
+
 template <int AUX>
 __device__ __forceinline__ float buf_load_f32(rsrc_t r, int voff, int coff)
 {

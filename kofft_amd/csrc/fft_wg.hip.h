@@ -126,6 +126,42 @@ struct StftIO : PlainTw {
     }
 };
 
+// visual::spectrogram::stft_magnitudes (visual/spectrogram.rs:52-76), SURVEY 8f row 2: the STFT of stft.rs:91-103 with
+// only bins 0 .. n/2-1 kept, as magnitudes sqrt(re*re + im*im) in f32 (un-fused, correctly rounded sqrt).  Fusing the
+// magnitude into the store cuts the output from 8 B x n to 4 B x n/2 per frame.  The maximum is a separate reduction.
+struct StftMagIO : StftIO {
+    float *__restrict__ mags;  // frames x n/2
+    // sqrtf is correctly rounded here (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt); __fsqrt_rn is not
+    __device__ __forceinline__ static float mag(cpx<float> c) { return sqrtf(c.re * c.re + c.im * c.im); }
+    __device__ __forceinline__ void store(size_t xf, int o, cpx<float> v) const
+    {
+        if (o < n / 2) mags[xf * (size_t)(n / 2) + o] = mag(v);
+    }
+    __device__ __forceinline__ rsrc_t out_desc(size_t xf) const { return make_rsrc(mags + xf * (size_t)(n / 2), (unsigned)(n / 2) * 4u); }
+    __device__ __forceinline__ void store_d(rsrc_t d, int lane_bytes, int ou, cpx<float> v) const
+    {
+        // lane_bytes = 8 * tau (complex offset); the magnitude row has 4-byte elements
+        if (ou + (lane_bytes >> 3) < n / 2) buf_store_f32(mag(v), d, lane_bytes >> 1, ou * 4);
+    }
+};
+
+// max over a non-negative f32 array, NaN never selected (spectrogram.rs:69-71: `if mag > max_mag`): non-negative floats
+// order like their bit patterns, so an unsigned atomicMax is exact whatever the order of arrival.
+__global__ __launch_bounds__(256) void max_nonneg_kernel(const float *__restrict__ x, const size_t count, unsigned *__restrict__ out_bits)
+{
+    float m = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        if (v > m) m = v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float o = __shfl_xor(m, off);
+        if (o > m) m = o;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __builtin_bit_cast(unsigned, m));
+}
+
 // rfft.rs:444-446 pack z[i] = (x[2i], x[2i+1]) (with the optional row window of the
 // batched entry point); the post-pass of rfft.rs:450-463 runs in the kernel epilogue,
 // which writes the m+1 outputs.

@@ -523,6 +523,51 @@ int istft_dev(kofft_hip_ctx *ctx, float *d_frames, size_t frames, const float *d
     return KOFFT_OK;
 }
 
+// visual::spectrogram::stft_magnitudes (visual/spectrogram.rs:52-76): hann(win_len) window, frames x win_len/2 magnitudes
+// and their maximum.  d_max receives one float.
+int stft_mag_dev(kofft_hip_ctx *ctx, const float *d_samples, size_t len, size_t win_len, size_t hop, float *d_mags,
+                 size_t frames, float *d_max)
+{
+    if (hop == 0) return KOFFT_ERR_INVALID_HOP_SIZE;  // the reference divides by hop (div_ceil) and would panic
+    const size_t required = (len + hop - 1) / hop;
+    if (frames < required) return KOFFT_ERR_MISMATCHED_LENGTHS;
+    if (frames > 0 && win_len == 0) return KOFFT_ERR_EMPTY_INPUT;
+    if (frames > 0 && (!is_pow2(win_len) || win_len > (size_t(1) << max_log2<float>()))) return KOFFT_ERR_UNSUPPORTED;
+    if (!ctx || !d_max || (frames && (!d_mags || (!d_samples && len)))) return KOFFT_ERR_NULL;
+    KOFFT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    KOFFT_HIP_TRY(ctx, hipMemsetAsync(d_max, 0, sizeof(float), ctx->stream));  // max_mag starts at 0.0
+    if (frames == 0) return KOFFT_OK;
+    // hann(win_len), cached per context like a planner table (kind 4)
+    const float *d_win = nullptr;
+    {
+        auto key = std::make_pair(4, win_len);
+        auto it = ctx->tables.find(key);
+        if (it == ctx->tables.end()) {
+            std::vector<float> w(win_len);
+            kofft_tables::hann_f32(win_len, w.data());
+            void *d = nullptr;
+            KOFFT_HIP_TRY(ctx, hipMalloc(&d, win_len * sizeof(float)));
+            KOFFT_HIP_TRY(ctx, hipMemcpy(d, w.data(), win_len * sizeof(float), hipMemcpyHostToDevice));
+            ctx->tables[key] = d;
+            d_win = static_cast<const float *>(d);
+        } else {
+            d_win = static_cast<const float *>(it->second);
+        }
+    }
+    StftMagIO io{{{}, d_samples, d_win, nullptr, len, hop, 0, (int)win_len}, d_mags};
+    int rc = dispatch<float, EPI_STORE>(ctx, io, win_len, frames);
+    if (rc) return rc;
+    const size_t count = frames * (win_len / 2);
+    if (count > 0) {
+        size_t blocks = (count + 255) / 256;
+        if (blocks > (size_t)ctx->num_cus * 8) blocks = (size_t)ctx->num_cus * 8;
+        hipLaunchKernelGGL(max_nonneg_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_mags, count,
+                           reinterpret_cast<unsigned *>(d_max));
+        KOFFT_HIP_TRY(ctx, hipGetLastError());
+    }
+    return KOFFT_OK;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------
@@ -784,6 +829,38 @@ int kofft_hip_istft_f32(kofft_hip_ctx *ctx, float *frames_data, size_t frames, c
         KOFFT_HIP_TRY(ctx, hipMemcpyAsync(output, base + a1, o_bytes, hipMemcpyDeviceToHost, ctx->stream));
         KOFFT_HIP_TRY(ctx, hipMemcpyAsync(scratch, base + a2, o_bytes, hipMemcpyDeviceToHost, ctx->stream));
     }
+    KOFFT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return KOFFT_OK;
+}
+
+int kofft_hip_stft_magnitudes_f32_dev(kofft_hip_ctx *ctx, const float *d_samples, size_t len, size_t win_len, size_t hop,
+                                      float *d_mags, size_t frames, float *d_max)
+{
+    return stft_mag_dev(ctx, d_samples, len, win_len, hop, d_mags, frames, d_max);
+}
+
+int kofft_hip_stft_magnitudes_f32(kofft_hip_ctx *ctx, const float *samples, size_t len, size_t win_len, size_t hop,
+                                  float *mags, size_t frames, float *max_mag)
+{
+    if (hop == 0) return KOFFT_ERR_INVALID_HOP_SIZE;
+    if (frames < (len + hop - 1) / hop) return KOFFT_ERR_MISMATCHED_LENGTHS;
+    if (frames > 0 && win_len == 0) return KOFFT_ERR_EMPTY_INPUT;
+    if (frames > 0 && (!is_pow2(win_len) || win_len > (size_t(1) << max_log2<float>()))) return KOFFT_ERR_UNSUPPORTED;
+    if (!ctx || !max_mag || (frames && (!mags || (!samples && len)))) return KOFFT_ERR_NULL;
+    KOFFT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t m_bytes = frames * (win_len / 2) * sizeof(float);
+    int rc = ensure_stage(ctx, 0, (len ? len : 1) * sizeof(float));
+    if (rc) return rc;
+    rc = ensure_stage(ctx, 1, m_bytes + 256);
+    if (rc) return rc;
+    rc = ensure_stage(ctx, 2, 256);
+    if (rc) return rc;
+    if (len) KOFFT_HIP_TRY(ctx, hipMemcpyAsync(ctx->stage[0], samples, len * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    rc = stft_mag_dev(ctx, static_cast<const float *>(ctx->stage[0]), len, win_len, hop, static_cast<float *>(ctx->stage[1]), frames,
+                      static_cast<float *>(ctx->stage[2]));
+    if (rc) return rc;
+    if (m_bytes) KOFFT_HIP_TRY(ctx, hipMemcpyAsync(mags, ctx->stage[1], m_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    KOFFT_HIP_TRY(ctx, hipMemcpyAsync(max_mag, ctx->stage[2], sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     KOFFT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return KOFFT_OK;
 }

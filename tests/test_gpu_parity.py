@@ -456,3 +456,19 @@ def test_istft_reference_tests(fft32, oracle):
     got = pre.copy()
     K.istft(spec.copy(), window, 2, got, np.zeros(8, np.float32), fft32)
     assert bits_equal(got, want)
+
+
+# ---- STFT magnitudes -----------------------------------------------------------------------------------
+@pytest.mark.parametrize("win_len,hop,length", [(4, 2, 10), (64, 16, 1000), (256, 64, 5000), (1024, 256, 20000), (1024, 256, 2_200_000)])
+def test_stft_magnitudes_match_oracle(fft32, oracle, win_len, hop, length):
+    """visual::spectrogram::stft_magnitudes (visual/spectrogram.rs:52-76): Hann STFT, first win_len/2 bins as
+    sqrt(re*re + im*im) in f32, and the maximum.  The last size takes the streaming kernel with the fused store."""
+    rng = seeded(1400 + win_len)
+    samples = rng.uniform(-1, 1, length).astype(np.float32)
+    frames = -(-length // hop)
+    spec = oracle.stft(samples, oracle.hann(win_len), hop, frames)[:, : win_len // 2]
+    re, im = spec.real.astype(np.float32), spec.imag.astype(np.float32)
+    want = np.sqrt((re * re + im * im).astype(np.float32)).astype(np.float32)  # f32 products, f32 sum, correctly rounded sqrt
+    mags, mx = fft32.stft_magnitudes(samples, win_len, hop)
+    assert_parity(mags, want, f"stft_magnitudes win={win_len}", REL_TOL_F32)
+    assert mx == float(want.max())
