@@ -33,6 +33,9 @@ template <typename T, bool INVERSE>
 struct BigColsIO {
     static constexpr bool kStreams = false;
     static constexpr bool kSlotMinor = true;
+    static constexpr bool kPairXcd = true;
+    static constexpr bool kSplitLds = sizeof(T) == 8;  // c64: 8-byte exchange elements (re / im in two rounds), 8-column tiles fit twice per CU
+    static constexpr int kMinWaves = sizeof(T) == 8 ? 4 : 1;  // two 512-thread workgroups per CU need <= 128 VGPRs
     const cpx<T> *__restrict__ in;
     cpx<T> *__restrict__ out;
     int LB;     // log2 of the column count
@@ -58,6 +61,9 @@ template <typename T, bool INVERSE>
 struct BigRowsIO {
     static constexpr bool kStreams = false;
     static constexpr bool kSlotMinor = true;  // lanes run over adjacent rows K: 64-byte segments for loads and stores
+    static constexpr bool kPairXcd = true;
+    static constexpr bool kSplitLds = sizeof(T) == 8;
+    static constexpr int kMinWaves = sizeof(T) == 8 ? 4 : 1;
     const cpx<T> *__restrict__ in;
     cpx<T> *__restrict__ out;
     int LA, LB;

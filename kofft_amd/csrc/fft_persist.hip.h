@@ -60,28 +60,7 @@ __device__ __forceinline__ void reg_pass_r(cpx<T> *v, const cpx<T> *twr)
 }
 
 template <int L, int RL, int P>
-struct PassGeom {
-    static constexpr int N = 1 << L;
-    static constexpr int R = 1 << RL;
-    static constexpr int TPT = N / R;
-    static constexpr int NP = (L + RL - 1) / RL;
-    static constexpr int S0 = P * RL;
-    static constexpr int Q = (P == NP - 1) ? (L - RL * (NP - 1)) : RL;
-    static constexpr int G = R >> Q;
-    static constexpr int JB = L - S0 - Q;
-    // element index handled by register u = g*2^Q + c of thread tau, as pass input / output
-    __device__ static constexpr int in_index(int tau, int u)
-    {
-        const int g = u >> Q, c = u & ((1 << Q) - 1);
-        const int m = tau + g * TPT;
-        return ((m >> JB) << (L - S0)) | (c << JB) | (m & ((1 << JB) - 1));
-    }
-    __device__ static constexpr int out_index(int tau, int u)
-    {
-        const int g = u >> Q, c = u & ((1 << Q) - 1);
-        return (bitrev(c, Q) << (L - Q)) | (tau + g * TPT);
-    }
-};
+using PassGeom = WgGeom<L, RL, P>;
 
 template <typename T, int L, int RL, int P>
 __device__ __forceinline__ void persist_load_tw(cpx<T> *twr, const int tau, const cpx<T> *__restrict__ tw)

@@ -28,6 +28,9 @@ struct NoInv {};
 // Default for every IO policy of a stand-alone transform: plain table indexing, threads of a transform contiguous.
 struct PlainTw {
     static constexpr bool kSlotMinor = false;
+    static constexpr bool kPairXcd = false;
+    static constexpr bool kSplitLds = false;
+    static constexpr int kMinWaves = 1;  // __launch_bounds__ second argument (waves per SIMD the kernel must fit)
     __device__ __forceinline__ TwPlain tw_map(size_t) const { return {}; }
 };
 
@@ -262,62 +265,101 @@ struct IrfftIO : PlainTw {
 
 enum : int { EPI_STORE = 0, EPI_RFFT = 1 };
 
-// One register pass (compile-time pass number P) of the workgroup kernel.
-template <typename T, int L, int RL, int BLOCK, int EPI, int P, class IO>
-__device__ __forceinline__ void wg_pass(cpx<T> *v, cpx<T> *buf, const IO &io, const cpx<T> *__restrict__ tw,
-                                        const size_t xf, const bool active, const int tau)
+// ---- LDS exchange layouts --------------------------------------------------------------------------------------
+// Plain (threads of a transform contiguous in the wave): each transform slot owns lds_elems(n) padded elements.
+// Slot-minor (lanes run over XPB adjacent transforms first; 8-byte exchange elements -- c32 values, or the real /
+// imaginary halves of c64 values moved in two rounds): the slots are INTERLEAVED at a two-element grain and two
+// index bits are XOR-swizzled,
+//     cell(idx, slot) = (idx >> 2) * 4*XPB  +  ((idx1 ^ idx3) * 2*XPB)  +  slot * 2  +  (idx0 ^ idx2),
+// so that every DS access shape of the kernel is conflict-free at XPB = 8: a ds_write_b64 lane group (16 lanes =
+// 2 consecutive threads x 8 slots) covers 16 consecutive cells; a ds_read_b64 lane group (32 lanes = 4 threads x
+// 8 slots) covers the 32 cells of one 256-byte row, whether the four threads differ in index bits (0,1) (gather of
+// the middle pass) or in bits (2,3) (gather of the last pass).  No padding: XPB * n * 8 bytes exactly.
+template <int XPB>
+__host__ __device__ constexpr int lds_cell_sm(int idx, int slot)
 {
+    return ((idx >> 2) * (4 * XPB)) + ((((idx >> 1) ^ (idx >> 3)) & 1) * (2 * XPB)) + slot * 2 + ((idx ^ (idx >> 2)) & 1);
+}
+
+// Bytes of LDS per workgroup.  SPLIT: the exchange moves real and imaginary parts in two rounds through a buffer
+// of scalars (half the footprint: what lets c64 tiles of 8 columns fit twice per CU).
+template <typename T, bool SPLIT, bool SLOT_MINOR, int XPB>
+__host__ __device__ constexpr size_t lds_wg_bytes(int n)
+{
+    const size_t elem = SPLIT ? sizeof(T) : sizeof(cpx<T>);
+    return SLOT_MINOR ? (size_t)XPB * n * elem : (size_t)XPB * lds_elems(n) * elem;
+}
+
+// Pass geometry: thread tau of a transform holds R = 2^RL registers u = g*2^Q + c.
+template <int L, int RL, int P>
+struct WgGeom {
+    static constexpr int N = 1 << L;
+    static constexpr int R = 1 << RL;
+    static constexpr int TPT = N / R;
+    static constexpr int NP = (L + RL - 1) / RL;
+    static constexpr int S0 = P * RL;
+    static constexpr int Q = (P == NP - 1) ? (L - RL * (NP - 1)) : RL;
+    static constexpr int G = R >> Q;       // independent (k, j) groups held by a thread
+    static constexpr int JB = L - S0 - Q;  // bits of j
+    __host__ __device__ static constexpr int in_index(int tau, int u)
+    {
+        const int g = u >> Q, c = u & ((1 << Q) - 1);
+        const int m = tau + g * TPT;
+        return ((m >> JB) << (L - S0)) | (c << JB) | (m & ((1 << JB) - 1));
+    }
+    __host__ __device__ static constexpr int out_index(int tau, int u)
+    {
+        const int g = u >> Q, c = u & ((1 << Q) - 1);
+        return (bitrev(c, Q) << (L - Q)) | (tau + g * TPT);
+    }
+};
+
+// LDS exchange between pass P and pass P+1: scatter pass P's outputs, gather pass P+1's inputs.
+// `base` is the workgroup's exchange region; SM selects the slot-minor interleaved layout.
+template <typename T, int L, int RL, int P, bool SPLIT, bool SM, int XPB>
+__device__ __forceinline__ void wg_exchange(cpx<T> *v, char *base, const int tau, const int slot)
+{
+    using Gs = WgGeom<L, RL, P>;
+    using Gg = WgGeom<L, RL, P + 1>;
     constexpr int N = 1 << L;
     constexpr int R = 1 << RL;
-    constexpr int TPT = N / R;
-    constexpr int NP = (L + RL - 1) / RL;
-    constexpr int S0 = P * RL;
-    constexpr int Q = (P == NP - 1) ? (L - RL * (NP - 1)) : RL;
-    constexpr int G = R >> Q;       // independent (k, j) groups held by this thread
-    constexpr int JB = L - S0 - Q;  // bits of j
-
-    // ---- gather the pass inputs
-    if (P > 0) __syncthreads();  // the exchange written by pass P-1 is complete
+    auto cell = [&](int idx) -> int { return SM ? lds_cell_sm<XPB>(idx, slot) : slot * lds_elems(N) + lds_pad(idx); };
+    if (P > 0) __syncthreads();  // every gather of the previous exchange is done
+    if constexpr (!SPLIT) {
+        cpx<T> *buf = reinterpret_cast<cpx<T> *>(base);
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const int m = tau + g * TPT;
-        const int k = m >> JB;
-        const int j = m & ((1 << JB) - 1);
+        for (int u = 0; u < R; ++u) buf[cell(Gs::out_index(tau, u))] = v[u];
+        __syncthreads();
 #pragma unroll
-        for (int c = 0; c < (1 << Q); ++c) {
-            const int i = (k << (L - S0)) | (c << JB) | j;
-            if (P == 0)
-                v[g * (1 << Q) + c] = active ? io.load(xf, i) : mk<T>(T(0), T(0));
-            else
-                v[g * (1 << Q) + c] = buf[lds_pad(i)];
-        }
-    }
-    // ---- Q stages in registers
+        for (int u = 0; u < R; ++u) v[u] = buf[cell(Gg::in_index(tau, u))];
+    } else {
+        T *buf = reinterpret_cast<T *>(base);
+        T re[R];
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const int m = tau + g * TPT;
-        reg_pass<T, L, S0, Q, false>(&v[g * (1 << Q)], m >> JB, tw, io.tw_map(xf));
-    }
-    // ---- scatter the pass outputs
-    constexpr bool to_lds = (P < NP - 1) || (EPI == EPI_RFFT);
-    if (P > 0 && to_lds) __syncthreads();  // every gather of this pass is done
+        for (int u = 0; u < R; ++u) buf[cell(Gs::out_index(tau, u))] = v[u].re;
+        __syncthreads();
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const int m = tau + g * TPT;
+        for (int u = 0; u < R; ++u) re[u] = buf[cell(Gg::in_index(tau, u))];
+        __syncthreads();
 #pragma unroll
-        for (int c = 0; c < (1 << Q); ++c) {
-            const int o = (bitrev(c, Q) << (L - Q)) | m;
-            if constexpr (to_lds) {
-                buf[lds_pad(o)] = v[g * (1 << Q) + c];
-            } else {
-                if (active) io.store(xf, o, v[g * (1 << Q) + c]);
-            }
-        }
+        for (int u = 0; u < R; ++u) buf[cell(Gs::out_index(tau, u))] = v[u].im;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < R; ++u) v[u] = mk<T>(re[u], buf[cell(Gg::in_index(tau, u))]);
     }
 }
 
+template <typename T, int L, int RL, int P, class IO>
+__device__ __forceinline__ void wg_compute(cpx<T> *v, const IO &io, const cpx<T> *__restrict__ tw, const size_t xf, const int tau)
+{
+    using Gm = WgGeom<L, RL, P>;
+#pragma unroll
+    for (int g = 0; g < Gm::G; ++g)
+        reg_pass<T, L, Gm::S0, Gm::Q, false>(&v[g * (1 << Gm::Q)], (tau + g * Gm::TPT) >> Gm::JB, tw, io.tw_map(xf));
+}
+
 template <typename T, int L, int RL, int BLOCK, int EPI, class IO>
-__global__ __launch_bounds__(BLOCK) void fft_wg_kernel(const IO io, const cpx<T> *__restrict__ tw, const size_t batch)
+__global__ __launch_bounds__(BLOCK, (IO::kMinWaves > 1 && BLOCK == 512 && L >= 9 && L <= 11) ? IO::kMinWaves : 1) void fft_wg_kernel(const IO io, const cpx<T> *__restrict__ tw, const size_t batch)
 {
     constexpr int N = 1 << L;
     constexpr int R = 1 << RL;
@@ -326,28 +368,45 @@ __global__ __launch_bounds__(BLOCK) void fft_wg_kernel(const IO io, const cpx<T>
     constexpr int XPB = BLOCK / TPT;
     constexpr int NP = (L + RL - 1) / RL;
     static_assert(NP >= 1 && NP <= 5, "pass count");
+    constexpr bool SPLIT = IO::kSplitLds;
+    constexpr bool SM = IO::kSlotMinor;
+    static_assert(!((SPLIT || SM) && EPI == EPI_RFFT), "the rfft epilogue reads whole complex values from a plain slot");
+    static_assert(!SM || (SPLIT ? sizeof(T) : sizeof(cpx<T>)) == 8, "slot-minor layout is built for 8-byte exchange elements");
 
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    cpx<T> *lds = reinterpret_cast<cpx<T> *>(smem_raw);
 
     const int tid = threadIdx.x;
     // kSlotMinor: consecutive lanes belong to consecutive transforms (used when adjacent transforms are adjacent
     // in memory, e.g. the columns of fft_big's first factor), otherwise to consecutive threads of one transform.
     const int tau = IO::kSlotMinor ? tid / XPB : tid % TPT;
     const int slot = IO::kSlotMinor ? tid % XPB : tid / TPT;
-    const size_t xf = (size_t)blockIdx.x * XPB + slot;
+    // kPairXcd: workgroups b and b+8 land on the same XCD at about the same time (round-robin dispatch; a speed
+    // heuristic only, results never depend on it).  Handing them ADJACENT tiles lets the two halves of each
+    // 128-byte line meet in that XCD's L2 instead of being fetched twice (measured on the column-tile copy: 3.1 -> 4.2 TB/s).
+    size_t blk = blockIdx.x;
+    if (IO::kPairXcd && blk < (gridDim.x & ~15u)) blk = 16 * (blk / 16) + 2 * (blk % 8) + ((blk / 8) % 2);
+    const size_t xf = blk * XPB + slot;
     const bool active = xf < batch;
-    cpx<T> *buf = lds + slot * lds_elems(N);
 
     cpx<T> v[R];
-    wg_pass<T, L, RL, BLOCK, EPI, 0>(v, buf, io, tw, xf, active, tau);
-    if constexpr (NP > 1) wg_pass<T, L, RL, BLOCK, EPI, 1>(v, buf, io, tw, xf, active, tau);
-    if constexpr (NP > 2) wg_pass<T, L, RL, BLOCK, EPI, 2>(v, buf, io, tw, xf, active, tau);
-    if constexpr (NP > 3) wg_pass<T, L, RL, BLOCK, EPI, 3>(v, buf, io, tw, xf, active, tau);
-    if constexpr (NP > 4) wg_pass<T, L, RL, BLOCK, EPI, 4>(v, buf, io, tw, xf, active, tau);
+    {   // pass 0 inputs through the IO policy
+        using G0 = WgGeom<L, RL, 0>;
+#pragma unroll
+        for (int u = 0; u < R; ++u) v[u] = active ? io.load(xf, G0::in_index(tau, u)) : mk<T>(T(0), T(0));
+    }
+    wg_compute<T, L, RL, 0>(v, io, tw, xf, tau);
+    if constexpr (NP > 1) { wg_exchange<T, L, RL, 0, SPLIT, SM, XPB>(v, smem_raw, tau, slot); wg_compute<T, L, RL, 1>(v, io, tw, xf, tau); }
+    if constexpr (NP > 2) { wg_exchange<T, L, RL, 1, SPLIT, SM, XPB>(v, smem_raw, tau, slot); wg_compute<T, L, RL, 2>(v, io, tw, xf, tau); }
+    if constexpr (NP > 3) { wg_exchange<T, L, RL, 2, SPLIT, SM, XPB>(v, smem_raw, tau, slot); wg_compute<T, L, RL, 3>(v, io, tw, xf, tau); }
+    if constexpr (NP > 4) { wg_exchange<T, L, RL, 3, SPLIT, SM, XPB>(v, smem_raw, tau, slot); wg_compute<T, L, RL, 4>(v, io, tw, xf, tau); }
 
+    using GL = WgGeom<L, RL, NP - 1>;
     if constexpr (EPI == EPI_RFFT) {
-        // rfft.rs:450-463 on Y = buf (natural order), m = N.
+        // rfft.rs:450-463: Y in natural order through LDS, then X[k] from Y[k], Y[m-k] (m = N)
+        cpx<T> *buf = reinterpret_cast<cpx<T> *>(smem_raw) + (size_t)slot * lds_elems(N);
+        if (NP > 1) __syncthreads();
+#pragma unroll
+        for (int u = 0; u < R; ++u) buf[lds_pad(GL::out_index(tau, u))] = v[u];
         __syncthreads();
         if (active) {
             cpx<T> *orow = io.out + xf * (size_t)(N + 1);
@@ -362,6 +421,11 @@ __global__ __launch_bounds__(BLOCK) void fft_wg_kernel(const IO io, const cpx<T>
                     orow[k] = io.post(k, buf[lds_pad(k)], buf[lds_pad(N - k)]);
                 }
             }
+        }
+    } else {
+        if (active) {
+#pragma unroll
+            for (int u = 0; u < R; ++u) io.store(xf, GL::out_index(tau, u), v[u]);
         }
     }
 }

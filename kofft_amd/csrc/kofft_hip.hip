@@ -122,14 +122,14 @@ template <typename T> constexpr int max_log2();
 template <> constexpr int max_log2<float>() { return 14; }
 template <> constexpr int max_log2<double>() { return 13; }
 
-template <typename T, int L, int EPI, class IO>
+template <typename T, int L, int EPI, class IO, int BLOCK_OVERRIDE = 0>
 int launch_wg(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t batch)
 {
     constexpr int RL = rl_for(L);
-    constexpr int BLOCK = block_for(L);
+    constexpr int BLOCK = BLOCK_OVERRIDE ? BLOCK_OVERRIDE : block_for(L);
     constexpr int TPT = (1 << L) >> RL;
     constexpr int XPB = BLOCK / TPT;
-    constexpr size_t lds = (size_t)XPB * lds_elems(1 << L) * sizeof(cpx<T>);
+    constexpr size_t lds = lds_wg_bytes<T, IO::kSplitLds, IO::kSlotMinor, XPB>(1 << L);
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = fft_wg_kernel<T, L, RL, BLOCK, EPI, IO>;
     if (lds > 64 * 1024) {
@@ -238,13 +238,26 @@ int dispatch(kofft_hip_ctx *ctx, const IO &io, size_t n, size_t batch)
 // ---------------------------------------------------------------------------------
 template <typename T> constexpr int max_log2_big() { return 26; }
 
+template <typename T, class IO, int LS>
+constexpr int big_block()
+{
+    const int tpt = (1 << LS) >> rl_for(LS);
+    int xpb = 8;
+    while (xpb > 1 && (xpb * tpt > 1024 || (size_t)xpb * (1 << LS) * 8 > 80 * 1024)) xpb /= 2;
+    int block = xpb * tpt;
+    if (block < 64) block = 64;
+    return block;
+}
+
 // Launch the generic kernel for a sub-transform of log2 size LS with an arbitrary IO policy.
 template <typename T, class IO>
 int launch_sub(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, int LS, size_t units)
 {
     switch (LS) {
+    // Eight adjacent columns/rows per workgroup (128-byte segments for c64, 64-byte for c32 -- paired across an XCD)
+    // while two workgroups still fit in a CU's LDS; larger sub-transforms fall back to fewer.
 #define KOFFT_CASE(LL) \
-    case LL: return launch_wg<T, LL, EPI_STORE>(ctx, io, tw, units);
+    case LL: return launch_wg<T, LL, EPI_STORE, IO, big_block<T, IO, LL>()>(ctx, io, tw, units);
         KOFFT_CASE(7)
         KOFFT_CASE(8)
         KOFFT_CASE(9)
