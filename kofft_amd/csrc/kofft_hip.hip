@@ -39,7 +39,7 @@ struct kofft_hip_ctx {
     // intermediate of the two-factor large-n path (fft_big.hip.h): `big_chunk` transforms at a time
     void *big_tmp = nullptr;
     size_t big_tmp_bytes = 0;
-    size_t big_chunk_bytes = 128u << 20;  // KOFFT_HIP_BIG_CHUNK_MB: keep the intermediate inside the 256 MiB Infinity Cache
+    size_t big_chunk_bytes = size_t(2048) << 20;  // KOFFT_HIP_BIG_CHUNK_MB; measured: small chunks do not profit from the Infinity Cache, larger launches overlap better
 };
 
 namespace {
