@@ -182,6 +182,18 @@ int kofft_hip_stft_magnitudes_f32_dev(kofft_hip_ctx *ctx, const float *d_samples
                                       size_t win_len, size_t hop, float *d_mags, size_t frames,
                                       float *d_max);
 
+/* ---- 2-D / 3-D FFT (SURVEY 8f "next" row 3) ----------------------------------------
+ * ndfft::fft2d_inplace (ndfft.rs:74-101) with depth == 1: FftImpl::fft on every row (length cols), then
+ * FftImpl::fft_strided down every column (length rows, stride cols).  ndfft::fft3d_inplace
+ * (ndfft.rs:114-155) with depth > 1: z axis (stride rows*cols), y axis (stride cols), x axis (rows).
+ * data: depth*rows*cols complex, row-major, in place.  Any zero dimension -> KOFFT_OK (nothing to do).
+ * The reference's scratch-length checks belong to the host mirrors (they take the scratch slices).
+ * inverse != 0 applies ifft / ifft_strided along the same axes in the same order. */
+int kofft_hip_fftnd_c32(kofft_hip_ctx *ctx, float *data, size_t depth, size_t rows, size_t cols, int inverse);
+int kofft_hip_fftnd_c64(kofft_hip_ctx *ctx, double *data, size_t depth, size_t rows, size_t cols, int inverse);
+int kofft_hip_fftnd_c32_dev(kofft_hip_ctx *ctx, float *d_data, size_t depth, size_t rows, size_t cols, int inverse);
+int kofft_hip_fftnd_c64_dev(kofft_hip_ctx *ctx, double *d_data, size_t depth, size_t rows, size_t cols, int inverse);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,6 +64,10 @@ SIGNATURES = {
     "kofft_hip_istft_f32_dev": (C.c_int, [_ctx, C.c_void_p, _sz, C.c_void_p, _sz, _sz, C.c_void_p, _sz, C.c_void_p, _sz]),
     "kofft_hip_stft_magnitudes_f32": (C.c_int, [_ctx, C.c_void_p, _sz, _sz, _sz, C.c_void_p, _sz, C.c_void_p]),
     "kofft_hip_stft_magnitudes_f32_dev": (C.c_int, [_ctx, C.c_void_p, _sz, _sz, _sz, C.c_void_p, _sz, C.c_void_p]),
+    "kofft_hip_fftnd_c32": (C.c_int, [_ctx, C.c_void_p, _sz, _sz, _sz, C.c_int]),
+    "kofft_hip_fftnd_c64": (C.c_int, [_ctx, C.c_void_p, _sz, _sz, _sz, C.c_int]),
+    "kofft_hip_fftnd_c32_dev": (C.c_int, [_ctx, C.c_void_p, _sz, _sz, _sz, C.c_int]),
+    "kofft_hip_fftnd_c64_dev": (C.c_int, [_ctx, C.c_void_p, _sz, _sz, _sz, C.c_int]),
     "kofft_hip_stft_f32_dev": (C.c_int, [_ctx, C.c_void_p, _sz, C.c_void_p, _sz, _sz, C.c_void_p, _sz, _sz]),
 }
 

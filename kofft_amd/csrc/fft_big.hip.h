@@ -88,4 +88,36 @@ struct BigRowsIO {
     }
 };
 
+// ndfft (ndfft.rs:74-155): FftImpl::fft_strided over every line of one axis.  Unit xf is one line:
+// element i lives at  (xf / inner) * outer_stride + (xf % inner) + i * stride.  Adjacent lines are adjacent in memory,
+// so lanes run over lines first (kSlotMinor), as for the column factor above.  Each line is a stand-alone transform
+// with its own table T_len (TwPlain), exactly what fft_strided's gather / fft / scatter computes.
+template <typename T, bool INVERSE>
+struct StridedIO {
+    static constexpr bool kStreams = false;
+    static constexpr bool kSlotMinor = true;
+    static constexpr bool kPairXcd = false;
+    static constexpr bool kSplitLds = sizeof(T) == 8;
+    static constexpr int kMinWaves = 1;
+    cpx<T> *__restrict__ data;  // in place
+    size_t inner, outer_stride, stride;
+    T scale;  // 1 / (len as f32 as T)
+    __device__ __forceinline__ TwPlain tw_map(size_t) const { return {}; }
+    __device__ __forceinline__ size_t base(size_t xf) const { return (xf / inner) * outer_stride + (xf % inner); }
+    __device__ __forceinline__ cpx<T> load(size_t xf, int i) const
+    {
+        cpx<T> v = data[base(xf) + (size_t)i * stride];
+        if (INVERSE) v.im = -v.im;
+        return v;
+    }
+    __device__ __forceinline__ void store(size_t xf, int o, cpx<T> v) const
+    {
+        if (INVERSE) {
+            const T im = -v.im;
+            v = mk<T>(v.re * scale, im * scale);
+        }
+        data[base(xf) + (size_t)o * stride] = v;
+    }
+};
+
 }  // namespace kofft

@@ -581,6 +581,65 @@ int stft_mag_dev(kofft_hip_ctx *ctx, const float *d_samples, size_t len, size_t 
     return KOFFT_OK;
 }
 
+// ndfft::fft2d_inplace / fft3d_inplace (ndfft.rs:74-155): one axis at a time, every line of the axis in one launch.
+template <typename T>
+int fft_axis_dev(kofft_hip_ctx *ctx, T *d_data, size_t len, size_t lines, size_t inner, size_t outer_stride, size_t stride,
+                 int inverse)
+{
+    if (len <= 1 || lines == 0) return KOFFT_OK;  // fft of one element: nothing to do (fft.rs:1059)
+    const T scale = (T)1 / (T)(float)len;
+    if (inverse) {
+        StridedIO<T, true> io{reinterpret_cast<cpx<T> *>(d_data), inner, outer_stride, stride, scale};
+        return dispatch<T, EPI_STORE>(ctx, io, len, lines);
+    }
+    StridedIO<T, false> io{reinterpret_cast<cpx<T> *>(d_data), inner, outer_stride, stride, scale};
+    return dispatch<T, EPI_STORE>(ctx, io, len, lines);
+}
+
+template <typename T>
+int fft_nd_dev(kofft_hip_ctx *ctx, T *d_data, size_t depth, size_t rows, size_t cols, int inverse)
+{
+    if (depth == 0 || rows == 0 || cols == 0) return KOFFT_OK;  // ndfft.rs:84-86, 124-126
+    for (size_t n : {depth, rows, cols})
+        if (!is_pow2(n) || n > (size_t(1) << max_log2<T>())) return KOFFT_ERR_UNSUPPORTED;
+    if (!ctx || !d_data) return KOFFT_ERR_NULL;
+    KOFFT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if (depth > 1) {  // z axis first (ndfft.rs:131-137): lines (r, c), stride rows*cols
+        rc = fft_axis_dev<T>(ctx, d_data, depth, rows * cols, rows * cols, 0, rows * cols, inverse);
+        if (rc) return rc;
+        // y axis (ndfft.rs:138-144): lines (d, c), stride cols
+        rc = fft_axis_dev<T>(ctx, d_data, rows, depth * cols, cols, rows * cols, cols, inverse);
+        if (rc) return rc;
+        // x axis (ndfft.rs:145-151): contiguous rows
+        return fft_dev<T>(ctx, d_data, d_data, cols, depth * rows, inverse);
+    }
+    // 2-D (ndfft.rs:89-98): rows first, then columns
+    rc = fft_dev<T>(ctx, d_data, d_data, cols, rows, inverse);
+    if (rc) return rc;
+    return fft_axis_dev<T>(ctx, d_data, rows, cols, cols, 0, cols, inverse);
+}
+
+template <typename T>
+int fft_nd_host(kofft_hip_ctx *ctx, T *data, size_t depth, size_t rows, size_t cols, int inverse)
+{
+    if (depth == 0 || rows == 0 || cols == 0) return KOFFT_OK;
+    for (size_t n : {depth, rows, cols})
+        if (!is_pow2(n) || n > (size_t(1) << max_log2<T>())) return KOFFT_ERR_UNSUPPORTED;
+    if (!ctx || !data) return KOFFT_ERR_NULL;
+    KOFFT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = depth * rows * cols * 2 * sizeof(T);
+    int rc = ensure_stage(ctx, 0, bytes);
+    if (rc) return rc;
+    T *d = static_cast<T *>(ctx->stage[0]);
+    KOFFT_HIP_TRY(ctx, hipMemcpyAsync(d, data, bytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = fft_nd_dev<T>(ctx, d, depth, rows, cols, inverse);
+    if (rc) return rc;
+    KOFFT_HIP_TRY(ctx, hipMemcpyAsync(data, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    KOFFT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return KOFFT_OK;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------
@@ -876,6 +935,23 @@ int kofft_hip_stft_magnitudes_f32(kofft_hip_ctx *ctx, const float *samples, size
     KOFFT_HIP_TRY(ctx, hipMemcpyAsync(max_mag, ctx->stage[2], sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     KOFFT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return KOFFT_OK;
+}
+
+int kofft_hip_fftnd_c32(kofft_hip_ctx *ctx, float *data, size_t depth, size_t rows, size_t cols, int inverse)
+{
+    return fft_nd_host<float>(ctx, data, depth, rows, cols, inverse);
+}
+int kofft_hip_fftnd_c64(kofft_hip_ctx *ctx, double *data, size_t depth, size_t rows, size_t cols, int inverse)
+{
+    return fft_nd_host<double>(ctx, data, depth, rows, cols, inverse);
+}
+int kofft_hip_fftnd_c32_dev(kofft_hip_ctx *ctx, float *d_data, size_t depth, size_t rows, size_t cols, int inverse)
+{
+    return fft_nd_dev<float>(ctx, d_data, depth, rows, cols, inverse);
+}
+int kofft_hip_fftnd_c64_dev(kofft_hip_ctx *ctx, double *d_data, size_t depth, size_t rows, size_t cols, int inverse)
+{
+    return fft_nd_dev<double>(ctx, d_data, depth, rows, cols, inverse);
 }
 
 }  // extern "C"

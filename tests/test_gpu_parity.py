@@ -472,3 +472,55 @@ def test_stft_magnitudes_match_oracle(fft32, oracle, win_len, hop, length):
     mags, mx = fft32.stft_magnitudes(samples, win_len, hop)
     assert_parity(mags, want, f"stft_magnitudes win={win_len}", REL_TOL_F32)
     assert mx == float(want.max())
+
+
+# ---- 2-D / 3-D FFT ---------------------------------------------------------------------------------------
+def _oracle_axis(oracle, x, axis, inverse=False):
+    moved = np.ascontiguousarray(np.moveaxis(x, axis, -1))
+    return np.ascontiguousarray(np.moveaxis(oracle.fft(moved, inverse=inverse), -1, axis))
+
+
+@pytest.mark.parametrize("rows,cols", [(4, 4), (8, 32), (64, 16), (256, 128), (1024, 64), (32, 4096), (2, 1), (1, 8)])
+def test_fft2d_matches_oracle(fft32, oracle, rows, cols):
+    """ndfft::fft2d_inplace (ndfft.rs:74-101): rows, then strided columns -- every line an independent reference FFT."""
+    import kofft_amd as K
+
+    rng = seeded(1500 + rows + cols)
+    x = rand_c(rng, (rows, cols))
+    want = _oracle_axis(oracle, _oracle_axis(oracle, x, 1), 0)
+    data = x.reshape(-1).copy()
+    K.fft2d_inplace(data, rows, cols, fft32, np.zeros(rows, np.complex64))
+    assert_parity(data.reshape(rows, cols), want, f"fft2d {rows}x{cols}", REL_TOL_F32)
+    fft32.fftnd(data, 1, rows, cols, inverse=True)  # round trip along the same axes (ndfft.rs tests, 165-176)
+    back = _oracle_axis(oracle, _oracle_axis(oracle, want, 1, True), 0, True)
+    assert_parity(data.reshape(rows, cols), back, f"ifft2d {rows}x{cols}", REL_TOL_F32)
+
+
+@pytest.mark.parametrize("depth,rows,cols", [(2, 2, 2), (4, 8, 16), (16, 32, 64), (64, 4, 256)])
+def test_fft3d_matches_oracle(fft32, fft64, oracle, depth, rows, cols):
+    """ndfft::fft3d_inplace (ndfft.rs:114-155): z, then y, then x."""
+    import kofft_amd as K
+
+    rng = seeded(1600 + depth)
+    for impl, dt in ((fft32, np.complex64), (fft64, np.complex128)):
+        x = rand_c(rng, (depth, rows, cols), dt)
+        want = _oracle_axis(oracle, _oracle_axis(oracle, _oracle_axis(oracle, x, 0), 1), 2)
+        data = x.reshape(-1).copy()
+        scratch = (np.zeros(depth, dt), np.zeros(rows, dt), np.zeros(cols, dt))
+        K.fft3d_inplace(data, depth, rows, cols, impl, scratch)
+        assert_parity(data.reshape(depth, rows, cols), want, f"fft3d {depth}x{rows}x{cols} {np.dtype(dt).name}", REL_TOL_F32)
+
+
+def test_ndfft_error_variants(fft32):
+    import kofft_amd as K
+    from kofft_amd import FftError
+
+    with pytest.raises(FftError) as e:
+        K.fft2d_inplace(np.zeros(7, np.complex64), 2, 4, fft32, np.zeros(2, np.complex64))
+    assert e.value.code == FftError.MismatchedLengths
+    with pytest.raises(FftError) as e:
+        K.fft2d_inplace(np.zeros(8, np.complex64), 2, 4, fft32, np.zeros(3, np.complex64))
+    assert e.value.code == FftError.MismatchedLengths
+    K.fft2d_inplace(np.zeros(0, np.complex64), 0, 4, fft32, np.zeros(0, np.complex64))  # Ok: nothing to do
+    with pytest.raises(FftError):
+        K.flatten_2d([[1, 2], [3]])
