@@ -25,8 +25,10 @@
  *   - Arithmetic: every butterfly performs the reference's un-fused operations with
  *     the reference's recurrence-generated twiddle tables (generated on the host with
  *     the reference's recipe and uploaded; no device-side trigonometry).
- *   - Lengths: n = 1 and every power of two.  Non-power-of-two lengths (the
- *     reference's Bluestein arm, fft.rs:1088-1132) return KOFFT_ERR_UNSUPPORTED.
+ *   - Lengths: complex transforms take any n up to 2^26 (powers of two) / 2^25 (others:
+ *     the reference's Bluestein arm, fft.rs:1088-1132, built from the same kernels).
+ *     rfft / irfft / stft need a power-of-two inner transform; anything else returns
+ *     KOFFT_ERR_UNSUPPORTED (never a wrong answer).
  */
 #ifndef KOFFT_HIP_H
 #define KOFFT_HIP_H

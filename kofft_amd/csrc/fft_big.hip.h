@@ -120,4 +120,55 @@ struct StridedIO {
     }
 };
 
+// ---- Bluestein arm for non-power-of-two lengths (fft.rs:1088-1132) --------------------------------
+// a = x * chirp (zero-padded to m = next_pow2(2n-1)); fft_m; a *= fft(b); conj; fft_m; conj; * 1/m; out = a * chirp.
+// The three pointwise steps below use Complex::mul's un-fused form; the two m-point transforms are the ordinary
+// power-of-two kernels.  INVERSE folds ifft's conj-in / conj-scale-out (fft.rs:1163-1172) around the same steps.
+template <typename T, bool INVERSE>
+__global__ __launch_bounds__(256) void bluestein_pre_kernel(const cpx<T> *__restrict__ in, cpx<T> *__restrict__ a,
+                                                            const cpx<T> *__restrict__ chirp, const size_t n, const size_t m,
+                                                            const size_t total /* batch * m */)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const size_t b = idx / m, i = idx % m;
+    cpx<T> v = mk<T>(T(0), T(0));
+    if (i < n) {
+        cpx<T> x = in[b * n + i];
+        if (INVERSE) x.im = -x.im;
+        v = cmul(x, chirp[i]);
+    }
+    a[idx] = v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bluestein_mid_kernel(cpx<T> *__restrict__ a, const cpx<T> *__restrict__ bfft, const size_t m,
+                                                            const size_t total)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    cpx<T> v = cmul(a[idx], bfft[idx % m]);
+    v.im = -v.im;
+    a[idx] = v;
+}
+
+template <typename T, bool INVERSE>
+__global__ __launch_bounds__(256) void bluestein_post_kernel(const cpx<T> *__restrict__ a, cpx<T> *__restrict__ out,
+                                                             const cpx<T> *__restrict__ chirp, const size_t n, const size_t m,
+                                                             const size_t total /* batch * n */, const T scale_m, const T scale_n)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const size_t b = idx / n, i = idx % n;
+    cpx<T> v = a[b * m + i];
+    v.im = -v.im;
+    v = mk<T>(v.re * scale_m, v.im * scale_m);
+    cpx<T> o = cmul(v, chirp[i]);
+    if (INVERSE) {
+        const T im = -o.im;
+        o = mk<T>(o.re * scale_n, im * scale_n);
+    }
+    out[idx] = o;
+}
+
 }  // namespace kofft

@@ -39,6 +39,8 @@ struct kofft_hip_ctx {
     // intermediate of the two-factor large-n path (fft_big.hip.h): `big_chunk` transforms at a time
     void *big_tmp = nullptr;
     size_t big_tmp_bytes = 0;
+    void *blue_tmp = nullptr;  // zero-padded work buffer of the Bluestein arm
+    size_t blue_tmp_bytes = 0;
     size_t big_chunk_bytes = size_t(2048) << 20;  // KOFFT_HIP_BIG_CHUNK_MB; measured: small chunks do not profit from the Infinity Cache, larger launches overlap better
 };
 
@@ -306,6 +308,83 @@ int fft_big_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t ba
 }
 
 // ---------------------------------------------------------------------------------
+// non-power-of-two lengths: Bluestein (fft.rs:1088-1132)
+// ---------------------------------------------------------------------------------
+template <typename T>
+int fft_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t batch, int inverse);
+
+template <typename T>
+int get_bluestein(kofft_hip_ctx *ctx, size_t n, size_t m, const cpx<T> **chirp, const cpx<T> **bfft)
+{
+    const int kc = sizeof(T) == 4 ? 5 : 6, kb = sizeof(T) == 4 ? 7 : 8;
+    auto ic = ctx->tables.find(std::make_pair(kc, n));
+    auto ib = ctx->tables.find(std::make_pair(kb, n));
+    if (ic != ctx->tables.end() && ib != ctx->tables.end()) {
+        *chirp = static_cast<const cpx<T> *>(ic->second);
+        *bfft = static_cast<const cpx<T> *>(ib->second);
+        return KOFFT_OK;
+    }
+    std::vector<T> hc(2 * n), hb(2 * m);
+    if constexpr (sizeof(T) == 4) kofft_tables::bluestein_f32(n, m, (float *)hc.data(), (float *)hb.data());
+    else kofft_tables::bluestein_f64(n, m, (double *)hc.data(), (double *)hb.data());
+    void *dc = nullptr, *db = nullptr;
+    KOFFT_HIP_TRY(ctx, hipMalloc(&dc, hc.size() * sizeof(T)));
+    KOFFT_HIP_TRY(ctx, hipMalloc(&db, hb.size() * sizeof(T)));
+    KOFFT_HIP_TRY(ctx, hipMemcpy(dc, hc.data(), hc.size() * sizeof(T), hipMemcpyHostToDevice));
+    KOFFT_HIP_TRY(ctx, hipMemcpy(db, hb.data(), hb.size() * sizeof(T), hipMemcpyHostToDevice));
+    // b_fft = fft(b) with the ordinary power-of-two path (fft.rs:425-427)
+    int rc = fft_dev<T>(ctx, static_cast<T *>(db), static_cast<T *>(db), m, 1, 0);
+    if (rc) return rc;
+    ctx->tables[std::make_pair(kc, n)] = dc;
+    ctx->tables[std::make_pair(kb, n)] = db;
+    *chirp = static_cast<const cpx<T> *>(dc);
+    *bfft = static_cast<const cpx<T> *>(db);
+    return KOFFT_OK;
+}
+
+template <typename T, bool INVERSE>
+int fft_bluestein_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t batch)
+{
+    size_t m = 1;
+    while (m < 2 * n - 1) m <<= 1;  // (2n-1).next_power_of_two()
+    const cpx<T> *chirp = nullptr, *bfft = nullptr;
+    int rc = get_bluestein<T>(ctx, n, m, &chirp, &bfft);
+    if (rc) return rc;
+    const size_t xf_bytes = m * sizeof(cpx<T>);
+    size_t chunk = (size_t(512) << 20) / xf_bytes;
+    if (chunk < 1) chunk = 1;
+    if (chunk > batch) chunk = batch;
+    if (ctx->blue_tmp_bytes < chunk * xf_bytes) {
+        if (ctx->blue_tmp) KOFFT_HIP_TRY(ctx, hipFree(ctx->blue_tmp));
+        ctx->blue_tmp = nullptr;
+        ctx->blue_tmp_bytes = 0;
+        KOFFT_HIP_TRY(ctx, hipMalloc(&ctx->blue_tmp, chunk * xf_bytes));
+        ctx->blue_tmp_bytes = chunk * xf_bytes;
+    }
+    cpx<T> *a = static_cast<cpx<T> *>(ctx->blue_tmp);
+    const T scale_m = (T)1 / (T)(float)m, scale_n = (T)1 / (T)(float)n;
+    for (size_t b0 = 0; b0 < batch; b0 += chunk) {
+        const size_t nb = (batch - b0 < chunk) ? batch - b0 : chunk;
+        const cpx<T> *src = reinterpret_cast<const cpx<T> *>(d_in) + b0 * n;
+        cpx<T> *dst = reinterpret_cast<cpx<T> *>(d_out) + b0 * n;
+        const size_t tm = nb * m, tn = nb * n;
+        hipLaunchKernelGGL((bluestein_pre_kernel<T, INVERSE>), dim3((unsigned)((tm + 255) / 256)), dim3(256), 0, ctx->stream, src, a,
+                           chirp, n, m, tm);
+        KOFFT_HIP_TRY(ctx, hipGetLastError());
+        rc = fft_dev<T>(ctx, reinterpret_cast<T *>(a), reinterpret_cast<T *>(a), m, nb, 0);
+        if (rc) return rc;
+        hipLaunchKernelGGL((bluestein_mid_kernel<T>), dim3((unsigned)((tm + 255) / 256)), dim3(256), 0, ctx->stream, a, bfft, m, tm);
+        KOFFT_HIP_TRY(ctx, hipGetLastError());
+        rc = fft_dev<T>(ctx, reinterpret_cast<T *>(a), reinterpret_cast<T *>(a), m, nb, 0);
+        if (rc) return rc;
+        hipLaunchKernelGGL((bluestein_post_kernel<T, INVERSE>), dim3((unsigned)((tn + 255) / 256)), dim3(256), 0, ctx->stream, a, dst,
+                           chirp, n, m, tn, scale_m, scale_n);
+        KOFFT_HIP_TRY(ctx, hipGetLastError());
+    }
+    return KOFFT_OK;
+}
+
+// ---------------------------------------------------------------------------------
 // typed entry points behind the C ABI
 // ---------------------------------------------------------------------------------
 template <typename T>
@@ -314,10 +393,11 @@ int fft_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t batch,
     // argument checks come first and need no device, so the reference's error order is testable anywhere
     if (batch == 0) return KOFFT_OK;
     if (n == 0) return KOFFT_ERR_EMPTY_INPUT;  // fft.rs:1056 / 1136
-    if (!is_pow2(n)) return KOFFT_ERR_UNSUPPORTED;  // Bluestein arm (fft.rs:1088-1132) not on the device path
-    if (n > (size_t(1) << max_log2_big<T>())) return KOFFT_ERR_UNSUPPORTED;
+    if (n > (size_t(1) << (is_pow2(n) ? max_log2_big<T>() : max_log2_big<T>() - 1))) return KOFFT_ERR_UNSUPPORTED;
     if (!ctx || !d_in || !d_out) return KOFFT_ERR_NULL;
     KOFFT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!is_pow2(n))  // fft.rs:1083-1132
+        return inverse ? fft_bluestein_dev<T, true>(ctx, d_in, d_out, n, batch) : fft_bluestein_dev<T, false>(ctx, d_in, d_out, n, batch);
     if (n > (size_t(1) << max_log2<T>()))
         return inverse ? fft_big_dev<T, true>(ctx, d_in, d_out, n, batch) : fft_big_dev<T, false>(ctx, d_in, d_out, n, batch);
     if (n == 1) {  // fft.rs:1059 / 1139: nothing to do
@@ -339,7 +419,7 @@ int fft_host(kofft_hip_ctx *ctx, T *data, size_t n, size_t batch, int inverse)
 {
     if (batch == 0) return KOFFT_OK;
     if (n == 0) return KOFFT_ERR_EMPTY_INPUT;
-    if (!is_pow2(n) || n > (size_t(1) << max_log2_big<T>())) return KOFFT_ERR_UNSUPPORTED;
+    if (n > (size_t(1) << (is_pow2(n) ? max_log2_big<T>() : max_log2_big<T>() - 1))) return KOFFT_ERR_UNSUPPORTED;
     if (n == 1) return KOFFT_OK;
     if (!ctx || !data) return KOFFT_ERR_NULL;
     KOFFT_HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -714,6 +794,7 @@ int kofft_hip_destroy(kofft_hip_ctx *ctx)
     for (int i = 0; i < 3; ++i)
         if (ctx->stage[i]) (void)hipFree(ctx->stage[i]);
     if (ctx->big_tmp) (void)hipFree(ctx->big_tmp);
+    if (ctx->blue_tmp) (void)hipFree(ctx->blue_tmp);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return KOFFT_OK;

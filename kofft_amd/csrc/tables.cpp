@@ -59,9 +59,30 @@ void rfft_table(size_t m, T *out)
     }
 }
 
+// FftPlanner::get_bluestein (fft.rs:411-433): chirp[i] = expi(-a_i), b[i] = expi(a_i) mirrored into the tail of a
+// zero-padded length-m buffer, a_i = pi * ((i*i) as f32) / (n as f32).  (b's FFT is taken on the device.)
+template <typename T>
+void bluestein(size_t n, size_t m, T *chirp, T *b)
+{
+    for (size_t i = 0; i < 2 * m; ++i) b[i] = (T)0;
+    for (size_t i = 0; i < n; ++i) {
+        const T angle = Num<T>::pi() * (T)(float)(i * i) / (T)(float)n;
+        chirp[2 * i] = Num<T>::cos(-angle);
+        chirp[2 * i + 1] = Num<T>::sin(-angle);
+        b[2 * i] = Num<T>::cos(angle);
+        b[2 * i + 1] = Num<T>::sin(angle);
+    }
+    for (size_t i = 1; i < n; ++i) {
+        b[2 * (m - i)] = b[2 * i];
+        b[2 * (m - i) + 1] = b[2 * i + 1];
+    }
+}
+
 }  // namespace
 
 namespace kofft_tables {
+void bluestein_f32(size_t n, size_t m, float *chirp, float *b) { bluestein<float>(n, m, chirp, b); }
+void bluestein_f64(size_t n, size_t m, double *chirp, double *b) { bluestein<double>(n, m, chirp, b); }
 void twiddles_f32(size_t n, float *out) { twiddles<float>(n, out); }
 void twiddles_f64(size_t n, double *out) { twiddles<double>(n, out); }
 void rfft_table_f32(size_t m, float *out) { rfft_table<float>(m, out); }

@@ -167,10 +167,21 @@ int main()
         fft.fft_batch(flat, 4096).unwrap();
         CHECK(std::memcmp(&flat[2 * 4096], wr.data(), 4096 * 8) == 0);
     }
-    {   // non-power-of-two: the device path reports it (DeviceError), it does not mis-compute
-        std::vector<Complex32> twelve(12);
+    {   // non-power-of-two lengths take the Bluestein arm (fft.rs:1088-1132): tests/bluestein.rs n = 15, lib.rs:267-282 n = 3
+        std::vector<Complex32> fifteen(15);
+        for (size_t i = 0; i < 15; ++i) fifteen[i] = Complex32((float)i, (float)i * 0.5f);
+        auto want = oracle_fft(fifteen);
+        fft.fft(fifteen).unwrap();
+        CHECK(same_bits(fifteen, want));
+        std::vector<Complex32> three = {{1, 0}, {2, 0}, {3, 0}};
+        fft.fft(three).unwrap();
+        fft.ifft(three).unwrap();
+        for (size_t i = 0; i < 3; ++i) { CHECK(std::fabs(three[i].re - (float)(i + 1)) < 1e-5f); CHECK(std::fabs(three[i].im) < 1e-5f); }
+        // a real FFT whose half length is not a power of two is outside the device path: reported (DeviceError), not mis-computed
+        std::vector<float> twelve(12, 1.0f);
+        std::vector<Complex32> seven(7);
         bool threw = false;
-        try { fft.fft(twelve); } catch (const DeviceError &e) { threw = e.status == KOFFT_ERR_UNSUPPORTED; }
+        try { fft.rfft(twelve, seven); } catch (const DeviceError &e) { threw = e.status == KOFFT_ERR_UNSUPPORTED; }
         CHECK(threw);
     }
     std::printf("%d checks, %d failed\n", g_checks, g_fail);

@@ -69,7 +69,7 @@ def test_argument_validation_needs_no_device(hiplib):
     assert hiplib.kofft_hip_fft_c64(null, p, sz(0), sz(1), 1) == 1
     assert hiplib.kofft_hip_fft_c32(null, p, sz(0), sz(0), 0) == 0       # batch() over no slices
     assert hiplib.kofft_hip_fft_c32(null, p, sz(1), sz(1), 0) == 0       # n == 1: Ok, nothing to do
-    assert hiplib.kofft_hip_fft_c32(null, p, sz(12), sz(1), 0) == -2     # Bluestein arm: unsupported
+    assert hiplib.kofft_hip_fft_c32(null, p, sz(12), sz(1), 0) == -3     # Bluestein arm: a valid request
     assert hiplib.kofft_hip_fft_c32(null, p, sz(1 << 27), sz(1), 0) == -2   # beyond the two-factor path (2^26)
     assert hiplib.kofft_hip_fft_c32(null, p, sz(8), sz(1), 0) == -3      # valid request, null context
     # fft.rs:1181-1190

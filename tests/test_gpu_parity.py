@@ -282,9 +282,9 @@ def test_error_variants_match_reference(fft32):
     fft32.fft_with_strategy(d, K.FftStrategy.SplitRadix)
     fft32.fft(e)
     assert bits_equal(d, e)
-    # non-power-of-two: outside the device path, reported (not silently mis-computed)
+    # non-power-of-two real FFT lengths (n/2 not a power of two) are outside the device path: reported, not mis-computed
     with pytest.raises(K.DeviceError):
-        fft32.fft(np.zeros(12, np.complex64))
+        fft32.rfft(np.zeros(12, np.float32), np.zeros(7, np.complex64))
 
 
 def test_strided_split_and_batch_helpers(fft32, fft64, oracle):
@@ -524,3 +524,51 @@ def test_ndfft_error_variants(fft32):
     K.fft2d_inplace(np.zeros(0, np.complex64), 0, 4, fft32, np.zeros(0, np.complex64))  # Ok: nothing to do
     with pytest.raises(FftError):
         K.flatten_2d([[1, 2], [3]])
+
+
+# ---- Bluestein arm: non-power-of-two lengths ---------------------------------------------------------------
+@pytest.mark.parametrize("n", [3, 5, 6, 7, 12, 15, 100, 1000, 4095, 5000, 100_003])
+def test_fft_non_power_of_two_matches_oracle(fft32, oracle, n):
+    """fft.rs:1088-1132: a = x*chirp, fft_m, *fft(b), conj, fft_m, conj, /m, *chirp with m = next_pow2(2n-1).  The
+    chirps come from the reference's f32 recipe on the host, the m-point transforms are the ordinary kernels."""
+    rng = seeded(1700 + n)
+    batch = 3 if n < 50_000 else 1
+    x = rand_c(rng, (batch, n))
+    y = x.copy()
+    fft32.fft_batch(y)
+    want = oracle.fft(x)
+    assert_parity(y, want, f"bluestein fft c32 n={n}", REL_TOL_F32)
+    fft32.fft_batch(y, inverse=True)
+    assert_parity(y, oracle.ifft(want), f"bluestein ifft c32 n={n}", REL_TOL_F32)
+
+
+@pytest.mark.parametrize("n", [3, 12, 15, 1000])
+def test_fft_non_power_of_two_f64(fft64, oracle, n):
+    rng = seeded(1800 + n)
+    x = rand_c(rng, (2, n), np.complex128)
+    y = x.copy()
+    fft64.fft_batch(y)
+    assert_parity(y, oracle.fft(x), f"bluestein fft c64 n={n}", REL_TOL_F64)
+
+
+def test_bluestein_reference_tests(fft32, fft64, oracle):
+    # tests/bluestein.rs:32-66: n = 15 against the naive f32 DFT within 1e-3
+    n = 15
+    i = np.arange(n, dtype=np.float32)
+    x = (i + 1j * (i * np.float32(0.5))).astype(np.complex64)
+    y = x.copy()
+    fft32.fft(y)
+    ref = np.fft.fft(x.astype(np.complex128))
+    assert np.all(np.abs(y - ref) < 1e-3)
+    # lib.rs:267-282 test_fft_ifft_nonpow2_f32: n = 3 round trip within 1e-5
+    d = np.array([1, 2, 3], np.complex64)
+    fft32.fft(d)
+    fft32.ifft(d)
+    assert np.all(np.abs(d - np.array([1, 2, 3])) < 1e-5)
+    # tests/split64.rs:20-34: n = 12 f64, SoA entry == AoS entry
+    re = np.arange(12, dtype=np.float64)
+    im = np.zeros(12)
+    aos = np.arange(12).astype(np.complex128)
+    fft64.fft(aos)
+    fft64.fft_split(re, im)
+    assert np.all(np.abs(aos.real - re) < 1e-10) and np.all(np.abs(aos.imag - im) < 1e-10)

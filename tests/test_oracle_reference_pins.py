@@ -252,3 +252,23 @@ def test_stft_istft_roundtrip_property(oracle):  # stft.rs:902-924 (proptest ran
                     norm[f * hop + i] += window[i] * window[i]
         ok = norm > 1e-3
         assert np.all(np.abs(back[ok] - signal[ok]) < 1e-2 * np.maximum(1.0, np.abs(signal[ok])) / np.minimum(1.0, norm[ok]))
+
+
+# ---- Bluestein arm ---------------------------------------------------------------------------------------------------
+def test_bluestein_n15_matches_naive_dft(oracle):  # tests/bluestein.rs:32-50
+    n = 15
+    i = np.arange(n, dtype=np.float32)
+    x = (i + 1j * (i * np.float32(0.5))).astype(np.complex64)
+    y, ref = oracle.fft(x), naive_dft_f32(x)
+    assert np.all(np.abs(y.real - ref.real) < 1e-3) and np.all(np.abs(y.imag - ref.imag) < 1e-3)
+
+
+def test_nonpow2_roundtrip_n3(oracle):  # lib.rs:267-282
+    x = c32([(1, 0), (2, 0), (3, 0)])
+    back = oracle.ifft(oracle.fft(x))
+    assert np.all(np.abs(back.real - x.real) < 1e-5) and np.all(np.abs(back.imag - x.imag) < 1e-5)
+
+
+def test_nonpow2_f64_n12_matches_dft(oracle):  # tests/split64.rs:20-34 input; truth = f64 DFT
+    x = np.arange(12, dtype=np.float64).astype(np.complex128)
+    assert np.all(np.abs(oracle.fft(x) - np.fft.fft(x)) < 1e-10)
