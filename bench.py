@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--workload", default="fft4096", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override per-GPU batch (debug only; invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inplace", action="store_true", help="fft4096 only: transform the buffer in place (values overflow after ~10 steps; timing study only)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work for the cpu_baseline sample")
     return ap.parse_args()
 
@@ -158,6 +159,8 @@ def main():
         unit = "GPoints/s"
         metric = "batched 4096-pt Complex32 forward FFT throughput"
         launch = lambda: fft.fft_dev_oop(src.data_ptr(), dst.data_ptr(), n, batch, False)  # noqa: E731
+        if args.inplace:
+            launch = lambda: fft.fft_dev(src.data_ptr(), n, batch, False)  # noqa: E731
         cfg = {"workload": WORKLOADS["fft4096"], "n": n, "batch_per_gpu": batch, "layout": "interleaved re/im, contiguous",
                "direction": "forward", "sharding": f"batch x{world}, no collective"}
     elif args.workload == "rfft2048":
