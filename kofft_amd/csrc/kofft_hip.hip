@@ -154,6 +154,7 @@ int launch_wg(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t batch)
 // and rfft variants carry window / post-pass operands and spill at 168, so they run 2 waves/SIMD.
 template <int L, class IO> struct PersistCfg;
 template <class IO> struct PersistCfg<12, IO> { static constexpr int BLOCK = 256, NBUF = 1, MINW = 2, WG_PER_CU = 2; };
+template <class IO> struct PersistCfg<11, IO> { static constexpr int BLOCK = 256, NBUF = 1, MINW = 2, WG_PER_CU = 2; };
 template <class IO> struct PersistCfg<10, IO> {
     static constexpr int BLOCK = 256, NBUF = 1, MINW = IO::kLeanRegisters ? 3 : 2, WG_PER_CU = MINW;
 };
@@ -213,6 +214,7 @@ int dispatch(kofft_hip_ctx *ctx, const IO &io, size_t n, size_t batch)
         if constexpr (EPI == EPI_STORE) {
             if (L == 12 && batch >= (size_t)ctx->num_cus * 4) return launch_persist<T, 12, EPI>(ctx, io, tw, batch);
         }
+        if (L == 11 && batch >= (size_t)ctx->num_cus * 16) return launch_persist<T, 11, EPI>(ctx, io, tw, batch);
         if (L == 10 && batch >= (size_t)ctx->num_cus * 32) return launch_persist<T, 10, EPI>(ctx, io, tw, batch);
     }
     switch (L) {

@@ -334,6 +334,23 @@ def test_fft_c32_1024_streaming_path(fft32, oracle, batch):
     assert_parity(y, oracle.ifft(want), f"streaming ifft c32 n=1024 batch={batch}", REL_TOL_F32)
 
 
+@pytest.mark.parametrize("batch", [4096, 4099])
+def test_n2048_streaming_paths(fft32, oracle, batch):
+    """n = 2048 (two wavefronts per transform, block-synchronised exchange): complex, rfft 4096 and STFT 2048 variants."""
+    rng = seeded(950 + batch)
+    x = rand_c(rng, (batch, 2048))
+    y = x.copy()
+    fft32.fft_batch(y)
+    assert_parity(y, oracle.fft(x), f"streaming fft c32 n=2048 batch={batch}", REL_TOL_F32)
+    r = rng.uniform(-1, 1, (batch, 4096)).astype(np.float32)
+    win = oracle.hann(4096)
+    assert_parity(fft32.rfft_batch(r, win), oracle.rfft(r, win), f"streaming rfft n=4096 batch={batch}", REL_TOL_F32)
+    sig = rng.uniform(-1, 1, 512 * batch + 100).astype(np.float32)
+    w2 = oracle.hann(2048)
+    frames = -(-sig.size // 512)
+    assert_parity(fft32.stft_into(sig, w2, 512, frames), oracle.stft(sig, w2, 512, frames), "streaming stft win=2048", REL_TOL_F32)
+
+
 @pytest.mark.parametrize("batch,windowed", [(8192, True), (8200, False), (10001, True)])
 def test_rfft_2048_streaming_path(fft32, oracle, batch, windowed):
     """BASELINE config #3 shape (2048-pt rfft + Hann) at a batch that takes the persistent kernel with the window and
