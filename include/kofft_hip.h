@@ -170,6 +170,15 @@ int kofft_hip_istft_f32(kofft_hip_ctx *ctx, float *frames_data, size_t frames, c
 int kofft_hip_istft_f32_dev(kofft_hip_ctx *ctx, float *d_frames, size_t frames, const float *d_window,
                             size_t win_len, size_t hop, float *d_output, size_t out_len,
                             float *d_scratch, size_t scratch_len);
+/* stft::inverse_parallel (stft.rs:289-343): the same sums, but the frames are not modified and samples
+ * whose window-square sum is <= 1e-8 are set to 0.  Only hop == 0 is rejected. */
+int kofft_hip_istft_parallel_f32(kofft_hip_ctx *ctx, const float *frames_data, size_t frames,
+                                 const float *window, size_t win_len, size_t hop, float *output,
+                                 size_t out_len);
+/* stft::inverse_frame (stft.rs:384-399): ifft(frame) in place, then output[start+i] += frame[i].re *
+ * window[i] for start+i < out_len; no normalisation. */
+int kofft_hip_istft_frame_f32(kofft_hip_ctx *ctx, float *frame, const float *window, size_t win_len,
+                              size_t start, float *output, size_t out_len);
 
 /* ---- STFT magnitudes (SURVEY 8f "next" row 2) --------------------------------------
  * visual::spectrogram::stft_magnitudes (visual/spectrogram.rs:52-76): STFT with a Hann window of

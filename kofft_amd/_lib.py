@@ -61,6 +61,8 @@ SIGNATURES = {
     "kofft_hip_stft_parallel_f32": (C.c_int, [_ctx, C.c_void_p, _sz, C.c_void_p, _sz, _sz, C.c_void_p, _sz]),
     "kofft_hip_stft_frame_f32": (C.c_int, [_ctx, C.c_void_p, _sz, C.c_void_p, _sz, _sz, C.c_void_p]),
     "kofft_hip_istft_f32": (C.c_int, [_ctx, C.c_void_p, _sz, C.c_void_p, _sz, _sz, C.c_void_p, _sz, C.c_void_p, _sz]),
+    "kofft_hip_istft_parallel_f32": (C.c_int, [_ctx, C.c_void_p, _sz, C.c_void_p, _sz, _sz, C.c_void_p, _sz]),
+    "kofft_hip_istft_frame_f32": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, _sz, _sz, C.c_void_p, _sz]),
     "kofft_hip_istft_f32_dev": (C.c_int, [_ctx, C.c_void_p, _sz, C.c_void_p, _sz, _sz, C.c_void_p, _sz, C.c_void_p, _sz]),
     "kofft_hip_stft_magnitudes_f32": (C.c_int, [_ctx, C.c_void_p, _sz, _sz, _sz, C.c_void_p, _sz, C.c_void_p]),
     "kofft_hip_stft_magnitudes_f32_dev": (C.c_int, [_ctx, C.c_void_p, _sz, _sz, _sz, C.c_void_p, _sz, C.c_void_p]),

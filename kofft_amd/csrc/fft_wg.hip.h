@@ -88,7 +88,7 @@ struct ComplexIO : PlainTw {
 // stft.rs:91-103: frame f starts at start0 + f*hop; x = signal[start+i]*window[i] or 0.
 struct StftIO : PlainTw {
     static constexpr bool kStreams = true;
-    static constexpr bool kInvInLds = false;  // 16 window samples per thread: registers
+    static constexpr bool kInvInLds = false;  // 16 window samples per thread: registers (LDS staging + 3 waves/SIMD measured slower)
     static constexpr bool kLeanRegisters = false;
     using Raw = float;
     using Inv = float;
@@ -436,28 +436,39 @@ __global__ __launch_bounds__(BLOCK, (IO::kMinWaves > 1 && BLOCK == 512 && L >= 9
 // increasing f, acc += frame[f][s - f*hop].re * window[i]; norm += window[i]*window[i]; then the > 1e-8 normalisation.
 // No atomics, so the f32 sums are the reference's sums bit for bit.  `frames` holds the already inverse-transformed
 // frames (the reference transforms them in place too).
+// MODE 0: stft::inverse_frame (stft.rs:384-399) -- accumulate only, no normalisation (scratch untouched);
+// MODE 1: stft::istft (stft.rs:117-156) -- normalise where the window-square sum exceeds 1e-8, else leave the sum;
+// MODE 2: stft::inverse_parallel (stft.rs:289-343) -- as MODE 1 but samples with a tiny sum become 0.
+// Frame f starts at sample start0 + f*hop.
+template <int MODE>
 __global__ __launch_bounds__(256) void istft_ola_kernel(const cpx<float> *__restrict__ frames, const float *__restrict__ window,
                                                         float *__restrict__ output, float *__restrict__ scratch,
                                                         const size_t nframes, const size_t win_len, const size_t hop,
-                                                        const size_t out_len)
+                                                        const size_t out_len, const size_t start0)
 {
     const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= out_len) return;
-    float acc = output[s];  // istft accumulates into the caller's buffer (stft.rs:144)
-    float norm = 0.0f;      // scratch is cleared first (stft.rs:132-134)
-    if (nframes > 0 && win_len > 0) {
-        size_t f_hi = s / hop;
+    float acc = output[s];  // accumulated into the caller's buffer (stft.rs:144, 330, 395)
+    float norm = 0.0f;      // scratch / norm start from zero (stft.rs:132-134, 325-326)
+    if (nframes > 0 && win_len > 0 && s >= start0) {
+        const size_t r = s - start0;
+        size_t f_hi = r / hop;
         if (f_hi > nframes - 1) f_hi = nframes - 1;
-        const size_t f_lo = (s >= win_len) ? (s - win_len) / hop + 1 : 0;
+        const size_t f_lo = (r >= win_len) ? (r - win_len) / hop + 1 : 0;
         for (size_t f = f_lo; f <= f_hi; ++f) {
-            const size_t i = s - f * hop;
+            const size_t i = r - f * hop;
             const float w = window[i];
             acc = acc + frames[f * win_len + i].re * w;
             norm = norm + w * w;
         }
     }
-    scratch[s] = norm;
-    output[s] = (norm > 1e-8f) ? acc / norm : acc;  // stft.rs:150-154
+    if (MODE == 0) {
+        output[s] = acc;
+    } else {
+        scratch[s] = norm;
+        if (norm > 1e-8f) output[s] = acc / norm;  // stft.rs:150-154 / 335-341
+        else output[s] = (MODE == 2) ? 0.0f : acc;
+    }
 }
 
 // ---- n = 1, 2, 4, 8, 16: one thread per transform, straight-line kernels ---------

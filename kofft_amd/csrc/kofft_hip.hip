@@ -593,15 +593,16 @@ int stft_host(kofft_hip_ctx *ctx, const float *signal, size_t len, const float *
     return KOFFT_OK;
 }
 
-// stft::istft (stft.rs:117-156): ifft every frame in place, overlap-add, normalise.
+// stft::istft (stft.rs:117-156, mode 1), stft::inverse_parallel (stft.rs:289-343, mode 2), stft::inverse_frame
+// (stft.rs:384-399, mode 0): ifft every frame in place, then the ordered overlap-add kernel.
 int istft_dev(kofft_hip_ctx *ctx, float *d_frames, size_t frames, const float *d_window, size_t win_len, size_t hop,
-              float *d_output, size_t out_len, float *d_scratch, size_t scratch_len)
+              float *d_output, size_t out_len, float *d_scratch, size_t scratch_len, int mode = 1, size_t start0 = 0)
 {
-    if (hop == 0) return KOFFT_ERR_INVALID_HOP_SIZE;                  // stft.rs:125
-    if (scratch_len != out_len) return KOFFT_ERR_MISMATCHED_LENGTHS;  // stft.rs:128
-    if (frames > 0 && win_len == 0) return KOFFT_ERR_EMPTY_INPUT;     // fft.ifft(&mut []) -> fft.rs:1136
+    if (hop == 0) return KOFFT_ERR_INVALID_HOP_SIZE;                               // stft.rs:125 / 299
+    if (mode == 1 && scratch_len != out_len) return KOFFT_ERR_MISMATCHED_LENGTHS;  // stft.rs:128
+    if (frames > 0 && win_len == 0) return KOFFT_ERR_EMPTY_INPUT;                  // fft.ifft(&mut []) -> fft.rs:1136
     if (frames > 0 && (!is_pow2(win_len) || win_len > (size_t(1) << max_log2<float>()))) return KOFFT_ERR_UNSUPPORTED;
-    if (!ctx || (frames && (!d_frames || !d_window)) || (out_len && (!d_output || !d_scratch))) return KOFFT_ERR_NULL;
+    if (!ctx || (frames && (!d_frames || !d_window)) || (out_len && (!d_output || (mode != 0 && !d_scratch)))) return KOFFT_ERR_NULL;
     KOFFT_HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (frames > 0) {
         int rc = fft_dev<float>(ctx, d_frames, d_frames, win_len, frames, 1);
@@ -610,11 +611,53 @@ int istft_dev(kofft_hip_ctx *ctx, float *d_frames, size_t frames, const float *d
     if (out_len > 0) {
         const size_t blocks = (out_len + 255) / 256;
         if (blocks > 0x7fffffffULL) return KOFFT_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL(istft_ola_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
-                           reinterpret_cast<const cpx<float> *>(d_frames), d_window, d_output, d_scratch, frames, win_len, hop,
-                           out_len);
+        const cpx<float> *fr = reinterpret_cast<const cpx<float> *>(d_frames);
+        if (mode == 0)
+            hipLaunchKernelGGL(istft_ola_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, fr, d_window, d_output,
+                               d_scratch, frames, win_len, hop, out_len, start0);
+        else if (mode == 2)
+            hipLaunchKernelGGL(istft_ola_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, fr, d_window, d_output,
+                               d_scratch, frames, win_len, hop, out_len, start0);
+        else
+            hipLaunchKernelGGL(istft_ola_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, fr, d_window, d_output,
+                               d_scratch, frames, win_len, hop, out_len, start0);
         KOFFT_HIP_TRY(ctx, hipGetLastError());
     }
+    return KOFFT_OK;
+}
+
+// host-pointer wrapper shared by istft / inverse_parallel / inverse_frame
+int istft_host(kofft_hip_ctx *ctx, float *frames_data, size_t frames, const float *window, size_t win_len, size_t hop,
+               float *output, size_t out_len, float *scratch, size_t scratch_len, int mode, size_t start0, bool copy_frames_back)
+{
+    if (hop == 0) return KOFFT_ERR_INVALID_HOP_SIZE;
+    if (mode == 1 && scratch_len != out_len) return KOFFT_ERR_MISMATCHED_LENGTHS;
+    if (frames > 0 && win_len == 0) return KOFFT_ERR_EMPTY_INPUT;
+    if (frames > 0 && (!is_pow2(win_len) || win_len > (size_t(1) << max_log2<float>()))) return KOFFT_ERR_UNSUPPORTED;
+    if (!ctx || (frames && (!frames_data || !window)) || (out_len && (!output || (mode == 1 && !scratch)))) return KOFFT_ERR_NULL;
+    KOFFT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t fr_bytes = frames * win_len * 2 * sizeof(float);
+    const size_t o_bytes = out_len * sizeof(float);
+    // one staging allocation: [frames | output | scratch | window]
+    const size_t a0 = 0, a1 = (fr_bytes + 255) & ~size_t(255), a2 = a1 + ((o_bytes + 255) & ~size_t(255)),
+                 a3 = a2 + ((o_bytes + 255) & ~size_t(255)), total = a3 + win_len * sizeof(float) + 256;
+    int rc = ensure_stage(ctx, 0, total);
+    if (rc) return rc;
+    char *base = static_cast<char *>(ctx->stage[0]);
+    if (fr_bytes) KOFFT_HIP_TRY(ctx, hipMemcpyAsync(base + a0, frames_data, fr_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (o_bytes) KOFFT_HIP_TRY(ctx, hipMemcpyAsync(base + a1, output, o_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (win_len) KOFFT_HIP_TRY(ctx, hipMemcpyAsync(base + a3, window, win_len * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    rc = istft_dev(ctx, reinterpret_cast<float *>(base + a0), frames, reinterpret_cast<const float *>(base + a3), win_len, hop,
+                   reinterpret_cast<float *>(base + a1), out_len, reinterpret_cast<float *>(base + a2), mode == 1 ? scratch_len : out_len,
+                   mode, start0);
+    if (rc) return rc;
+    if (fr_bytes && copy_frames_back)
+        KOFFT_HIP_TRY(ctx, hipMemcpyAsync(frames_data, base + a0, fr_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (o_bytes) {
+        KOFFT_HIP_TRY(ctx, hipMemcpyAsync(output, base + a1, o_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        if (mode == 1 && scratch) KOFFT_HIP_TRY(ctx, hipMemcpyAsync(scratch, base + a2, o_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    KOFFT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return KOFFT_OK;
 }
 
@@ -959,33 +1002,22 @@ int kofft_hip_istft_f32_dev(kofft_hip_ctx *ctx, float *d_frames, size_t frames, 
 int kofft_hip_istft_f32(kofft_hip_ctx *ctx, float *frames_data, size_t frames, const float *window, size_t win_len,
                         size_t hop, float *output, size_t out_len, float *scratch, size_t scratch_len)
 {
-    if (hop == 0) return KOFFT_ERR_INVALID_HOP_SIZE;
-    if (scratch_len != out_len) return KOFFT_ERR_MISMATCHED_LENGTHS;
-    if (frames > 0 && win_len == 0) return KOFFT_ERR_EMPTY_INPUT;
-    if (frames > 0 && (!is_pow2(win_len) || win_len > (size_t(1) << max_log2<float>()))) return KOFFT_ERR_UNSUPPORTED;
-    if (!ctx || (frames && (!frames_data || !window)) || (out_len && (!output || !scratch))) return KOFFT_ERR_NULL;
-    KOFFT_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const size_t fr_bytes = frames * win_len * 2 * sizeof(float);
-    const size_t o_bytes = out_len * sizeof(float);
-    // one staging allocation: [frames | output | scratch | window]
-    const size_t a0 = 0, a1 = (fr_bytes + 255) & ~size_t(255), a2 = a1 + ((o_bytes + 255) & ~size_t(255)),
-                 a3 = a2 + ((o_bytes + 255) & ~size_t(255)), total = a3 + win_len * sizeof(float) + 256;
-    int rc = ensure_stage(ctx, 0, total);
-    if (rc) return rc;
-    char *base = static_cast<char *>(ctx->stage[0]);
-    if (fr_bytes) KOFFT_HIP_TRY(ctx, hipMemcpyAsync(base + a0, frames_data, fr_bytes, hipMemcpyHostToDevice, ctx->stream));
-    if (o_bytes) KOFFT_HIP_TRY(ctx, hipMemcpyAsync(base + a1, output, o_bytes, hipMemcpyHostToDevice, ctx->stream));
-    if (win_len) KOFFT_HIP_TRY(ctx, hipMemcpyAsync(base + a3, window, win_len * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    rc = istft_dev(ctx, reinterpret_cast<float *>(base + a0), frames, reinterpret_cast<const float *>(base + a3), win_len, hop,
-                   reinterpret_cast<float *>(base + a1), out_len, reinterpret_cast<float *>(base + a2), scratch_len);
-    if (rc) return rc;
-    if (fr_bytes) KOFFT_HIP_TRY(ctx, hipMemcpyAsync(frames_data, base + a0, fr_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    if (o_bytes) {
-        KOFFT_HIP_TRY(ctx, hipMemcpyAsync(output, base + a1, o_bytes, hipMemcpyDeviceToHost, ctx->stream));
-        KOFFT_HIP_TRY(ctx, hipMemcpyAsync(scratch, base + a2, o_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    }
-    KOFFT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return KOFFT_OK;
+    return istft_host(ctx, frames_data, frames, window, win_len, hop, output, out_len, scratch, scratch_len, 1, 0, true);
+}
+
+int kofft_hip_istft_parallel_f32(kofft_hip_ctx *ctx, const float *frames_data, size_t frames, const float *window,
+                                 size_t win_len, size_t hop, float *output, size_t out_len)
+{
+    // inverse_parallel clones each frame (stft.rs:310): the caller's frames are left untouched
+    return istft_host(ctx, const_cast<float *>(frames_data), frames, window, win_len, hop, output, out_len, nullptr, out_len, 2, 0,
+                      false);
+}
+
+int kofft_hip_istft_frame_f32(kofft_hip_ctx *ctx, float *frame, const float *window, size_t win_len, size_t start,
+                              float *output, size_t out_len)
+{
+    // inverse_frame (stft.rs:384-399): ifft(frame) in place, output[start + i] += frame[i].re * window[i], no normalisation
+    return istft_host(ctx, frame, 1, window, win_len, win_len ? win_len : 1, output, out_len, nullptr, out_len, 0, start, true);
 }
 
 int kofft_hip_stft_magnitudes_f32_dev(kofft_hip_ctx *ctx, const float *d_samples, size_t len, size_t win_len, size_t hop,

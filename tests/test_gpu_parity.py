@@ -589,3 +589,35 @@ def test_bluestein_reference_tests(fft32, fft64, oracle):
     fft64.fft(aos)
     fft64.fft_split(re, im)
     assert np.all(np.abs(aos.real - re) < 1e-10) and np.all(np.abs(aos.imag - im) < 1e-10)
+
+
+def test_inverse_parallel_and_inverse_frame(fft32, oracle):
+    """stft.rs:289-343 and 384-399 (+ the frame round trip of stft.rs:526-557)."""
+    import kofft_amd as K
+
+    rng = seeded(1900)
+    signal = rng.uniform(-1, 1, 3000).astype(np.float32)
+    window = oracle.hann(256)
+    hop = 64
+    nframes = -(-signal.size // hop)
+    spec = oracle.stft(signal, window, hop, nframes)
+    want = oracle.istft(spec, window, hop, signal.size)  # same sums; differs only where the norm is <= 1e-8 (sample 0 of a Hann window)
+    keep = spec.copy()
+    out = np.zeros(signal.size, np.float32)
+    K.inverse_parallel(spec, window, hop, out, fft32)
+    assert bits_equal(spec, keep)                        # frames are cloned, not transformed (stft.rs:310)
+    assert out[0] == 0.0 and bits_equal(out[1:], want[1:])
+    # frame / inverse_frame streaming round trip with a rectangular window (stft.rs:526-557)
+    sig = np.arange(1, 9, dtype=np.float32)
+    win = np.ones(4, np.float32)
+    output = np.zeros(8, np.float32)
+    norm = np.zeros(8, np.float32)
+    buf = np.zeros(4, np.complex64)
+    for pos in range(0, 8, 2):
+        K.frame(sig, win, pos, buf, fft32)
+        K.inverse_frame(buf, win, pos, output, fft32)
+        for i in range(4):
+            if pos + i < 8:
+                norm[pos + i] += win[i] * win[i]
+    output[norm > 1e-8] /= norm[norm > 1e-8]
+    assert np.all(np.abs(output - sig) < 1e-4)
