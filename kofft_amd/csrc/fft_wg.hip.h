@@ -54,6 +54,15 @@ struct ComplexIO : PlainTw {
         return make_rsrc(in + (valid ? xf : 0) * (size_t)n, valid ? (unsigned)n * sizeof(cpx<T>) : 0u);
     }
     __device__ __forceinline__ rsrc_t out_desc(size_t xf) const { return make_rsrc(out + xf * (size_t)n, (unsigned)n * sizeof(cpx<T>)); }
+    // workgroup forms (fft_wg_kernel, several transforms per wave): one descriptor over the xpb consecutive
+    // transforms starting at xf0, cut at the end of the batch; lane offset = slot * in_slot_bytes() + element.
+    __device__ __forceinline__ bool wg_desc_ok(int) const { return true; }
+    __device__ __forceinline__ unsigned in_slot_bytes() const { return (unsigned)n * sizeof(cpx<T>); }
+    __device__ __forceinline__ rsrc_t in_desc_wg(size_t xf0, size_t batch, int xpb) const
+    {
+        const size_t cnt = xf0 < batch ? (batch - xf0 < (size_t)xpb ? batch - xf0 : (size_t)xpb) : 0;
+        return make_rsrc(in + (cnt ? xf0 : 0) * (size_t)n, (unsigned)(cnt * n * sizeof(cpx<T>)));
+    }
     __device__ __forceinline__ Raw fetch_d(rsrc_t d, int lane_bytes, int iu) const
     {
         return buf_load_cpx<T, AUX_NT>(d, lane_bytes, iu * (int)sizeof(cpx<T>));
@@ -112,6 +121,18 @@ struct StftIO : PlainTw {
         return make_rsrc(signal + (avail ? start : 0), (unsigned)(avail < (size_t)n ? avail : (size_t)n) * 4u);
     }
     __device__ __forceinline__ rsrc_t out_desc(size_t xf) const { return make_rsrc(out + xf * (size_t)n, (unsigned)n * 8u); }
+    // workgroup forms: the descriptor starts at frame xf0's first sample and ends with the signal (or 4 GiB
+    // earlier); frames past `batch` read real samples or zeros and are never stored.  32-bit lane offsets
+    // bound the hop this form can serve.
+    __device__ __forceinline__ bool wg_desc_ok(int xpb) const { return hop <= (size_t(1) << 22) && (size_t)xpb * hop < (size_t(1) << 28); }
+    __device__ __forceinline__ unsigned in_slot_bytes() const { return (unsigned)hop * 4u; }
+    __device__ __forceinline__ rsrc_t in_desc_wg(size_t xf0, size_t, int) const
+    {
+        const size_t start = start0 + xf0 * hop;
+        size_t avail = start < len ? len - start : 0;
+        if (avail > 0x3fffffffULL) avail = 0x3fffffffULL;
+        return make_rsrc(signal + (avail ? start : 0), (unsigned)avail * 4u);
+    }
     __device__ __forceinline__ Raw fetch_d(rsrc_t d, int lane_bytes, int iu) const { return buf_load_f32<AUX_DEFAULT>(d, lane_bytes, iu * 4); }
     __device__ __forceinline__ void store_d(rsrc_t d, int lane_bytes, int ou, cpx<float> v) const
     {
@@ -192,6 +213,13 @@ struct RfftIO : PlainTw {
     __device__ __forceinline__ rsrc_t out_desc(size_t xf) const
     {
         return make_rsrc(out + xf * (size_t)(m + 1), (unsigned)(m + 1) * sizeof(cpx<T>));
+    }
+    __device__ __forceinline__ bool wg_desc_ok(int) const { return true; }
+    __device__ __forceinline__ unsigned in_slot_bytes() const { return (unsigned)m * sizeof(cpx<T>); }
+    __device__ __forceinline__ rsrc_t in_desc_wg(size_t xf0, size_t batch, int xpb) const
+    {
+        const size_t cnt = xf0 < batch ? (batch - xf0 < (size_t)xpb ? batch - xf0 : (size_t)xpb) : 0;
+        return make_rsrc(in + (cnt ? xf0 : 0) * (size_t)(2 * m), (unsigned)(cnt * m * sizeof(cpx<T>)));
     }
     __device__ __forceinline__ Raw fetch_d(rsrc_t d, int lane_bytes, int iu) const
     {
@@ -391,8 +419,29 @@ __global__ __launch_bounds__(BLOCK, (IO::kMinWaves > 1 && BLOCK == 512 && L >= 9
     cpx<T> v[R];
     {   // pass 0 inputs through the IO policy
         using G0 = WgGeom<L, RL, 0>;
+        bool fetched = false;
+        if constexpr (IO::kStreams && !IO::kSlotMinor) {
+            // Streaming policies: every load of the workgroup goes through ONE buffer descriptor whose bounds
+            // check supplies the zeros past the end of the batch / signal, so the R loads issue back to back
+            // with no per-element address test or branch (the per-element form serialises on s_waitcnt).
+            if (io.wg_desc_ok(XPB)) {
+                const rsrc_t d = io.in_desc_wg(blk * XPB, batch, XPB);
+                const int lane_bytes = slot * (int)io.in_slot_bytes() + tau * IO::kRawBytes;
+                typename IO::Raw raw[R];
 #pragma unroll
-        for (int u = 0; u < R; ++u) v[u] = active ? io.load(xf, G0::in_index(tau, u)) : mk<T>(T(0), T(0));
+                for (int u = 0; u < R; ++u) raw[u] = io.fetch_d(d, lane_bytes, G0::in_index(0, u));
+#pragma unroll
+                for (int u = 0; u < R; ++u) {
+                    const int i = G0::in_index(tau, u);
+                    v[u] = io.finish(xf, i, raw[u], io.invariant(i));
+                }
+                fetched = true;
+            }
+        }
+        if (!fetched) {
+#pragma unroll
+            for (int u = 0; u < R; ++u) v[u] = active ? io.load(xf, G0::in_index(tau, u)) : mk<T>(T(0), T(0));
+        }
     }
     wg_compute<T, L, RL, 0>(v, io, tw, xf, tau);
     if constexpr (NP > 1) { wg_exchange<T, L, RL, 0, SPLIT, SM, XPB>(v, smem_raw, tau, slot); wg_compute<T, L, RL, 1>(v, io, tw, xf, tau); }
@@ -473,27 +522,99 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const cpx<float> *__rest
 
 // ---- n = 1, 2, 4, 8, 16: one thread per transform, straight-line kernels ---------
 // (fft.rs:1059-1071 dispatch; ifft wraps them with conj / conj*scale via the IO policy)
+// A thread's n inputs are n*8 (or 16) consecutive bytes, so lanes reading "their own" element i would touch 64
+// different cache lines per instruction.  The workgroup therefore moves its 256 transforms through LDS: global
+// reads and writes run over the workgroup's elements in memory order (fully coalesced), and each thread picks its
+// row out of LDS (row stride n+1 cells: odd, so the 64 lanes hit distinct banks).
+constexpr int kSmallBlock = 256;
+template <typename T, int N>
+constexpr size_t small_lds_bytes() { return N == 1 ? 0 : (size_t)kSmallBlock * (N + 1) * sizeof(cpx<T>); }
+
 template <typename T, int N, int EPI, class IO>
-__global__ __launch_bounds__(256) void fft_small_kernel(const IO io, const size_t batch)
+__global__ __launch_bounds__(kSmallBlock) void fft_small_kernel(const IO io, const size_t batch)
 {
-    const size_t xf = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (xf >= batch) return;
+    constexpr int B = kSmallBlock;
+    constexpr int S = N + 1;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cpx<T> *buf = reinterpret_cast<cpx<T> *>(smem_raw);
+    const int t = threadIdx.x;
+    const size_t xf0 = (size_t)blockIdx.x * B;
+    const size_t xf = xf0 + t;
     cpx<T> x[N];
+    if constexpr (N == 1) {
+        if (xf >= batch) return;
+        x[0] = io.load(xf, 0);
+    } else {
+        bool fetched = false;
+        if constexpr (IO::kStreams) {
+            if (io.wg_desc_ok(B)) {
+                const rsrc_t d = io.in_desc_wg(xf0, batch, B);
+                typename IO::Raw raw[N];
 #pragma unroll
-    for (int i = 0; i < N; ++i) x[i] = io.load(xf, i);
+                for (int j = 0; j < N; ++j) {
+                    const int e = j * B + t, r = e / N, i = e % N;
+                    raw[j] = io.fetch_d(d, r * (int)io.in_slot_bytes() + i * IO::kRawBytes, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const int e = j * B + t, r = e / N, i = e % N;
+                    buf[r * S + i] = io.finish(xf0 + r, i, raw[j], io.invariant(i));
+                }
+                fetched = true;
+            }
+        }
+        if (!fetched) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const int e = j * B + t, r = e / N, i = e % N;
+                buf[r * S + i] = (xf0 + r < batch) ? io.load(xf0 + r, i) : mk<T>(T(0), T(0));
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < N; ++i) x[i] = buf[t * S + i];
+    }
     if constexpr (N == 2) small_fft2(x);
     if constexpr (N == 4) small_fft4(x);
     if constexpr (N == 8) small_fft8(x);
     if constexpr (N == 16) small_fft16(x);
     if constexpr (EPI == EPI_RFFT) {
-        cpx<T> *orow = io.out + xf * (size_t)(N + 1);
-        orow[0] = mk<T>(x[0].re + x[0].im, T(0));
-        orow[N] = mk<T>(x[0].re - x[0].im, T(0));
+        // rfft.rs:450-463 on registers; a row of LDS (n+1 cells) is exactly one output row
+        const cpx<T> x0 = mk<T>(x[0].re + x[0].im, T(0)), xn = mk<T>(x[0].re - x[0].im, T(0));
+        if constexpr (N == 1) {
+            cpx<T> *orow = io.out + xf * (size_t)2;
+            orow[0] = x0;
+            orow[1] = xn;
+        } else {
+            cpx<T> y[N];
 #pragma unroll
-        for (int k = 1; k < N; ++k) orow[k] = io.post(k, x[k], x[N - k]);
+            for (int k = 1; k < N; ++k) y[k] = io.post(k, x[k], x[N - k]);
+            buf[t * S] = x0;
+            buf[t * S + N] = xn;
+#pragma unroll
+            for (int k = 1; k < N; ++k) buf[t * S + k] = y[k];
+            __syncthreads();
+            const size_t cnt = batch - xf0 < (size_t)B ? batch - xf0 : (size_t)B;
+            cpx<T> *ochunk = io.out + xf0 * (size_t)S;
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                const int e = j * B + t;
+                if ((size_t)e < cnt * S) ochunk[e] = buf[e];
+            }
+        }
     } else {
+        if constexpr (N == 1) {
+            io.store(xf, 0, x[0]);
+        } else {
 #pragma unroll
-        for (int i = 0; i < N; ++i) io.store(xf, i, x[i]);
+            for (int i = 0; i < N; ++i) buf[t * S + i] = x[i];
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const int e = j * B + t, r = e / N, o = e % N;
+                if (xf0 + r < batch) io.store(xf0 + r, o, buf[r * S + o]);
+            }
+        }
     }
 }
 

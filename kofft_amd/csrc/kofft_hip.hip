@@ -183,10 +183,15 @@ int launch_persist(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t ba
 template <typename T, int N, int EPI, class IO>
 int launch_small(kofft_hip_ctx *ctx, const IO &io, size_t batch)
 {
-    const size_t blocks = (batch + 255) / 256;
+    const size_t blocks = (batch + kSmallBlock - 1) / kSmallBlock;
     if (blocks > 0x7fffffffULL) return KOFFT_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((fft_small_kernel<T, N, EPI, IO>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, io,
-                       batch);
+    constexpr size_t lds = small_lds_bytes<T, N>();
+    auto kern = fft_small_kernel<T, N, EPI, IO>;
+    if (lds > 64 * 1024) {
+        KOFFT_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kSmallBlock), lds, ctx->stream, io, batch);
     KOFFT_HIP_TRY(ctx, hipGetLastError());
     return KOFFT_OK;
 }
