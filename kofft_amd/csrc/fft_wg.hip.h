@@ -439,8 +439,14 @@ __global__ __launch_bounds__(BLOCK, (IO::kMinWaves > 1 && BLOCK == 512 && L >= 9
             }
         }
         if (!fetched) {
+            // one branch around ALL loads (a per-element test would put a branch and a wait between them)
+            if (active) {
 #pragma unroll
-            for (int u = 0; u < R; ++u) v[u] = active ? io.load(xf, G0::in_index(tau, u)) : mk<T>(T(0), T(0));
+                for (int u = 0; u < R; ++u) v[u] = io.load(xf, G0::in_index(tau, u));
+            } else {
+#pragma unroll
+                for (int u = 0; u < R; ++u) v[u] = mk<T>(T(0), T(0));
+            }
         }
     }
     wg_compute<T, L, RL, 0>(v, io, tw, xf, tau);
@@ -459,16 +465,28 @@ __global__ __launch_bounds__(BLOCK, (IO::kMinWaves > 1 && BLOCK == 512 && L >= 9
         __syncthreads();
         if (active) {
             cpx<T> *orow = io.out + xf * (size_t)(N + 1);
+            // all table entries first, then all results, then all stores: interleaving them makes every store wait
+            // for the next table load (the compiler cannot prove the table and the output disjoint)
+            cpx<T> w[R], xo[R];
+#pragma unroll
+            for (int g = 0; g < R; ++g) w[g] = io.rtab[tau + g * TPT];
 #pragma unroll
             for (int g = 0; g < R; ++g) {
                 const int k = tau + g * TPT;
-                if (k == 0) {
+                if (g == 0) {
+                    // k == 0 (tau == 0): X[0] here, X[N] below; other lanes: the ordinary post-pass
                     const cpx<T> y0 = buf[lds_pad(0)];
-                    orow[0] = mk<T>(y0.re + y0.im, T(0));
-                    orow[N] = mk<T>(y0.re - y0.im, T(0));
+                    const cpx<T> p = io.post_w(w[0], buf[lds_pad(k)], buf[lds_pad((N - k) & (N - 1))]);
+                    xo[0] = (k == 0) ? mk<T>(y0.re + y0.im, T(0)) : p;
                 } else {
-                    orow[k] = io.post(k, buf[lds_pad(k)], buf[lds_pad(N - k)]);
+                    xo[g] = io.post_w(w[g], buf[lds_pad(k)], buf[lds_pad(N - k)]);
                 }
+            }
+#pragma unroll
+            for (int g = 0; g < R; ++g) orow[tau + g * TPT] = xo[g];
+            if (tau == 0) {
+                const cpx<T> y0 = buf[lds_pad(0)];
+                orow[N] = mk<T>(y0.re - y0.im, T(0));
             }
         }
     } else {
@@ -564,10 +582,24 @@ __global__ __launch_bounds__(kSmallBlock) void fft_small_kernel(const IO io, con
             }
         }
         if (!fetched) {
+            if (xf0 + B <= batch) {  // full workgroup: no per-element test between the loads
+                cpx<T> tmp[N];
 #pragma unroll
-            for (int j = 0; j < N; ++j) {
-                const int e = j * B + t, r = e / N, i = e % N;
-                buf[r * S + i] = (xf0 + r < batch) ? io.load(xf0 + r, i) : mk<T>(T(0), T(0));
+                for (int j = 0; j < N; ++j) {
+                    const int e = j * B + t;
+                    tmp[j] = io.load(xf0 + e / N, e % N);
+                }
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const int e = j * B + t;
+                    buf[(e / N) * S + e % N] = tmp[j];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const int e = j * B + t, r = e / N, i = e % N;
+                    buf[r * S + i] = (xf0 + r < batch) ? io.load(xf0 + r, i) : mk<T>(T(0), T(0));
+                }
             }
         }
         __syncthreads();

@@ -91,6 +91,19 @@ def main():
                     rows.append(dict(kind=kind, n=n, batch=batch, ms=ms, gbs=gbs, frac=gbs / 8000))
                     print(f"{kind:7s} n={n:9d} batch={batch:9d} {ms:8.4f} ms {gbs:8.1f} GB/s frac {gbs/8000:.3f}", flush=True)
                     del src, dst
+            elif kind == "irfft32":
+                fft = kofft_amd.HipFftImpl(np.float32, device=0)
+                fft.set_stream(stream.cuda_stream)
+                for L in range(2, 16):
+                    n = 1 << L
+                    batch = max(1, (args.mb << 20) // (4 * n))
+                    src = torch.empty((batch, n // 2 + 1, 2), dtype=torch.float32, device=dev).uniform_(-1, 1)
+                    dst = torch.empty((batch, n), dtype=torch.float32, device=dev)
+                    ms = timeit(stream, lambda: fft.irfft_dev(src.data_ptr(), dst.data_ptr(), n, batch))
+                    gbs = batch * (4 * n + 8 * (n // 2 + 1)) / ms / 1e6
+                    rows.append(dict(kind=kind, n=n, batch=batch, ms=ms, gbs=gbs, frac=gbs / 8000))
+                    print(f"{kind:7s} n={n:9d} batch={batch:9d} {ms:8.4f} ms {gbs:8.1f} GB/s frac {gbs/8000:.3f}", flush=True)
+                    del src, dst
             elif kind == "stft":
                 fft = kofft_amd.HipFftImpl(np.float32, device=0)
                 fft.set_stream(stream.cuda_stream)
