@@ -386,8 +386,16 @@ __device__ __forceinline__ void wg_compute(cpx<T> *v, const IO &io, const cpx<T>
         reg_pass<T, L, Gm::S0, Gm::Q, false>(&v[g * (1 << Gm::Q)], (tau + g * Gm::TPT) >> Gm::JB, tw, io.tw_map(xf));
 }
 
+// A single transform whose complex exchange buffer would leave room for only one workgroup per CU moves its real
+// and imaginary parts in two rounds instead (half the LDS, two workgroups per CU overlap each other's HBM phases).
+template <typename T, int L, int EPI, class IO>
+constexpr bool wg_split_lds()
+{
+    return IO::kSplitLds || (EPI == 0 && !IO::kSlotMinor && sizeof(T) == 4 && L == 14);
+}
+
 template <typename T, int L, int RL, int BLOCK, int EPI, class IO>
-__global__ __launch_bounds__(BLOCK, (IO::kMinWaves > 1 && BLOCK == 512 && L >= 9 && L <= 11) ? IO::kMinWaves : 1) void fft_wg_kernel(const IO io, const cpx<T> *__restrict__ tw, const size_t batch)
+__global__ __launch_bounds__(BLOCK, (IO::kMinWaves > 1 && BLOCK == 512 && L >= 9 && L <= 11) ? IO::kMinWaves : (wg_split_lds<T, L, EPI, IO>() && !IO::kSplitLds ? 2 : 1)) void fft_wg_kernel(const IO io, const cpx<T> *__restrict__ tw, const size_t batch)
 {
     constexpr int N = 1 << L;
     constexpr int R = 1 << RL;
@@ -396,7 +404,7 @@ __global__ __launch_bounds__(BLOCK, (IO::kMinWaves > 1 && BLOCK == 512 && L >= 9
     constexpr int XPB = BLOCK / TPT;
     constexpr int NP = (L + RL - 1) / RL;
     static_assert(NP >= 1 && NP <= 5, "pass count");
-    constexpr bool SPLIT = IO::kSplitLds;
+    constexpr bool SPLIT = wg_split_lds<T, L, EPI, IO>();
     constexpr bool SM = IO::kSlotMinor;
     static_assert(!((SPLIT || SM) && EPI == EPI_RFFT), "the rfft epilogue reads whole complex values from a plain slot");
     static_assert(!SM || (SPLIT ? sizeof(T) : sizeof(cpx<T>)) == 8, "slot-minor layout is built for 8-byte exchange elements");
@@ -538,7 +546,7 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const cpx<float> *__rest
     }
 }
 
-// ---- n = 1, 2, 4, 8, 16: one thread per transform, straight-line kernels ---------
+// ---- n = 1, 2, 4, 8, 16 (and 32 in f32): one thread per transform ---------
 // (fft.rs:1059-1071 dispatch; ifft wraps them with conj / conj*scale via the IO policy)
 // A thread's n inputs are n*8 (or 16) consecutive bytes, so lanes reading "their own" element i would touch 64
 // different cache lines per instruction.  The workgroup therefore moves its 256 transforms through LDS: global
@@ -549,7 +557,7 @@ template <typename T, int N>
 constexpr size_t small_lds_bytes() { return N == 1 ? 0 : (size_t)kSmallBlock * (N + 1) * sizeof(cpx<T>); }
 
 template <typename T, int N, int EPI, class IO>
-__global__ __launch_bounds__(kSmallBlock) void fft_small_kernel(const IO io, const size_t batch)
+__global__ __launch_bounds__(kSmallBlock) void fft_small_kernel(const IO io, const cpx<T> *__restrict__ tw, const size_t batch)
 {
     constexpr int B = kSmallBlock;
     constexpr int S = N + 1;
@@ -610,9 +618,13 @@ __global__ __launch_bounds__(kSmallBlock) void fft_small_kernel(const IO io, con
     if constexpr (N == 4) small_fft4(x);
     if constexpr (N == 8) small_fft8(x);
     if constexpr (N == 16) small_fft16(x);
+    // n = 32 is the first size of the table-driven Stockham path (fft.rs:1059-1071): all five stages in registers,
+    // k == 0 so every twiddle index is a compile-time constant; output o ends up in register bitrev(o).
+    if constexpr (N == 32) reg_pass<T, 5, 0, 5, true>(x, 0, tw, io.tw_map(xf));
+    auto Y = [&](int o) -> cpx<T> & { return x[N == 32 ? bitrev(o, 5) : o]; };
     if constexpr (EPI == EPI_RFFT) {
         // rfft.rs:450-463 on registers; a row of LDS (n+1 cells) is exactly one output row
-        const cpx<T> x0 = mk<T>(x[0].re + x[0].im, T(0)), xn = mk<T>(x[0].re - x[0].im, T(0));
+        const cpx<T> x0 = mk<T>(Y(0).re + Y(0).im, T(0)), xn = mk<T>(Y(0).re - Y(0).im, T(0));
         if constexpr (N == 1) {
             cpx<T> *orow = io.out + xf * (size_t)2;
             orow[0] = x0;
@@ -620,7 +632,7 @@ __global__ __launch_bounds__(kSmallBlock) void fft_small_kernel(const IO io, con
         } else {
             cpx<T> y[N];
 #pragma unroll
-            for (int k = 1; k < N; ++k) y[k] = io.post(k, x[k], x[N - k]);
+            for (int k = 1; k < N; ++k) y[k] = io.post(k, Y(k), Y(N - k));
             buf[t * S] = x0;
             buf[t * S + N] = xn;
 #pragma unroll
@@ -639,7 +651,7 @@ __global__ __launch_bounds__(kSmallBlock) void fft_small_kernel(const IO io, con
             io.store(xf, 0, x[0]);
         } else {
 #pragma unroll
-            for (int i = 0; i < N; ++i) buf[t * S + i] = x[i];
+            for (int i = 0; i < N; ++i) buf[t * S + i] = Y(i);
             __syncthreads();
 #pragma unroll
             for (int j = 0; j < N; ++j) {

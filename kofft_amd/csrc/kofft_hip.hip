@@ -131,7 +131,7 @@ int launch_wg(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t batch)
     constexpr int BLOCK = BLOCK_OVERRIDE ? BLOCK_OVERRIDE : block_for(L);
     constexpr int TPT = (1 << L) >> RL;
     constexpr int XPB = BLOCK / TPT;
-    constexpr size_t lds = lds_wg_bytes<T, IO::kSplitLds, IO::kSlotMinor, XPB>(1 << L);
+    constexpr size_t lds = lds_wg_bytes<T, wg_split_lds<T, L, EPI, IO>(), IO::kSlotMinor, XPB>(1 << L);
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = fft_wg_kernel<T, L, RL, BLOCK, EPI, IO>;
     if (lds > 64 * 1024) {
@@ -181,7 +181,7 @@ int launch_persist(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t ba
 }
 
 template <typename T, int N, int EPI, class IO>
-int launch_small(kofft_hip_ctx *ctx, const IO &io, size_t batch)
+int launch_small(kofft_hip_ctx *ctx, const IO &io, size_t batch, const cpx<T> *tw = nullptr)
 {
     const size_t blocks = (batch + kSmallBlock - 1) / kSmallBlock;
     if (blocks > 0x7fffffffULL) return KOFFT_ERR_UNSUPPORTED;
@@ -191,7 +191,7 @@ int launch_small(kofft_hip_ctx *ctx, const IO &io, size_t batch)
         KOFFT_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kSmallBlock), lds, ctx->stream, io, batch);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kSmallBlock), lds, ctx->stream, io, tw, batch);
     KOFFT_HIP_TRY(ctx, hipGetLastError());
     return KOFFT_OK;
 }
@@ -214,6 +214,8 @@ int dispatch(kofft_hip_ctx *ctx, const IO &io, size_t n, size_t batch)
     const cpx<T> *tw = nullptr;
     int rc = get_table<T>(ctx, Kind<T>::tw, n, &tw);
     if (rc) return rc;
+    // n = 32 in f32: still one thread per transform (64 data registers), IO staged through LDS like the small sizes
+    if constexpr (sizeof(T) == 4 && !IO::kSlotMinor) if (L == 5) return launch_small<T, 32, EPI>(ctx, io, batch, tw);
     if constexpr (sizeof(T) == 4 && IO::kStreams) if (ctx->use_persist) {
         // streaming sizes: enough transforms to give every resident workgroup several iterations
         if constexpr (EPI == EPI_STORE) {

@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--mb", type=int, default=512, help="input size per launch in MiB")
     ap.add_argument("--out", default="gpurun_out/sweep.json")
     ap.add_argument("--kinds", default="c32,c64,rfft32,stft")
+    ap.add_argument("--only-n", type=int, default=0, help="restrict every kind to this n")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
@@ -57,6 +58,8 @@ def main():
                 esz = 8 if kind == "c32" else 16
                 for L in range(1, 25):
                     n = 1 << L
+                    if args.only_n and n != args.only_n:
+                        continue
                     batch = max(1, (args.mb << 20) // (esz * n))
                     src = torch.empty((batch, n, 2), dtype=dt, device=dev).uniform_(-1, 1)
                     dst = torch.empty_like(src)
@@ -82,6 +85,8 @@ def main():
                 fft.set_stream(stream.cuda_stream)
                 for L in range(2, 16):
                     n = 1 << L
+                    if args.only_n and n != args.only_n:
+                        continue
                     batch = max(1, (args.mb << 20) // (4 * n))
                     src = torch.empty((batch, n), dtype=torch.float32, device=dev).uniform_(-1, 1)
                     dst = torch.empty((batch, n // 2 + 1, 2), dtype=torch.float32, device=dev)
@@ -96,6 +101,8 @@ def main():
                 fft.set_stream(stream.cuda_stream)
                 for L in range(2, 16):
                     n = 1 << L
+                    if args.only_n and n != args.only_n:
+                        continue
                     batch = max(1, (args.mb << 20) // (4 * n))
                     src = torch.empty((batch, n // 2 + 1, 2), dtype=torch.float32, device=dev).uniform_(-1, 1)
                     dst = torch.empty((batch, n), dtype=torch.float32, device=dev)
@@ -111,6 +118,8 @@ def main():
                 sig = torch.empty(total, dtype=torch.float32, device=dev).uniform_(-1, 1)
                 for L in range(5, 15):
                     n = 1 << L
+                    if args.only_n and n != args.only_n:
+                        continue
                     hop = n // 4
                     frames = -(-total // hop)
                     win = torch.from_numpy(kofft_amd.hann(n)).to(dev)
