@@ -114,7 +114,10 @@ int ensure_stage(kofft_hip_ctx *ctx, int which, size_t bytes)
 // ---------------------------------------------------------------------------------
 // launch geometry
 // ---------------------------------------------------------------------------------
-constexpr int rl_for(int L) { return (L == 5 || L == 6 || L == 9) ? 3 : (L >= 13 ? 5 : 4); }
+#ifndef KOFFT_RL_BIG
+#define KOFFT_RL_BIG 5
+#endif
+constexpr int rl_for(int L) { return (L == 5 || L == 6 || L == 9) ? 3 : (L >= 13 ? KOFFT_RL_BIG : 4); }
 constexpr int block_for(int L)
 {
     const int tpt = (1 << L) >> rl_for(L);
