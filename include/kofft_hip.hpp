@@ -95,6 +95,7 @@ template <> struct Abi<float> {
     static int irfft(kofft_hip_ctx *c, const float *i, float *o, size_t n, size_t b) { return kofft_hip_irfft_f32(c, i, o, n, b); }
     static int twiddles(size_t n, float *o) { return kofft_hip_twiddles_f32(n, o); }
     static int rfft_table(size_t m, float *o) { return kofft_hip_rfft_table_f32(m, o); }
+    static int fftnd(kofft_hip_ctx *c, float *d, size_t dp, size_t r, size_t cl, int inv) { return kofft_hip_fftnd_c32(c, d, dp, r, cl, inv); }
 };
 template <> struct Abi<double> {
     static int fft(kofft_hip_ctx *c, double *d, size_t n, size_t b, int inv) { return kofft_hip_fft_c64(c, d, n, b, inv); }
@@ -103,6 +104,7 @@ template <> struct Abi<double> {
     static int irfft(kofft_hip_ctx *c, const double *i, double *o, size_t n, size_t b) { return kofft_hip_irfft_f64(c, i, o, n, b); }
     static int twiddles(size_t n, double *o) { return kofft_hip_twiddles_f64(n, o); }
     static int rfft_table(size_t m, double *o) { return kofft_hip_rfft_table_f64(m, o); }
+    static int fftnd(kofft_hip_ctx *c, double *d, size_t dp, size_t r, size_t cl, int inv) { return kofft_hip_fftnd_c64(c, d, dp, r, cl, inv); }
 };
 }  // namespace detail
 
@@ -358,6 +360,64 @@ inline Result istft(std::vector<std::vector<Complex32>> &frames, const std::vect
     for (size_t f = 0; f < frames.size(); ++f) frames[f].assign(flat.begin() + f * wl, flat.begin() + (f + 1) * wl);
     return Result::Ok();
 }
+// stft::inverse_parallel (stft.rs:289-343): frames are left untouched, samples whose window-square sum is <= 1e-8
+// become 0; only hop == 0 is rejected (a frame shorter than the window panics in the reference: out_of_range here)
+inline Result inverse_parallel(const std::vector<std::vector<Complex32>> &frames, const std::vector<float> &window,
+                               size_t hop_size, std::vector<float> &output, const HipFftImpl<float> &fft)
+{
+    if (hop_size == 0) return Result::Err(FftError::InvalidHopSize);
+    const size_t wl = window.size();
+    std::vector<Complex32> flat(frames.size() * wl);
+    for (size_t f = 0; f < frames.size(); ++f) {
+        if (frames[f].size() != wl) throw std::out_of_range("frame length differs from the window (the reference panics)");
+        std::copy(frames[f].begin(), frames[f].end(), flat.begin() + f * wl);
+    }
+    return fft.st(kofft_hip_istft_parallel_f32(fft.raw(), reinterpret_cast<const float *>(flat.data()), frames.size(),
+                                               window.data(), wl, hop_size, output.data(), output.size()));
+}
+// stft::inverse_frame (stft.rs:384-399): ifft(frame) in place, windowed add into output from `start`, no normalisation
+inline Result inverse_frame(std::vector<Complex32> &frame_io, const std::vector<float> &window, size_t start,
+                            std::vector<float> &output, const HipFftImpl<float> &fft)
+{
+    if (frame_io.size() != window.size()) throw std::out_of_range("frame length differs from the window (the reference panics)");
+    return fft.st(kofft_hip_istft_frame_f32(fft.raw(), reinterpret_cast<float *>(frame_io.data()), window.data(), window.size(),
+                                            start, output.data(), output.size()));
+}
+// visual::spectrogram::stft_magnitudes (visual/spectrogram.rs:52-76): (frames x win_len/2 magnitudes, max magnitude)
+inline Result stft_magnitudes(const std::vector<float> &samples, size_t win_len, size_t hop,
+                              std::vector<std::vector<float>> &mags, float &max_mag, const HipFftImpl<float> &fft)
+{
+    if (hop == 0) return Result::Err(FftError::InvalidHopSize);  // the reference divides by hop (panic)
+    const size_t frames = (samples.size() + hop - 1) / hop, half = win_len / 2;
+    std::vector<float> flat(frames * half);
+    Result r = fft.st(kofft_hip_stft_magnitudes_f32(fft.raw(), samples.data(), samples.size(), win_len, hop, flat.data(), frames,
+                                                    &max_mag));
+    if (r.is_err()) return r;
+    mags.assign(frames, std::vector<float>());
+    for (size_t f = 0; f < frames; ++f) mags[f].assign(flat.begin() + f * half, flat.begin() + (f + 1) * half);
+    return Result::Ok();
+}
+
+// ndfft::fft2d_inplace (ndfft.rs:74-101) / fft3d_inplace (ndfft.rs:114-155): same length checks, same order
+template <typename T>
+Result fft2d_inplace(std::vector<Complex<T>> &data, size_t rows, size_t cols, const HipFftImpl<T> &fft,
+                     std::vector<Complex<T>> &scratch_col)
+{
+    if (rows * cols != data.size()) return Result::Err(FftError::MismatchedLengths);
+    if (rows == 0 || cols == 0) return Result::Ok();
+    if (scratch_col.size() != rows) return Result::Err(FftError::MismatchedLengths);
+    return fft.st(detail::Abi<T>::fftnd(fft.raw(), reinterpret_cast<T *>(data.data()), 1, rows, cols, 0));
+}
+template <typename T>
+Result fft3d_inplace(std::vector<Complex<T>> &data, size_t depth, size_t rows, size_t cols, const HipFftImpl<T> &fft,
+                     std::vector<Complex<T>> &tube, std::vector<Complex<T>> &row, std::vector<Complex<T>> &col)
+{
+    if (depth * rows * cols != data.size()) return Result::Err(FftError::MismatchedLengths);
+    if (depth == 0 || rows == 0 || cols == 0) return Result::Ok();
+    if (tube.size() != depth || row.size() != rows || col.size() != cols) return Result::Err(FftError::MismatchedLengths);
+    return fft.st(detail::Abi<T>::fftnd(fft.raw(), reinterpret_cast<T *>(data.data()), depth, rows, cols, 0));
+}
+
 // stft::parallel (stft.rs:232-263): only hop == 0 is rejected
 inline Result parallel(const std::vector<float> &signal, const std::vector<float> &window, size_t hop_size,
                        std::vector<std::vector<Complex32>> &output, const HipFftImpl<float> &fft)

@@ -27,6 +27,17 @@ extern "C" {
     fn kofft_hip_rfft_f32(ctx: *mut KofftHipCtx, input: *const f32, out: *mut f32, window: *const f32, n: usize, batch: usize) -> c_int;
     fn kofft_hip_stft_f32(ctx: *mut KofftHipCtx, signal: *const f32, len: usize, window: *const f32, win_len: usize,
                           hop: usize, out: *mut f32, frames: usize) -> c_int;
+    fn kofft_hip_stft_parallel_f32(ctx: *mut KofftHipCtx, signal: *const f32, len: usize, window: *const f32, win_len: usize,
+                                   hop: usize, out: *mut f32, frames: usize) -> c_int;
+    fn kofft_hip_irfft_f32(ctx: *mut KofftHipCtx, input: *const f32, out: *mut f32, n: usize, batch: usize) -> c_int;
+    fn kofft_hip_istft_f32(ctx: *mut KofftHipCtx, frames_data: *mut f32, frames: usize, window: *const f32, win_len: usize,
+                           hop: usize, output: *mut f32, out_len: usize, scratch: *mut f32, scratch_len: usize) -> c_int;
+    fn kofft_hip_istft_parallel_f32(ctx: *mut KofftHipCtx, frames_data: *const f32, frames: usize, window: *const f32,
+                                    win_len: usize, hop: usize, output: *mut f32, out_len: usize) -> c_int;
+    fn kofft_hip_stft_magnitudes_f32(ctx: *mut KofftHipCtx, samples: *const f32, len: usize, win_len: usize, hop: usize,
+                                     mags: *mut f32, frames: usize, max_mag: *mut f32) -> c_int;
+    fn kofft_hip_fftnd_c32(ctx: *mut KofftHipCtx, data: *mut f32, depth: usize, rows: usize, cols: usize, inverse: c_int) -> c_int;
+    fn kofft_hip_fftnd_c64(ctx: *mut KofftHipCtx, data: *mut f64, depth: usize, rows: usize, cols: usize, inverse: c_int) -> c_int;
 }
 
 /// 0 = Ok, 1..=6 = FftError in declaration order (kofft fft.rs:447-454).  FftError has no variant for a
@@ -142,6 +153,31 @@ macro_rules! impl_fft {
 impl_fft!(f32, Complex32, kofft_hip_fft_c32, kofft_hip_fft_c32_strided);
 impl_fft!(f64, Complex64, kofft_hip_fft_c64, kofft_hip_fft_c64_strided);
 
+macro_rules! impl_ndfft {
+    ($t:ty, $cplx:ty, $nd:ident) => {
+        impl HipFftImpl<$t> {
+            /// `ndfft::fft2d_inplace` (kofft ndfft.rs:74-101): kofft's function takes `&ScalarFftImpl<T>` concretely,
+            /// so the device version is an inherent method with the same length checks.
+            pub fn fft2d_inplace(&self, data: &mut [$cplx], rows: usize, cols: usize, scratch_col: &mut [$cplx]) -> Result<(), FftError> {
+                if rows * cols != data.len() { return Err(FftError::MismatchedLengths); }
+                if rows == 0 || cols == 0 { return Ok(()); }
+                if scratch_col.len() != rows { return Err(FftError::MismatchedLengths); }
+                status(self.ctx, unsafe { $nd(self.ctx, data.as_mut_ptr() as *mut $t, 1, rows, cols, 0) })
+            }
+            /// `ndfft::fft3d_inplace` (kofft ndfft.rs:114-155).
+            pub fn fft3d_inplace(&self, data: &mut [$cplx], depth: usize, rows: usize, cols: usize, tube: &mut [$cplx],
+                                 row: &mut [$cplx], col: &mut [$cplx]) -> Result<(), FftError> {
+                if depth * rows * cols != data.len() { return Err(FftError::MismatchedLengths); }
+                if depth == 0 || rows == 0 || cols == 0 { return Ok(()); }
+                if tube.len() != depth || row.len() != rows || col.len() != cols { return Err(FftError::MismatchedLengths); }
+                status(self.ctx, unsafe { $nd(self.ctx, data.as_mut_ptr() as *mut $t, depth, rows, cols, 0) })
+            }
+        }
+    };
+}
+impl_ndfft!(f32, Complex32, kofft_hip_fftnd_c32);
+impl_ndfft!(f64, Complex64, kofft_hip_fftnd_c64);
+
 impl HipFftImpl<f32> {
     /// Batched real FFT with an optional fused window: `out` holds `batch * (n/2 + 1)` complex values.
     pub fn rfft_batch(&self, input: &[f32], n: usize, window: Option<&[f32]>, out: &mut [Complex<f32>]) -> Result<(), FftError> {
@@ -160,6 +196,60 @@ impl HipFftImpl<f32> {
             kofft_hip_stft_f32(self.ctx, signal.as_ptr(), signal.len(), window.as_ptr(), window.len(), hop_size,
                                out.as_mut_ptr() as *mut f32, frames)
         })
+    }
+}
+
+impl HipFftImpl<f32> {
+    /// `stft::parallel` (kofft stft.rs:232-263) ignores the `fft` it is handed and builds a `ScalarFftImpl` per
+    /// frame; this is the same arithmetic on the device (only `hop_size == 0` is rejected, as there).
+    pub fn stft_parallel_contiguous(&self, signal: &[f32], window: &[f32], hop_size: usize, out: &mut [Complex32]) -> Result<(), FftError> {
+        let frames = if window.is_empty() { 0 } else { out.len() / window.len() };
+        status(self.ctx, unsafe {
+            kofft_hip_stft_parallel_f32(self.ctx, signal.as_ptr(), signal.len(), window.as_ptr(), window.len(), hop_size,
+                                        out.as_mut_ptr() as *mut f32, frames)
+        })
+    }
+
+    /// Batched `irfft` (kofft rfft.rs:468-508): `input` holds `batch * (n/2 + 1)` complex values, `out` `batch * n` reals.
+    pub fn irfft_batch(&self, input: &[Complex32], n: usize, out: &mut [f32]) -> Result<(), FftError> {
+        if n == 0 { return Err(FftError::EmptyInput); }
+        let batch = out.len() / n;
+        if out.len() % n != 0 || input.len() != batch * (n / 2 + 1) { return Err(FftError::MismatchedLengths); }
+        status(self.ctx, unsafe { kofft_hip_irfft_f32(self.ctx, input.as_ptr() as *const f32, out.as_mut_ptr(), n, batch) })
+    }
+
+    /// `stft::istft` (kofft stft.rs:117-156) over one contiguous `frames * window.len()` buffer: the frames are
+    /// inverse-transformed in place, `output` is accumulated into and normalised, `scratch` receives the window-square sums.
+    pub fn istft_contiguous(&self, frames: &mut [Complex32], window: &[f32], hop_size: usize, output: &mut [f32],
+                            scratch: &mut [f32]) -> Result<(), FftError> {
+        let count = if window.is_empty() { 0 } else { frames.len() / window.len() };
+        status(self.ctx, unsafe {
+            kofft_hip_istft_f32(self.ctx, frames.as_mut_ptr() as *mut f32, count, window.as_ptr(), window.len(), hop_size,
+                                output.as_mut_ptr(), output.len(), scratch.as_mut_ptr(), scratch.len())
+        })
+    }
+
+    /// `stft::inverse_parallel` (kofft stft.rs:289-343): frames untouched, tiny-norm samples set to zero.
+    pub fn inverse_parallel_contiguous(&self, frames: &[Complex32], window: &[f32], hop_size: usize, output: &mut [f32]) -> Result<(), FftError> {
+        let count = if window.is_empty() { 0 } else { frames.len() / window.len() };
+        status(self.ctx, unsafe {
+            kofft_hip_istft_parallel_f32(self.ctx, frames.as_ptr() as *const f32, count, window.as_ptr(), window.len(), hop_size,
+                                         output.as_mut_ptr(), output.len())
+        })
+    }
+
+    /// `visual::spectrogram::stft_magnitudes` (kofft visual/spectrogram.rs:52-76): magnitudes of bins
+    /// `0 .. win_len/2` of every Hann-windowed frame (row-major `frames x win_len/2`) and their maximum.
+    pub fn stft_magnitudes(&self, samples: &[f32], win_len: usize, hop: usize) -> Result<(Vec<Vec<f32>>, f32), FftError> {
+        if hop == 0 { return Err(FftError::InvalidHopSize); }
+        let frames = (samples.len() + hop - 1) / hop;
+        let half = win_len / 2;
+        let mut flat = vec![0.0f32; frames * half];
+        let mut max_mag = 0.0f32;
+        status(self.ctx, unsafe {
+            kofft_hip_stft_magnitudes_f32(self.ctx, samples.as_ptr(), samples.len(), win_len, hop, flat.as_mut_ptr(), frames, &mut max_mag)
+        })?;
+        Ok((flat.chunks(half.max(1)).take(frames).map(|c| c.to_vec()).collect(), max_mag))
     }
 }
 

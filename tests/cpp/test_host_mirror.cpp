@@ -184,6 +184,81 @@ int main()
         try { fft.rfft(twelve, seven); } catch (const DeviceError &e) { threw = e.status == KOFFT_ERR_UNSUPPORTED; }
         CHECK(threw);
     }
+    {   // stft.rs:526-557 frame / inverse_frame streaming round trip; stft.rs:289-343 inverse_parallel vs istft
+        std::vector<float> sig = {1, 2, 3, 4, 5, 6, 7, 8}, win(4, 1.0f), output(8, 0.0f), norm(8, 0.0f);
+        std::vector<Complex32> buf(4);
+        for (size_t pos = 0; pos < 8; pos += 2) {
+            frame(sig, win, pos, buf, fft).unwrap();
+            inverse_frame(buf, win, pos, output, fft).unwrap();
+            for (size_t i = 0; i < 4 && pos + i < 8; ++i) norm[pos + i] += win[i] * win[i];
+        }
+        for (size_t i = 0; i < 8; ++i) CHECK(std::fabs(output[i] / norm[i] - sig[i]) < 1e-4f);
+        std::vector<float> hw = hann(8), out_a(16, 0.0f), out_b(16, 0.0f), scratch(16, 0.0f), sig16(16);
+        for (size_t i = 0; i < 16; ++i) sig16[i] = std::sin(0.37f * (float)i);
+        std::vector<std::vector<Complex32>> frames(8, std::vector<Complex32>(8)), copy;
+        stft(sig16, hw, 2, frames, fft).unwrap();
+        copy = frames;
+        inverse_parallel(frames, hw, 2, out_b, fft).unwrap();
+        CHECK(frames == copy);  // untouched
+        istft(copy, hw, 2, out_a, scratch, fft).unwrap();
+        for (size_t i = 0; i < 16; ++i) CHECK(scratch[i] > 1e-8f ? std::memcmp(&out_a[i], &out_b[i], 4) == 0 : out_b[i] == 0.0f);
+        CHECK(inverse_parallel(frames, hw, 0, out_b, fft) == Result::Err(FftError::InvalidHopSize));
+    }
+    {   // visual/spectrogram.rs:52-76 stft_magnitudes against the mirror's own stft (same kernel arithmetic, sqrt of re*re + im*im)
+        std::vector<float> sig(300);
+        for (size_t i = 0; i < sig.size(); ++i) sig[i] = std::sin(0.05f * (float)i) + 0.25f * std::cos(0.31f * (float)i);
+        std::vector<std::vector<float>> mags;
+        float mx = -1.0f;
+        stft_magnitudes(sig, 64, 16, mags, mx, fft).unwrap();
+        CHECK(mags.size() == 19 && mags[0].size() == 32);
+        std::vector<std::vector<Complex32>> fr(19, std::vector<Complex32>(64));
+        stft(sig, hann(64), 16, fr, fft).unwrap();
+        float want_max = 0.0f;
+        bool same = true;
+        for (size_t f = 0; f < 19; ++f)
+            for (size_t k = 0; k < 32; ++k) {
+                const float m = std::sqrt(fr[f][k].re * fr[f][k].re + fr[f][k].im * fr[f][k].im);
+                same = same && std::memcmp(&m, &mags[f][k], 4) == 0;
+                if (m > want_max) want_max = m;
+            }
+        CHECK(same);
+        CHECK(mx == want_max);
+        CHECK(stft_magnitudes(sig, 64, 0, mags, mx, fft) == Result::Err(FftError::InvalidHopSize));
+    }
+    {   // ndfft.rs:158-225 tests: 2-D impulse -> all ones; length checks; 3-D round trip through rows/columns/tubes
+        std::vector<Complex32> img(8 * 16, Complex32(0, 0)), col(8), bad(7);
+        img[0] = Complex32(1, 0);
+        fft2d_inplace<float>(img, 8, 16, fft, col).unwrap();
+        bool ones = true;
+        for (auto &c : img) ones = ones && c.re == 1.0f && c.im == 0.0f;
+        CHECK(ones);
+        CHECK(fft2d_inplace<float>(img, 8, 16, fft, bad) == Result::Err(FftError::MismatchedLengths));
+        CHECK(fft2d_inplace<float>(img, 8, 15, fft, col) == Result::Err(FftError::MismatchedLengths));
+        // 2-D against the oracle: rows, then columns through gather / fft / scatter (ndfft.rs:88-99)
+        std::vector<Complex32> a(4 * 8), want;
+        for (size_t i = 0; i < a.size(); ++i) a[i] = Complex32(std::sin((float)i), 0.5f * std::cos(2.0f * (float)i));
+        want = a;
+        for (size_t r = 0; r < 4; ++r) {
+            std::vector<Complex32> row(want.begin() + r * 8, want.begin() + (r + 1) * 8);
+            row = oracle_fft(row);
+            std::copy(row.begin(), row.end(), want.begin() + r * 8);
+        }
+        for (size_t c = 0; c < 8; ++c) {
+            std::vector<Complex32> cc(4);
+            for (size_t r = 0; r < 4; ++r) cc[r] = want[r * 8 + c];
+            cc = oracle_fft(cc);
+            for (size_t r = 0; r < 4; ++r) want[r * 8 + c] = cc[r];
+        }
+        std::vector<Complex32> col4(4);
+        fft2d_inplace<float>(a, 4, 8, fft, col4).unwrap();
+        CHECK(same_bits(a, want));
+        std::vector<Complex64> vol(2 * 4 * 8, Complex64(0, 0)), t2(2), r4(4), c8(8);
+        vol[0] = Complex64(2, 0);
+        fft3d_inplace<double>(vol, 2, 4, 8, fft64, t2, r4, c8).unwrap();
+        bool twos = true;
+        for (auto &c : vol) twos = twos && c.re == 2.0 && c.im == 0.0;
+        CHECK(twos);
+    }
     std::printf("%d checks, %d failed\n", g_checks, g_fail);
     return g_fail == 0 ? 0 : 1;
 }
