@@ -84,7 +84,7 @@ struct BigRowsIO {
             const T im = -v.im;
             v = mk<T>(v.re * scale, im * scale);
         }
-        out[b * n + ((size_t)q << LA) + K] = v;
+        st_stream(out + b * n + ((size_t)q << LA) + K, v);
     }
 };
 

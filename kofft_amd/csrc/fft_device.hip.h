@@ -47,6 +47,30 @@ __device__ __forceinline__ cpx<T> ld_stream(const cpx<T> *p)
     return mk<T>(v.x, v.y);
 }
 
+// Streaming (write-once) global store: same hint on the way out.  Measured on the bench kernels (buffer form,
+// one box, back to back): STFT 0.216 -> 0.193 ms, 65536 x 4096 c32 0.80 -> 0.775 ms, rfft unchanged.
+template <typename T>
+__device__ __forceinline__ void st_stream(cpx<T> *p, cpx<T> v)
+{
+    typedef T vec2 __attribute__((ext_vector_type(2)));
+    vec2 f;
+    f.x = v.re;
+    f.y = v.im;
+#ifdef KOFFT_PLAIN_STORES
+    *reinterpret_cast<vec2 *>(p) = f;
+#else
+    __builtin_nontemporal_store(f, reinterpret_cast<vec2 *>(p));
+#endif
+}
+__device__ __forceinline__ void st_stream(float *p, float v)
+{
+#ifdef KOFFT_PLAIN_STORES
+    *p = v;
+#else
+    __builtin_nontemporal_store(v, p);
+#endif
+}
+
 // ---- buffer (SRSRC) addressing for the streaming kernels ---------------------------------------------
 // A per-transform descriptor built from wave-uniform values (base pointer + byte count) lets every access be
 // "descriptor (SGPRs) + one per-thread byte offset (a single VGPR) + a constant", instead of a 64-bit address
@@ -79,6 +103,9 @@ __device__ __forceinline__ cpx<T> buf_load_cpx(rsrc_t r, int voff, int coff)
     return mk<T>(f.x, f.y);
 }
 
+#ifndef KOFFT_STORE_AUX
+#define KOFFT_STORE_AUX AUX_NT  // outputs are written once and not read back by the kernel (see st_stream)
+#endif
 template <typename T>
 __device__ __forceinline__ void buf_store_cpx(cpx<T> c, rsrc_t r, int voff, int coff)
 {
@@ -88,16 +115,16 @@ __device__ __forceinline__ void buf_store_cpx(cpx<T> c, rsrc_t r, int voff, int 
     f.y = c.im;
     if constexpr (sizeof(T) == 4) {
         typedef unsigned v2u __attribute__((ext_vector_type(2)));
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, f), r, voff, coff, AUX_DEFAULT);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, f), r, voff, coff, KOFFT_STORE_AUX);
     } else {
         typedef unsigned v4u __attribute__((ext_vector_type(4)));
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, f), r, voff, coff, AUX_DEFAULT);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, f), r, voff, coff, KOFFT_STORE_AUX);
     }
 }
 
 __device__ __forceinline__ void buf_store_f32(float v, rsrc_t r, int voff, int coff)
 {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, coff, AUX_DEFAULT);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, coff, KOFFT_STORE_AUX);
 }
 
 template <int AUX>

@@ -90,7 +90,7 @@ struct ComplexIO : PlainTw {
             v.re = v.re * scale;
             v.im = im * scale;
         }
-        out[xf * (size_t)n + o] = v;
+        st_stream(out + xf * (size_t)n + o, v);
     }
 };
 
@@ -146,7 +146,7 @@ struct StftIO : PlainTw {
     __device__ __forceinline__ cpx<float> load(size_t xf, int i) const { return finish(xf, i, fetch(xf, i), invariant(i)); }
     __device__ __forceinline__ void store(size_t xf, int o, cpx<float> v) const
     {
-        out[xf * (size_t)n + o] = v;
+        st_stream(out + xf * (size_t)n + o, v);
     }
 };
 
@@ -159,7 +159,7 @@ struct StftMagIO : StftIO {
     __device__ __forceinline__ static float mag(cpx<float> c) { return sqrtf(c.re * c.re + c.im * c.im); }
     __device__ __forceinline__ void store(size_t xf, int o, cpx<float> v) const
     {
-        if (o < n / 2) mags[xf * (size_t)(n / 2) + o] = mag(v);
+        if (o < n / 2) st_stream(mags + xf * (size_t)(n / 2) + o, mag(v));
     }
     __device__ __forceinline__ rsrc_t out_desc(size_t xf) const { return make_rsrc(mags + xf * (size_t)(n / 2), (unsigned)(n / 2) * 4u); }
     __device__ __forceinline__ void store_d(rsrc_t d, int lane_bytes, int ou, cpx<float> v) const
@@ -287,7 +287,7 @@ struct IrfftIO : PlainTw {
             const T im = -v.im;
             v = mk<T>(v.re * scale, im * scale);
         }
-        out[xf * (size_t)m + o] = v;
+        st_stream(out + xf * (size_t)m + o, v);
     }
 };
 
@@ -491,10 +491,10 @@ __global__ __launch_bounds__(BLOCK, (IO::kMinWaves > 1 && BLOCK == 512 && L >= 9
                 }
             }
 #pragma unroll
-            for (int g = 0; g < R; ++g) orow[tau + g * TPT] = xo[g];
+            for (int g = 0; g < R; ++g) st_stream(orow + tau + g * TPT, xo[g]);
             if (tau == 0) {
                 const cpx<T> y0 = buf[lds_pad(0)];
-                orow[N] = mk<T>(y0.re - y0.im, T(0));
+                st_stream(orow + N, mk<T>(y0.re - y0.im, T(0)));
             }
         }
     } else {
@@ -643,7 +643,7 @@ __global__ __launch_bounds__(kSmallBlock) void fft_small_kernel(const IO io, con
 #pragma unroll
             for (int j = 0; j < S; ++j) {
                 const int e = j * B + t;
-                if ((size_t)e < cnt * S) ochunk[e] = buf[e];
+                if ((size_t)e < cnt * S) st_stream(ochunk + e, buf[e]);
             }
         }
     } else {

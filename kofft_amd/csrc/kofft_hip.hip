@@ -117,7 +117,9 @@ int ensure_stage(kofft_hip_ctx *ctx, int which, size_t bytes)
 #ifndef KOFFT_RL_BIG
 #define KOFFT_RL_BIG 5
 #endif
-constexpr int rl_for(int L) { return (L == 5 || L == 6 || L == 9) ? 3 : (L >= 13 ? KOFFT_RL_BIG : 4); }
+// threads per transform >= 8 (c64) / 16 (c32): every load / store instruction covers whole 128-byte lines per transform
+// (A/B on one box: n = 32 c64 0.65 -> 0.79 of the roofline, n = 64 c32 0.64 -> 0.71, n = 128 c32 0.60 -> 0.70.)
+constexpr int rl_for(int L) { return (L == 5 || L == 6) ? 2 : (L == 7 || L == 9) ? 3 : (L >= 13 ? KOFFT_RL_BIG : 4); }
 constexpr int block_for(int L)
 {
     const int tpt = (1 << L) >> rl_for(L);

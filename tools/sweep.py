@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--out", default="gpurun_out/sweep.json")
     ap.add_argument("--kinds", default="c32,c64,rfft32,stft")
     ap.add_argument("--only-n", type=int, default=0, help="restrict every kind to this n")
+    ap.add_argument("--max-n", type=int, default=0, help="skip sizes above this n")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
@@ -58,7 +59,7 @@ def main():
                 esz = 8 if kind == "c32" else 16
                 for L in range(1, 25):
                     n = 1 << L
-                    if args.only_n and n != args.only_n:
+                    if (args.only_n and n != args.only_n) or (args.max_n and n > args.max_n):
                         continue
                     batch = max(1, (args.mb << 20) // (esz * n))
                     src = torch.empty((batch, n, 2), dtype=dt, device=dev).uniform_(-1, 1)
@@ -85,7 +86,7 @@ def main():
                 fft.set_stream(stream.cuda_stream)
                 for L in range(2, 16):
                     n = 1 << L
-                    if args.only_n and n != args.only_n:
+                    if (args.only_n and n != args.only_n) or (args.max_n and n > args.max_n):
                         continue
                     batch = max(1, (args.mb << 20) // (4 * n))
                     src = torch.empty((batch, n), dtype=torch.float32, device=dev).uniform_(-1, 1)
@@ -101,7 +102,7 @@ def main():
                 fft.set_stream(stream.cuda_stream)
                 for L in range(2, 16):
                     n = 1 << L
-                    if args.only_n and n != args.only_n:
+                    if (args.only_n and n != args.only_n) or (args.max_n and n > args.max_n):
                         continue
                     batch = max(1, (args.mb << 20) // (4 * n))
                     src = torch.empty((batch, n // 2 + 1, 2), dtype=torch.float32, device=dev).uniform_(-1, 1)
@@ -118,7 +119,7 @@ def main():
                 sig = torch.empty(total, dtype=torch.float32, device=dev).uniform_(-1, 1)
                 for L in range(5, 15):
                     n = 1 << L
-                    if args.only_n and n != args.only_n:
+                    if (args.only_n and n != args.only_n) or (args.max_n and n > args.max_n):
                         continue
                     hop = n // 4
                     frames = -(-total // hop)
