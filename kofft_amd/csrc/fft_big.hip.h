@@ -71,6 +71,7 @@ struct BigRowsIO {
     int kbase;  // L - 1 - LA
     size_t n;
     T scale;    // 1 / (n as f32 as T), fft.rs:1167
+    bool nt;    // non-temporal stores: only when a workgroup's adjacent rows fill at least 64-byte segments
     __device__ __forceinline__ TwSub tw_map(size_t xf) const { return TwSub{shift, (int)(xf & ((size_t(1) << LA) - 1)), kbase}; }
     __device__ __forceinline__ cpx<T> load(size_t xf, int c) const
     {
@@ -84,7 +85,8 @@ struct BigRowsIO {
             const T im = -v.im;
             v = mk<T>(v.re * scale, im * scale);
         }
-        st_stream(out + b * n + ((size_t)q << LA) + K, v);
+        if (nt) st_stream(out + b * n + ((size_t)q << LA) + K, v);
+        else out[b * n + ((size_t)q << LA) + K] = v;
     }
 };
 

@@ -261,23 +261,21 @@ struct IrfftIO : PlainTw {
     T scale;  // 1 / (m as f32 as T)
     __device__ __forceinline__ cpx<T> load(size_t xf, int k) const
     {
+        // Branch-free: k == 0 reads row[0] and row[m] like every other k reads row[k] and row[m-k]; both forms are
+        // evaluated and one is selected (a per-lane branch here would put a wait between consecutive loads).
         const cpx<T> *row = in + xf * (size_t)(m + 1);
         const T half = T(0.5f);
-        cpx<T> s;
-        if (k == 0) {
-            const T a = row[0].re, b = row[m].re;
-            s = mk<T>((a + b) * half, (a - b) * half);
-        } else {
-            const cpx<T> a = row[k];
-            const cpx<T> rb = row[m - k];
-            const cpx<T> b = mk<T>(rb.re, -rb.im);
-            const cpx<T> sum = cadd(a, b), diff = csub(a, b);
-            const cpx<T> tw = rtab[k];
-            const cpx<T> w = mk<T>(tw.re, -tw.im);
-            const cpx<T> t = cmul(w, diff);
-            const cpx<T> temp = csub(sum, mk<T>(t.im, -t.re));
-            s = mk<T>(temp.re * half, temp.im * half);
-        }
+        const cpx<T> a = ld_stream(row + k);
+        const cpx<T> rb = ld_stream(row + (m - k));
+        const cpx<T> tw = rtab[k];
+        const cpx<T> b = mk<T>(rb.re, -rb.im);
+        const cpx<T> sum = cadd(a, b), diff = csub(a, b);
+        const cpx<T> w = mk<T>(tw.re, -tw.im);
+        const cpx<T> t = cmul(w, diff);
+        const cpx<T> temp = csub(sum, mk<T>(t.im, -t.re));
+        const cpx<T> general = mk<T>(temp.re * half, temp.im * half);                   // rfft.rs:495-503
+        const cpx<T> first = mk<T>((a.re + rb.re) * half, (a.re - rb.re) * half);       // rfft.rs:491-493 (k == 0)
+        cpx<T> s = (k == 0) ? first : general;
         if (m > 1) s.im = -s.im;  // ifft: conj on the way in (fft.rs:1163-1165); n == 1 returns early
         return s;
     }

@@ -314,7 +314,9 @@ int fft_big_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t ba
         BigColsIO<T, INVERSE> a{src, mid, LB, L - LA, n};
         rc = launch_sub<T>(ctx, a, tw, LA, nb << LB);
         if (rc) return rc;
-        BigRowsIO<T, INVERSE> b{mid, dst, LA, LB, L - LB, L - 1 - LA, n, scale};
+        // rows per workgroup of factor B (big_block): short segments are better left to the L2 to merge
+        const int rows_per_wg = LB <= 10 ? 8 : LB == 11 ? 4 : LB == 12 ? 2 : 1;
+        BigRowsIO<T, INVERSE> b{mid, dst, LA, LB, L - LB, L - 1 - LA, n, scale, rows_per_wg * sizeof(cpx<T>) >= 64};
         rc = launch_sub<T>(ctx, b, tw, LB, nb << LA);
         if (rc) return rc;
     }
