@@ -190,6 +190,22 @@ __device__ __forceinline__ void bfly_f32_pk(v2f &e, v2f &o, const v2f w)
     o = d;
 }
 
+// The real-FFT post-pass (rfft.rs:454-463) in packed form, 7 instructions (the compiler's own packing takes 10-11):
+//   b = conj(ymk); sum = a + b; diff = a - b; t = w * diff (Complex::mul, un-fused); X = (sum + (t.im, -t.re)) * 0.5
+// The conjugation and the (t.im, -t.re) swizzle are folded into neg_* / op_sel modifiers, which are exact.
+__device__ __forceinline__ v2f rfft_post_f32_pk(const v2f w, const v2f a, const v2f ymk)
+{
+    v2f s, d, p1, p2, t, x;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,0] neg_hi:[0,1]" : "=v"(s) : "v"(a), "v"(ymk));  // (a.re + y.re, a.im - y.im)
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(d) : "v"(a), "v"(ymk));  // (a.re - y.re, a.im + y.im)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(p1) : "v"(w), "v"(d));  // (w.re*d.re, w.re*d.im)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(p2) : "v"(w), "v"(d));  // (w.im*d.im, w.im*d.re)
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(t) : "v"(p1), "v"(p2));    // (t.re, t.im)
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(x) : "v"(s), "v"(t));  // (s.re + t.im, s.im - t.re)
+    asm("v_pk_mul_f32 %0, %1, 0.5 op_sel_hi:[1,0]" : "=v"(x) : "v"(x));
+    return x;
+}
+
 template <typename T, bool W_UNIFORM = false>
 __device__ __forceinline__ void bfly(cpx<T> &e, cpx<T> &o, const cpx<T> w)
 {

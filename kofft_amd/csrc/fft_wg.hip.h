@@ -239,6 +239,13 @@ struct RfftIO : PlainTw {
     // X[k] for 1 <= k < m from Y[k], Y[m-k] and W[k]  (rfft.rs:454-463)
     __device__ __forceinline__ cpx<T> post_w(cpx<T> w, cpx<T> a, cpx<T> ymk) const
     {
+#ifndef KOFFT_BFLY_NOASM
+        if constexpr (sizeof(T) == 4) {
+            const v2f wv = {w.re, w.im}, av = {a.re, a.im}, yv = {ymk.re, ymk.im};
+            const v2f x = rfft_post_f32_pk(wv, av, yv);
+            return mk<T>(x.x, x.y);
+        }
+#endif
         const T half = T(0.5f);
         const cpx<T> b = mk<T>(ymk.re, -ymk.im);
         const cpx<T> sum = cadd(a, b), diff = csub(a, b);
