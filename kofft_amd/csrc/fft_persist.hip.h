@@ -181,18 +181,32 @@ __device__ __forceinline__ void persist_transform(const typename IO::Raw *raw, c
         persist_lds_scatter<T, L, RL, NP - 1>(cur, ybuf, st.sc);
         exchange_sync<WAVE>();
         if (active) {
-            const rsrc_t od = io.out_desc(xf);
-            const int lane_bytes = tau * (int)sizeof(cpx<T>);
+            // Output rows are (N+1) complex values back to back, so a row starts `a` elements past a 128-byte line.
+            // Lane tau of store g handles k = g*TPT + tau - a: every store instruction then covers whole lines (the
+            // row-contiguous form touches 5 lines per 512-byte store, 2 of them partially; measured +8 % on config 3),
+            // at the price of one extra, mostly empty, store (g = R) that also carries X[N].
+            constexpr int LINE = 128 / (int)sizeof(cpx<T>);
+            constexpr int PSTEP = TPT + TPT / 16;  // lds_pad(k + TPT) - lds_pad(k)
+            const int a = io.row_misalign(xf) & (LINE - 1);
+            const int k0 = tau - a;  // -15 .. TPT-1
+            // descriptor based LINE elements before the row, so that every byte offset below is non-negative
+            const rsrc_t od = io.out_desc_back(xf, LINE);
+            const cpx<T> y0 = ybuf[lds_pad(0)];
+            const cpx<T> *yk = ybuf + (k0 + (k0 >> 4));              // lds_pad(k0 + g*TPT) = lds_pad(k0) + g*PSTEP (also for k0 < 0)
+            const cpx<T> *ynk = ybuf + ((N - k0) + ((N - k0) >> 4));  // lds_pad(N - k0 - g*TPT) = lds_pad(N - k0) - g*PSTEP
+            const cpx<T> *wk = st.rt_lds + k0;
+            const int lane_bytes = (k0 + LINE) * (int)sizeof(cpx<T>);
+            if (k0 >= 0) {  // g = 0: k = k0 (lanes that fall before the row start sit this one out)
+                const cpx<T> p = io.post_w(wk[0], yk[0], ynk[0]);  // k0 == 0 reads cell lds_pad(N): in range, value replaced
+                io.store_d(od, lane_bytes, 0, k0 == 0 ? mk<T>(y0.re + y0.im, T(0)) : p);
+            }
 #pragma unroll
-            for (int g = 0; g < R; ++g) {
-                const int k = tau + g * TPT;
-                if (g == 0 && tau == 0) {
-                    const cpx<T> y0 = ybuf[lds_pad(0)];
-                    io.store_d(od, 0, 0, mk<T>(y0.re + y0.im, T(0)));
-                    io.store_d(od, 0, N, mk<T>(y0.re - y0.im, T(0)));
-                } else {
-                    io.store_d(od, lane_bytes, g * TPT, io.post_w((st.rt_lds + tau)[g * TPT], ybuf[lds_pad(k)], ybuf[lds_pad(N - k)]));
-                }
+            for (int g = 1; g < R; ++g)
+                io.store_d(od, lane_bytes, g * TPT, io.post_w(wk[g * TPT], yk[g * PSTEP], ynk[-g * PSTEP]));
+            if (k0 <= 0) {  // g = R: k = N + k0 <= N; k == N is X[N]
+                const int kr = (k0 < 0) ? N + k0 : N - 1;  // clamped for the LDS reads of the lane that holds X[N]
+                const cpx<T> p = io.post_w(st.rt_lds[kr], ybuf[lds_pad(kr)], ybuf[lds_pad(N - kr)]);
+                io.store_d(od, lane_bytes, R * TPT, k0 == 0 ? mk<T>(y0.re - y0.im, T(0)) : p);
             }
         }
         if (NBUF == 2) exchange_sync<WAVE>();  // ybuf is the next transform's first exchange buffer

@@ -214,6 +214,16 @@ struct RfftIO : PlainTw {
     {
         return make_rsrc(out + xf * (size_t)(m + 1), (unsigned)(m + 1) * sizeof(cpx<T>));
     }
+    // the same row seen from `back` elements earlier (the persistent epilogue never touches those first elements)
+    __device__ __forceinline__ rsrc_t out_desc_back(size_t xf, int back) const
+    {
+        return make_rsrc(out + xf * (size_t)(m + 1) - back, (unsigned)(m + 1 + back) * sizeof(cpx<T>));
+    }
+    // elements between the start of output row xf and the previous 128-byte line boundary (modulo the line)
+    __device__ __forceinline__ int row_misalign(size_t xf) const
+    {
+        return (int)((reinterpret_cast<size_t>(out) / sizeof(cpx<T>) + xf * (size_t)(m + 1)) & 127);
+    }
     __device__ __forceinline__ bool wg_desc_ok(int) const { return true; }
     __device__ __forceinline__ unsigned in_slot_bytes() const { return (unsigned)m * sizeof(cpx<T>); }
     __device__ __forceinline__ rsrc_t in_desc_wg(size_t xf0, size_t batch, int xpb) const
