@@ -88,6 +88,15 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm wheels bundle their own HIP runtime under the same soname (libamdhip64.so.7).  Whichever copy is
+    # loaded first serves the whole process; torch cannot find the GPU through the system copy, while this library is
+    # happy with either.  So when torch is installed it goes first.
+    import sys
+    if "torch" not in sys.modules and not os.environ.get("KOFFT_HIP_NO_TORCH_PRELOAD"):
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     path = Path(os.environ.get("KOFFT_HIP_LIB", LIB_PATH))
     if not path.exists():
         raise LibraryMissing(

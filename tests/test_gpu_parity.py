@@ -621,3 +621,28 @@ def test_inverse_parallel_and_inverse_frame(fft32, oracle):
                 norm[pos + i] += win[i] * win[i]
     output[norm > 1e-8] /= norm[norm > 1e-8]
     assert np.all(np.abs(output - sig) < 1e-4)
+
+
+@pytest.mark.parametrize("n,batch,offset", [(2048, 8300, 1), (2048, 8192, 5), (4096, 4200, 3), (2048, 8192, 16)])
+def test_rfft_streaming_unaligned_output_base(fft32, oracle, n, batch, offset):
+    """The streaming rfft epilogue aligns its stores to 128-byte lines from the ABSOLUTE address of every output row:
+    the result must not depend on where the caller's output buffer starts (here `offset` complex values into a
+    device allocation), and nothing before or after the rows may be touched."""
+    torch = pytest.importorskip("torch")
+    rng = seeded(2100 + n + offset)
+    x = rng.uniform(-1, 1, (batch, n)).astype(np.float32)
+    win = oracle.hann(n)
+    rows = n // 2 + 1
+    guard = 64
+    d_in = torch.from_numpy(x).cuda()
+    d_win = torch.from_numpy(win).cuda()
+    d_out = torch.full((guard + offset + batch * rows + guard, 2), 7.5, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    base = d_out.data_ptr() + 8 * (guard + offset)
+    fft32.rfft_dev(d_in.data_ptr(), base, d_win.data_ptr(), n, batch)
+    fft32.synchronize()
+    torch.cuda.synchronize()
+    h = d_out.cpu().numpy()
+    got = h[guard + offset:guard + offset + batch * rows].copy().view(np.complex64).reshape(batch, rows)
+    assert_parity(got, oracle.rfft(x, win), f"unaligned rfft n={n} offset={offset}", REL_TOL_F32)
+    assert np.all(h[:guard + offset] == 7.5) and np.all(h[guard + offset + batch * rows:] == 7.5)
