@@ -487,30 +487,32 @@ __global__ __launch_bounds__(BLOCK, (IO::kMinWaves > 1 && BLOCK == 512 && L >= 9
         for (int u = 0; u < R; ++u) buf[lds_pad(GL::out_index(tau, u))] = v[u];
         __syncthreads();
         if (active) {
+            // Rows are N+1 values back to back, so row xf starts `a` elements past a 128-byte line.  Lane tau of
+            // store g handles k = g*TPT + tau - a: each store instruction then covers whole lines per row (see the
+            // persistent kernel's epilogue; there: +8 %).  g = 0 and g = R are partial, g = R also carries X[N].
+            constexpr int LINE = 128 / (int)sizeof(cpx<T>);
             cpx<T> *orow = io.out + xf * (size_t)(N + 1);
+            const int k0 = tau - (TPT >= LINE ? (io.row_misalign(xf) & (LINE - 1)) : 0);  // narrower rows: as they come
             // all table entries first, then all results, then all stores: interleaving them makes every store wait
             // for the next table load (the compiler cannot prove the table and the output disjoint)
-            cpx<T> w[R], xo[R];
+            cpx<T> w[R + 1], xo[R + 1];
 #pragma unroll
-            for (int g = 0; g < R; ++g) w[g] = io.rtab[tau + g * TPT];
-#pragma unroll
-            for (int g = 0; g < R; ++g) {
-                const int k = tau + g * TPT;
-                if (g == 0) {
-                    // k == 0 (tau == 0): X[0] here, X[N] below; other lanes: the ordinary post-pass
-                    const cpx<T> y0 = buf[lds_pad(0)];
-                    const cpx<T> p = io.post_w(w[0], buf[lds_pad(k)], buf[lds_pad((N - k) & (N - 1))]);
-                    xo[0] = (k == 0) ? mk<T>(y0.re + y0.im, T(0)) : p;
-                } else {
-                    xo[g] = io.post_w(w[g], buf[lds_pad(k)], buf[lds_pad(N - k)]);
-                }
+            for (int g = 0; g <= R; ++g) {
+                const int k = k0 + g * TPT;
+                w[g] = io.rtab[k < 0 ? 0 : (k > N - 1 ? N - 1 : k)];
             }
+            const cpx<T> y0 = buf[lds_pad(0)];
 #pragma unroll
-            for (int g = 0; g < R; ++g) st_stream(orow + tau + g * TPT, xo[g]);
-            if (tau == 0) {
-                const cpx<T> y0 = buf[lds_pad(0)];
-                st_stream(orow + N, mk<T>(y0.re - y0.im, T(0)));
+            for (int g = 0; g <= R; ++g) {
+                const int k = k0 + g * TPT;
+                const int kc = k < 1 ? 1 : (k > N - 1 ? N - 1 : k);  // LDS addressing only
+                const cpx<T> p = io.post_w(w[g], buf[lds_pad(kc)], buf[lds_pad(N - kc)]);
+                xo[g] = (g == 0 && k == 0) ? mk<T>(y0.re + y0.im, T(0)) : (g == R && k == N) ? mk<T>(y0.re - y0.im, T(0)) : p;
             }
+            if (k0 >= 0) st_stream(orow + k0, xo[0]);
+#pragma unroll
+            for (int g = 1; g < R; ++g) st_stream(orow + k0 + g * TPT, xo[g]);
+            if (k0 <= 0) st_stream(orow + k0 + N, xo[R]);
         }
     } else {
         if (active) {
