@@ -45,14 +45,14 @@ struct BigColsIO {
     __device__ __forceinline__ cpx<T> load(size_t xf, int c) const
     {
         const size_t b = xf >> LB, j = xf & ((size_t(1) << LB) - 1);
-        cpx<T> v = in[b * n + ((size_t)c << LB) + j];
+        cpx<T> v = ld_stream(in + b * n + ((size_t)c << LB) + j);  // read once
         if (INVERSE) v.im = -v.im;  // ifft: conj on the way in (fft.rs:1163-1165)
         return v;
     }
     __device__ __forceinline__ void store(size_t xf, int q, cpx<T> v) const
     {
         const size_t b = xf >> LB, j = xf & ((size_t(1) << LB) - 1);
-        out[b * n + ((size_t)q << LB) + j] = v;
+        out[b * n + ((size_t)q << LB) + j] = v;  // read back by factor B: plain store (non-temporal measured no better)
     }
 };
 
@@ -76,7 +76,7 @@ struct BigRowsIO {
     __device__ __forceinline__ cpx<T> load(size_t xf, int c) const
     {
         const size_t b = xf >> LA, K = xf & ((size_t(1) << LA) - 1);
-        return in[b * n + (K << LB) + (size_t)c];
+        return ld_stream(in + b * n + (K << LB) + (size_t)c);  // the intermediate is read exactly once
     }
     __device__ __forceinline__ void store(size_t xf, int q, cpx<T> v) const
     {
