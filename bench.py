@@ -157,7 +157,7 @@ def main():
         units_per_step = batch * n                      # complex points
         alg_bytes = 16 * units_per_step                 # 8 B read + 8 B written per point
         unit = "GPoints/s"
-        metric = "batched 4096-pt Complex32 forward FFT throughput"
+        metric = "batched 4096-pt c32 FFT throughput, GPoints/s (achieved HBM GB/s: roofline.achieved)"
         launch = lambda: fft.fft_dev_oop(src.data_ptr(), dst.data_ptr(), n, batch, False)  # noqa: E731
         if args.inplace:
             launch = lambda: fft.fft_dev(src.data_ptr(), n, batch, False)  # noqa: E731

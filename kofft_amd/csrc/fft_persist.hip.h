@@ -131,11 +131,12 @@ __device__ __forceinline__ void exchange_sync()
 template <typename T, int L, int RL, int EPI, class IO>
 struct PersistState {
     static constexpr int R = 1 << RL;
-    cpx<T> tw1[R - 1], tw2[R - 1];
+    static constexpr int NP = (L + RL - 1) / RL;
+    cpx<T> tw1[R - 1], tw2[NP >= 3 ? R - 1 : 1], tw3[NP >= 4 ? R - 1 : 1];
     typename IO::Inv inv[IO::kInvInLds ? 1 : R];  // window samples etc. (registers unless the policy stages them in LDS)
     const typename IO::Inv *inv_lds;               // [N], natural order (kInvInLds)
     const cpx<T> *rt_lds;                          // rfft post-pass table W[k], k < N (EPI_RFFT)
-    int g1, g2, sc;  // LDS bases: pass-1 gather, pass-2 gather, scatter
+    int g1, g2, g3, sc;  // LDS bases: gathers of passes 1, 2, 3; scatter
 };
 
 // One transform: raw[] holds its (already landed or still in flight) inputs.
@@ -166,16 +167,24 @@ __device__ __forceinline__ void persist_transform(const typename IO::Raw *raw, c
     exchange_sync<WAVE>();
     persist_lds_gather<T, L, RL, 1>(cur, buf0, st.g1);
     persist_compute<T, L, RL, 1>(cur, st.tw1);
-    if constexpr (NP == 3) {
+    if constexpr (NP >= 3) {
         if (NBUF == 1) exchange_sync<WAVE>();
         persist_lds_scatter<T, L, RL, 1>(cur, buf1, st.sc);
         exchange_sync<WAVE>();
         persist_lds_gather<T, L, RL, 2>(cur, buf1, st.g2);
         persist_compute<T, L, RL, 2>(cur, st.tw2);
     }
+    if constexpr (NP == 4) {  // n = 8192 (NBUF == 1)
+        exchange_sync<WAVE>();
+        persist_lds_scatter<T, L, RL, 2>(cur, buf0, st.sc);
+        exchange_sync<WAVE>();
+        persist_lds_gather<T, L, RL, 3>(cur, buf0, st.g3);
+        persist_compute<T, L, RL, 3>(cur, st.tw3);
+    }
 
     if constexpr (EPI == EPI_RFFT) {
         // rfft.rs:450-463: Y in natural order through LDS, then X[k] from Y[k], Y[m-k]
+        static_assert(NP <= 3, "rfft epilogue: the staged tables do not fit next to an 8192-point exchange buffer");
         cpx<T> *ybuf = (NP == 3) ? buf0 : buf1;  // not the buffer the last gather read from (when NBUF == 2)
         if (NBUF == 1) exchange_sync<WAVE>();
         persist_lds_scatter<T, L, RL, NP - 1>(cur, ybuf, st.sc);
@@ -234,7 +243,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void fft_persist_kernel(const IO io, c
     constexpr int NP = (L + RL - 1) / RL;
     constexpr bool WAVE = (TPT == 64);  // one wavefront per transform
     static_assert(TPT >= 64 && BLOCK % TPT == 0, "persistent kernel: at least one wavefront per transform");
-    static_assert(NP == 2 || NP == 3, "persistent kernel is built for 2 or 3 register passes");
+    static_assert(NP >= 2 && NP <= 4 && (NP < 4 || NBUF == 1), "persistent kernel is built for 2 to 4 register passes");
     static_assert(NBUF == 1 || (NBUF == 2 && !WAVE), "NBUF");
     using FirstG = PassGeom<L, RL, 0>;
     using Raw = typename IO::Raw;
@@ -251,7 +260,8 @@ __global__ __launch_bounds__(BLOCK, MINW) void fft_persist_kernel(const IO io, c
     // ---- per-thread invariants, fetched once
     PersistState<T, L, RL, EPI, IO> st;
     persist_load_tw<T, L, RL, 1>(st.tw1, tau, tw);
-    if constexpr (NP == 3) persist_load_tw<T, L, RL, 2>(st.tw2, tau, tw);
+    if constexpr (NP >= 3) persist_load_tw<T, L, RL, 2>(st.tw2, tau, tw);
+    if constexpr (NP == 4) persist_load_tw<T, L, RL, 3>(st.tw3, tau, tw);
     {
         // transform-independent operands: registers, or (kInvInLds / rfft table) one LDS copy per workgroup
         char *extra = smem_raw + (size_t)XPB * NBUF * lds_elems(N) * sizeof(cpx<T>);
@@ -271,7 +281,8 @@ __global__ __launch_bounds__(BLOCK, MINW) void fft_persist_kernel(const IO io, c
         if constexpr (IO::kInvInLds || EPI == EPI_RFFT) __syncthreads();
     }
     st.g1 = lds_pad(PassGeom<L, RL, 1>::in_index(tau, 0));
-    st.g2 = (NP == 3) ? lds_pad(PassGeom<L, RL, NP - 1>::in_index(tau, 0)) : 0;
+    st.g2 = (NP >= 3) ? lds_pad(PassGeom<L, RL, (NP >= 3 ? 2 : 1)>::in_index(tau, 0)) : 0;
+    st.g3 = (NP == 4) ? lds_pad(PassGeom<L, RL, NP - 1>::in_index(tau, 0)) : 0;
     st.sc = lds_pad(tau);
 
     const size_t step = (size_t)gridDim.x * XPB;

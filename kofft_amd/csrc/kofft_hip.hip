@@ -158,6 +158,7 @@ int launch_wg(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t batch)
 // Waves per SIMD are set per IO policy: the plain complex n = 1024 kernel fits 3 waves/SIMD (156 VGPRs); the STFT
 // and rfft variants carry window / post-pass operands and spill at 168, so they run 2 waves/SIMD.
 template <int L, class IO> struct PersistCfg;
+template <class IO> struct PersistCfg<13, IO> { static constexpr int BLOCK = 512, NBUF = 1, MINW = 2, WG_PER_CU = 1; };
 template <class IO> struct PersistCfg<12, IO> { static constexpr int BLOCK = 256, NBUF = 1, MINW = 2, WG_PER_CU = 2; };
 template <class IO> struct PersistCfg<11, IO> { static constexpr int BLOCK = 256, NBUF = 1, MINW = 2, WG_PER_CU = 2; };
 template <class IO> struct PersistCfg<10, IO> {
@@ -224,6 +225,7 @@ int dispatch(kofft_hip_ctx *ctx, const IO &io, size_t n, size_t batch)
     if constexpr (sizeof(T) == 4 && IO::kStreams) if (ctx->use_persist) {
         // streaming sizes: enough transforms to give every resident workgroup several iterations
         if constexpr (EPI == EPI_STORE) {
+            if (L == 13 && batch >= (size_t)ctx->num_cus * 4) return launch_persist<T, 13, EPI>(ctx, io, tw, batch);
             if (L == 12 && batch >= (size_t)ctx->num_cus * 4) return launch_persist<T, 12, EPI>(ctx, io, tw, batch);
         }
         if (L == 11 && batch >= (size_t)ctx->num_cus * 16) return launch_persist<T, 11, EPI>(ctx, io, tw, batch);

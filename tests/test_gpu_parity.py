@@ -646,3 +646,21 @@ def test_rfft_streaming_unaligned_output_base(fft32, oracle, n, batch, offset):
     got = h[guard + offset:guard + offset + batch * rows].copy().view(np.complex64).reshape(batch, rows)
     assert_parity(got, oracle.rfft(x, win), f"unaligned rfft n={n} offset={offset}", REL_TOL_F32)
     assert np.all(h[:guard + offset] == 7.5) and np.all(h[guard + offset + batch * rows:] == 7.5)
+
+
+@pytest.mark.parametrize("batch", [1024, 1031])
+def test_n8192_streaming_paths(fft32, oracle, batch):
+    """n = 8192 (512 threads per transform, four register passes, one workgroup per CU): complex forward / inverse and
+    STFT with an 8192-sample window on the persistent kernel."""
+    rng = seeded(990 + batch)
+    x = rand_c(rng, (batch, 8192))
+    y = x.copy()
+    fft32.fft_batch(y)
+    assert_parity(y, oracle.fft(x), f"streaming fft c32 n=8192 batch={batch}", REL_TOL_F32)
+    z = x.copy()
+    fft32.fft_batch(z, inverse=True)
+    assert_parity(z, oracle.ifft(x), f"streaming ifft c32 n=8192 batch={batch}", REL_TOL_F32)
+    sig = rng.uniform(-1, 1, 2048 * batch + 77).astype(np.float32)
+    w = oracle.hann(8192)
+    frames = -(-sig.size // 2048)
+    assert_parity(fft32.stft_into(sig, w, 2048, frames), oracle.stft(sig, w, 2048, frames), "streaming stft win=8192", REL_TOL_F32)
