@@ -29,6 +29,7 @@ struct kofft_hip_ctx {
     hipStream_t stream = nullptr;
     int num_cus = 256;
     bool use_persist = true;  // KOFFT_HIP_NO_PERSIST=1 forces the generic kernels (A/B measurements, tests)
+    int persist_grid_pct = 0; // KOFFT_HIP_PERSIST_GRID_PCT: scale the persistent grids (measurements only)
     std::string last_error;
     // planner caches: (kind, n) -> device table.  kind 0/1 = FftPlanner twiddles f32/f64,
     // 2/3 = RfftPlanner post-pass table f32/f64.
@@ -179,6 +180,8 @@ int launch_persist(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t ba
     KOFFT_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     size_t blocks = (size_t)ctx->num_cus * Cfg::WG_PER_CU;
+    if (ctx->persist_grid_pct > 0) blocks = blocks * (size_t)ctx->persist_grid_pct / 100;  // measurement knob
+    if (blocks < 1) blocks = 1;
     const size_t need = (batch + XPB - 1) / XPB;
     if (blocks > need) blocks = need;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Cfg::BLOCK), lds, ctx->stream, io, tw, batch);
@@ -828,6 +831,7 @@ int kofft_hip_create(int device, kofft_hip_ctx **out)
     if (!ctx) return KOFFT_ERR_ALLOC;
     ctx->device = device;
     if (const char *e = getenv("KOFFT_HIP_NO_PERSIST")) ctx->use_persist = !(e[0] == '1');
+    if (const char *e = getenv("KOFFT_HIP_PERSIST_GRID_PCT")) ctx->persist_grid_pct = atoi(e);
     if (const char *e = getenv("KOFFT_HIP_BIG_CHUNK_MB")) {
         const long mb = atol(e);
         if (mb > 0) ctx->big_chunk_bytes = (size_t)mb << 20;
