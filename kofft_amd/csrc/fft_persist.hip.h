@@ -128,23 +128,31 @@ __device__ __forceinline__ void exchange_sync()
 }
 
 // Everything a thread keeps across transforms.
-template <typename T, int L, int RL, int EPI, class IO>
+// CFG (kofft_hip.hip: PersistCfg<L, IO>) carries the per-size, per-policy choices: BLOCK, NBUF, MINW and where the
+// thread-invariant operands live -- kInvInLds (window samples in one LDS copy per workgroup instead of R registers)
+// and kTwLastInLds (the last pass reads its twiddles from an LDS copy of the table instead of holding them in
+// registers): both trade LDS reads for the registers that decide between 2 and 3 waves per SIMD.
+template <typename T, int L, int RL, int EPI, class IO, class CFG>
 struct PersistState {
     static constexpr int R = 1 << RL;
     static constexpr int NP = (L + RL - 1) / RL;
-    cpx<T> tw1[R - 1], tw2[NP >= 3 ? R - 1 : 1], tw3[NP >= 4 ? R - 1 : 1];
-    typename IO::Inv inv[IO::kInvInLds ? 1 : R];  // window samples etc. (registers unless the policy stages them in LDS)
+    static constexpr bool TW2_REG = NP >= 3 && !(CFG::kTwLastInLds && NP == 3);
+    static constexpr bool TW3_REG = NP >= 4 && !CFG::kTwLastInLds;
+    cpx<T> tw1[(NP == 2 && CFG::kTwLastInLds) ? 1 : R - 1], tw2[TW2_REG ? R - 1 : 1], tw3[TW3_REG ? R - 1 : 1];
+    typename IO::Inv inv[CFG::kInvInLds ? 1 : R];  // window samples etc. (registers unless staged in LDS)
     const typename IO::Inv *inv_lds;               // [N], natural order (kInvInLds)
+    const cpx<T> *tw_lds;                          // the whole table T_N, N/2 entries (kTwLastInLds)
     const cpx<T> *rt_lds;                          // rfft post-pass table W[k], k < N (EPI_RFFT)
     int g1, g2, g3, sc;  // LDS bases: gathers of passes 1, 2, 3; scatter
 };
 
 // One transform: raw[] holds its (already landed or still in flight) inputs.
-template <typename T, int L, int RL, int BLOCK, int NBUF, int EPI, class IO>
-__device__ __forceinline__ void persist_transform(const typename IO::Raw *raw, const PersistState<T, L, RL, EPI, IO> &st,
+template <typename T, int L, int RL, int EPI, class CFG, class IO>
+__device__ __forceinline__ void persist_transform(const typename IO::Raw *raw, const PersistState<T, L, RL, EPI, IO, CFG> &st,
                                                   const IO &io, const cpx<T> *__restrict__ tw, cpx<T> *buf0, cpx<T> *buf1,
                                                   const size_t xf, const bool active, const int tau)
 {
+    constexpr int NBUF = CFG::NBUF;
     constexpr int N = 1 << L;
     constexpr int R = 1 << RL;
     constexpr int TPT = N / R;
@@ -157,7 +165,7 @@ __device__ __forceinline__ void persist_transform(const typename IO::Raw *raw, c
 #pragma unroll
     for (int u = 0; u < R; ++u) {
         const int i = FirstG::in_index(0, u) + tau;
-        if constexpr (IO::kInvInLds) cur[u] = io.finish(xf, i, raw[u], (st.inv_lds + tau)[FirstG::in_index(0, u)]);
+        if constexpr (CFG::kInvInLds) cur[u] = io.finish(xf, i, raw[u], (st.inv_lds + tau)[FirstG::in_index(0, u)]);
         else cur[u] = io.finish(xf, i, raw[u], st.inv[u]);
     }
 
@@ -166,20 +174,23 @@ __device__ __forceinline__ void persist_transform(const typename IO::Raw *raw, c
     persist_lds_scatter<T, L, RL, 0>(cur, buf0, st.sc);
     exchange_sync<WAVE>();
     persist_lds_gather<T, L, RL, 1>(cur, buf0, st.g1);
-    persist_compute<T, L, RL, 1>(cur, st.tw1);
+    if constexpr (NP == 2 && CFG::kTwLastInLds) wg_compute<T, L, RL, 1>(cur, io, st.tw_lds, xf, tau);
+    else persist_compute<T, L, RL, 1>(cur, st.tw1);
     if constexpr (NP >= 3) {
         if (NBUF == 1) exchange_sync<WAVE>();
         persist_lds_scatter<T, L, RL, 1>(cur, buf1, st.sc);
         exchange_sync<WAVE>();
         persist_lds_gather<T, L, RL, 2>(cur, buf1, st.g2);
-        persist_compute<T, L, RL, 2>(cur, st.tw2);
+        if constexpr (NP == 3 && CFG::kTwLastInLds) wg_compute<T, L, RL, 2>(cur, io, st.tw_lds, xf, tau);
+        else persist_compute<T, L, RL, 2>(cur, st.tw2);
     }
     if constexpr (NP == 4) {  // n = 8192 (NBUF == 1)
         exchange_sync<WAVE>();
         persist_lds_scatter<T, L, RL, 2>(cur, buf0, st.sc);
         exchange_sync<WAVE>();
         persist_lds_gather<T, L, RL, 3>(cur, buf0, st.g3);
-        persist_compute<T, L, RL, 3>(cur, st.tw3);
+        if constexpr (CFG::kTwLastInLds) wg_compute<T, L, RL, 3>(cur, io, st.tw_lds, xf, tau);
+        else persist_compute<T, L, RL, 3>(cur, st.tw3);
     }
 
     if constexpr (EPI == EPI_RFFT) {
@@ -232,10 +243,11 @@ __device__ __forceinline__ void persist_transform(const typename IO::Raw *raw, c
 // BLOCK threads carry XPB = BLOCK/TPT transforms at a time (TPT = N/16 threads each).
 // NBUF = 1: one LDS exchange buffer per transform slot; NBUF = 2 (block-synchronised sizes): exchanges
 // alternate between two buffers, which halves the number of barriers.
-template <typename T, int L, int RL, int BLOCK, int NBUF, int MINW, int EPI, class IO>
-__global__ __launch_bounds__(BLOCK, MINW) void fft_persist_kernel(const IO io, const cpx<T> *__restrict__ tw,
-                                                                  const size_t batch)
+template <typename T, int L, int RL, int EPI, class IO, class CFG>
+__global__ __launch_bounds__(CFG::BLOCK, CFG::MINW) void fft_persist_kernel(const IO io, const cpx<T> *__restrict__ tw,
+                                                                            const size_t batch)
 {
+    constexpr int BLOCK = CFG::BLOCK, NBUF = CFG::NBUF;
     constexpr int N = 1 << L;
     constexpr int R = 1 << RL;
     constexpr int TPT = N / R;
@@ -258,16 +270,20 @@ __global__ __launch_bounds__(BLOCK, MINW) void fft_persist_kernel(const IO io, c
     cpx<T> *buf1 = (NBUF == 2) ? buf0 + lds_elems(N) : buf0;
 
     // ---- per-thread invariants, fetched once
-    PersistState<T, L, RL, EPI, IO> st;
-    persist_load_tw<T, L, RL, 1>(st.tw1, tau, tw);
-    if constexpr (NP >= 3) persist_load_tw<T, L, RL, 2>(st.tw2, tau, tw);
-    if constexpr (NP == 4) persist_load_tw<T, L, RL, 3>(st.tw3, tau, tw);
+    PersistState<T, L, RL, EPI, IO, CFG> st;
+    using St = PersistState<T, L, RL, EPI, IO, CFG>;
+    if constexpr (!(NP == 2 && CFG::kTwLastInLds)) persist_load_tw<T, L, RL, 1>(st.tw1, tau, tw);
+    if constexpr (St::TW2_REG) persist_load_tw<T, L, RL, 2>(st.tw2, tau, tw);
+    if constexpr (St::TW3_REG) persist_load_tw<T, L, RL, 3>(st.tw3, tau, tw);
     {
         // transform-independent operands: registers, or (kInvInLds / rfft table) one LDS copy per workgroup
         char *extra = smem_raw + (size_t)XPB * NBUF * lds_elems(N) * sizeof(cpx<T>);
         typename IO::Inv *inv_lds = reinterpret_cast<typename IO::Inv *>(extra);
-        cpx<T> *rt_lds = reinterpret_cast<cpx<T> *>(extra + (IO::kInvInLds ? N * sizeof(typename IO::Inv) : 0));
-        if constexpr (IO::kInvInLds) {
+        extra += CFG::kInvInLds ? N * sizeof(typename IO::Inv) : 0;
+        cpx<T> *rt_lds = reinterpret_cast<cpx<T> *>(extra);
+        extra += (EPI == EPI_RFFT) ? N * sizeof(cpx<T>) : 0;
+        cpx<T> *tw_lds = reinterpret_cast<cpx<T> *>(extra);
+        if constexpr (CFG::kInvInLds) {
             for (int i = tid; i < N; i += BLOCK) inv_lds[i] = io.invariant(i);
         } else {
 #pragma unroll
@@ -276,9 +292,13 @@ __global__ __launch_bounds__(BLOCK, MINW) void fft_persist_kernel(const IO io, c
         if constexpr (EPI == EPI_RFFT) {
             for (int i = tid; i < N; i += BLOCK) rt_lds[i] = io.rtab[i];
         }
+        if constexpr (CFG::kTwLastInLds) {
+            for (int i = tid; i < N / 2; i += BLOCK) tw_lds[i] = tw[i];
+        }
         st.inv_lds = inv_lds;
         st.rt_lds = rt_lds;
-        if constexpr (IO::kInvInLds || EPI == EPI_RFFT) __syncthreads();
+        st.tw_lds = tw_lds;
+        if constexpr (CFG::kInvInLds || CFG::kTwLastInLds || EPI == EPI_RFFT) __syncthreads();
     }
     st.g1 = lds_pad(PassGeom<L, RL, 1>::in_index(tau, 0));
     st.g2 = (NP >= 3) ? lds_pad(PassGeom<L, RL, (NP >= 3 ? 2 : 1)>::in_index(tau, 0)) : 0;
@@ -299,38 +319,33 @@ __global__ __launch_bounds__(BLOCK, MINW) void fft_persist_kernel(const IO io, c
         for (int u = 0; u < R; ++u) ra[u] = io.fetch_d(d, in_lane_bytes, FirstG::in_index(0, u));
     }
 
-    for (;;) {
-        {   // ---- transform in A, prefetch into B
-            const size_t nbase = base + step;
-            const bool more = nbase < batch;  // workgroup-uniform
-            {
-                // Unconditional loads through a descriptor that is EMPTY when there is no next transform: the
-                // bounds check then returns zeros without touching memory.  No branch, so the loads carry no
-                // register shuffles behind them and stay in flight until their first use one transform later.
-                const rsrc_t d = io.in_desc(nbase + slot, nbase + slot < batch);
-#pragma unroll
-                for (int u = 0; u < R; ++u) rb[u] = io.fetch_d(d, in_lane_bytes, FirstG::in_index(0, u));
-            }
-            persist_transform<T, L, RL, BLOCK, NBUF, EPI>(ra, st, io, tw, buf0, buf1, base + slot, base + slot < batch, tau);
-            if (!more) break;
-            base = nbase;
-        }
-        {   // ---- transform in B, prefetch into A
-            const size_t nbase = base + step;
-            const bool more = nbase < batch;
-            {
-                // Unconditional loads through a descriptor that is EMPTY when there is no next transform: the
-                // bounds check then returns zeros without touching memory.  No branch, so the loads carry no
-                // register shuffles behind them and stay in flight until their first use one transform later.
-                const rsrc_t d = io.in_desc(nbase + slot, nbase + slot < batch);
-#pragma unroll
-                for (int u = 0; u < R; ++u) ra[u] = io.fetch_d(d, in_lane_bytes, FirstG::in_index(0, u));
-            }
-            persist_transform<T, L, RL, BLOCK, NBUF, EPI>(rb, st, io, tw, buf0, buf1, base + slot, base + slot < batch, tau);
-            if (!more) break;
-            base = nbase;
-        }
+    // One step: issue the NEXT transform's loads into NXT (unconditionally, through a descriptor that is EMPTY when
+    // there is no next transform -- the bounds check then returns zeros without touching memory; no branch, so the
+    // loads carry no register shuffles behind them), then run the transform held in CUR.
+#define KOFFT_PERSIST_STEP(CUR, NXT, LEAVE)                                                                          \
+    {                                                                                                                \
+        const size_t nbase = base + step;                                                                            \
+        const bool more = nbase < batch; /* workgroup-uniform */                                                     \
+        {                                                                                                            \
+            const rsrc_t d = io.in_desc(nbase + slot, nbase + slot < batch);                                         \
+            _Pragma("unroll") for (int u = 0; u < R; ++u) NXT[u] = io.fetch_d(d, in_lane_bytes, FirstG::in_index(0, u)); \
+        }                                                                                                            \
+        __builtin_amdgcn_sched_barrier(0); /* keep the prefetch ahead of CUR's first use */                          \
+        persist_transform<T, L, RL, EPI, CFG>(CUR, st, io, tw, buf0, buf1, base + slot, base + slot < batch, tau);   \
+        if (!more) LEAVE;                                                                                            \
+        base = nbase;                                                                                                \
     }
+    // The first step is peeled off the loop.  s_waitcnt vmcnt counts loads AND stores in issue order, so "CUR has
+    // landed" is vmcnt(32 - i): 16 stores of the previous transform and 16 loads of the next one may stay in flight.
+    // With the first step inside the loop the compiler must merge the entry state (no stores yet) with the back-edge
+    // state and emits vmcnt(15 - i) for both -- which, on the back edge, waits for the previous transform's STORES to
+    // complete, once per two transforms.  After the peel both predecessors of the loop header look the same.
+    KOFFT_PERSIST_STEP(ra, rb, return)
+    for (;;) {
+        KOFFT_PERSIST_STEP(rb, ra, break)
+        KOFFT_PERSIST_STEP(ra, rb, break)
+    }
+#undef KOFFT_PERSIST_STEP
 }
 
 }  // namespace kofft

@@ -158,13 +158,24 @@ int launch_wg(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t batch)
 // loads in flight while it computes.
 // Waves per SIMD are set per IO policy: the plain complex n = 1024 kernel fits 3 waves/SIMD (156 VGPRs); the STFT
 // and rfft variants carry window / post-pass operands and spill at 168, so they run 2 waves/SIMD.
+// kInvInLds / kTwLastInLds: see fft_persist.hip.h (PersistState).
 template <int L, class IO> struct PersistCfg;
-template <class IO> struct PersistCfg<13, IO> { static constexpr int BLOCK = 512, NBUF = 1, MINW = 2, WG_PER_CU = 1; };
-template <class IO> struct PersistCfg<12, IO> { static constexpr int BLOCK = 256, NBUF = 1, MINW = 2, WG_PER_CU = 2; };
-template <class IO> struct PersistCfg<11, IO> { static constexpr int BLOCK = 256, NBUF = 1, MINW = 2, WG_PER_CU = 2; };
-template <class IO> struct PersistCfg<10, IO> {
-    static constexpr int BLOCK = 256, NBUF = 1, MINW = IO::kLeanRegisters ? 3 : 2, WG_PER_CU = MINW;
+template <class IO> struct PersistCfgBase {
+    static constexpr int NBUF = 1;
+    static constexpr bool kInvInLds = IO::kInvInLds, kTwLastInLds = false;
 };
+template <class IO> struct PersistCfg<13, IO> : PersistCfgBase<IO> { static constexpr int BLOCK = 512, MINW = 2, WG_PER_CU = 1; };
+template <class IO> struct PersistCfg<12, IO> : PersistCfgBase<IO> { static constexpr int BLOCK = 256, MINW = 2, WG_PER_CU = 2; };
+template <class IO> struct PersistCfg<11, IO> : PersistCfgBase<IO> { static constexpr int BLOCK = 256, MINW = 2, WG_PER_CU = 2; };
+template <class IO> struct PersistCfg<10, IO> : PersistCfgBase<IO> {
+    static constexpr int BLOCK = 256, MINW = IO::kLeanRegisters ? 3 : 2, WG_PER_CU = MINW;
+};
+#ifdef KOFFT_EXP_STFT_LEAN
+template <> struct PersistCfg<10, StftIO> {
+    static constexpr int BLOCK = 256, NBUF = 1, MINW = 3, WG_PER_CU = 3;
+    static constexpr bool kInvInLds = true, kTwLastInLds = true;
+};
+#endif
 
 template <typename T, int L, int EPI, class IO>
 int launch_persist(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t batch)
@@ -173,10 +184,11 @@ int launch_persist(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t ba
     constexpr int RL = 4;
     constexpr int XPB = Cfg::BLOCK / ((1 << L) >> RL);
     constexpr size_t lds = (size_t)XPB * Cfg::NBUF * lds_elems(1 << L) * sizeof(cpx<T>) +
-                           (IO::kInvInLds ? (size_t)(1 << L) * sizeof(typename IO::Inv) : 0) +
-                           (EPI == EPI_RFFT ? (size_t)(1 << L) * sizeof(cpx<T>) : 0);
+                           (Cfg::kInvInLds ? (size_t)(1 << L) * sizeof(typename IO::Inv) : 0) +
+                           (EPI == EPI_RFFT ? (size_t)(1 << L) * sizeof(cpx<T>) : 0) +
+                           (Cfg::kTwLastInLds ? (size_t)(1 << L) / 2 * sizeof(cpx<T>) : 0);
     static_assert(lds * Cfg::WG_PER_CU <= 160 * 1024, "LDS budget");
-    auto kern = fft_persist_kernel<T, L, RL, Cfg::BLOCK, Cfg::NBUF, Cfg::MINW, EPI, IO>;
+    auto kern = fft_persist_kernel<T, L, RL, EPI, IO, Cfg>;
     KOFFT_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     size_t blocks = (size_t)ctx->num_cus * Cfg::WG_PER_CU;
