@@ -466,4 +466,73 @@ private:
     const HipFftImpl<float> &fft_;
 };
 
+// stft::IstftStream (stft.rs:401-518): streaming overlap-add with normalisation.  push_frame hands the frame to the
+// device (ifft + windowed add into the ring buffer = inverse_frame's arithmetic); the window-square bookkeeping and the
+// "> 1e-8" division of the samples that leave the buffer are host bookkeeping, as in the reference's helper.
+class IstftStream {
+public:
+    static Result create(size_t win_len, size_t hop, std::vector<float> window, const HipFftImpl<float> &fft, IstftStream *&out)
+    {
+        if (hop == 0) return Result::Err(FftError::InvalidHopSize);
+        out = new IstftStream(win_len, hop, std::move(window), fft);
+        return Result::Ok();
+    }
+    // the next `hop` samples of the reconstructed signal
+    Result push_frame(const std::vector<Complex32> &frame_in, std::vector<float> &out)
+    {
+        if (frame_in.size() != win_len_) return Result::Err(FftError::MismatchedLengths);
+        if (window_.size() < win_len_) throw std::out_of_range("window shorter than win_len (the reference panics)");
+        time_buf_ = frame_in;
+        Result r = fft_.st(kofft_hip_istft_frame_f32(fft_.raw(), reinterpret_cast<float *>(time_buf_.data()), window_.data(), win_len_,
+                                                     0, buffer_.data() + buf_pos_, win_len_));
+        if (r.is_err()) return r;
+        for (size_t i = 0; i < win_len_; ++i) norm_buf_[buf_pos_ + i] += window_[i] * window_[i];
+        ++frame_count_;
+        normalise(out_pos_, out_pos_ + hop_, out);
+        out_pos_ += hop_;
+        buf_pos_ += hop_;
+        if (buf_pos_ + win_len_ > buffer_.size()) {
+            buffer_.resize(buf_pos_ + win_len_, 0.0f);
+            norm_buf_.resize(buf_pos_ + win_len_, 0.0f);
+        }
+        for (size_t i = 0; i < hop_; ++i) {
+            buffer_[buf_pos_ + win_len_ - hop_ + i] = 0.0f;
+            norm_buf_[buf_pos_ + win_len_ - hop_ + i] = 0.0f;
+        }
+        return Result::Ok();
+    }
+    // the remaining win_len - hop samples after the last frame (empty before the first frame and on later calls)
+    void flush(std::vector<float> &out)
+    {
+        out.clear();
+        if (frame_count_ == 0) return;
+        const size_t lo = out_pos_, hi = buf_pos_ + win_len_ - hop_;
+        if (lo >= hi) return;
+        normalise(lo, hi, out);
+        out_pos_ = hi;
+    }
+
+private:
+    IstftStream(size_t win_len, size_t hop, std::vector<float> window, const HipFftImpl<float> &fft)
+        : win_len_(win_len), hop_(hop), window_(std::move(window)), fft_(fft), buffer_(win_len + 2 * hop, 0.0f),
+          norm_buf_(win_len + 2 * hop, 0.0f), time_buf_(win_len)
+    {
+    }
+    void normalise(size_t lo, size_t hi, std::vector<float> &out)
+    {
+        out.resize(hi - lo);
+        for (size_t i = lo; i < hi; ++i) {
+            if (norm_buf_[i] > 1e-8f) buffer_[i] /= norm_buf_[i];
+            norm_buf_[i] = 0.0f;
+            out[i - lo] = buffer_[i];
+        }
+    }
+    size_t win_len_, hop_;
+    std::vector<float> window_;
+    const HipFftImpl<float> &fft_;
+    std::vector<float> buffer_, norm_buf_;
+    std::vector<Complex32> time_buf_;
+    size_t buf_pos_ = 0, out_pos_ = 0, frame_count_ = 0;
+};
+
 }  // namespace kofft

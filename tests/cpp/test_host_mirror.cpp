@@ -259,6 +259,35 @@ int main()
         for (auto &c : vol) twos = twos && c.re == 2.0 && c.im == 0.0;
         CHECK(twos);
     }
+    {   // tests/istft_stream.rs:4-52 istft_stream_reconstructs_and_flushes; stft.rs:679-690 frame size mismatch
+        std::vector<float> signal = {1, 2, 3, 4, 5, 6, 7, 8}, window(4, 1.0f);
+        StftStream *ss = nullptr;
+        IstftStream *is = nullptr;
+        CHECK(StftStream::create(signal, window, 2, fft, ss).is_ok());
+        CHECK(IstftStream::create(4, 2, window, fft, is).is_ok());
+        std::vector<Complex32> fr(4);
+        std::vector<std::vector<Complex32>> frames;
+        std::vector<float> stream_out, chunk, tail;
+        bool more = false;
+        while (ss->next_frame(fr, more).is_ok() && more) {
+            frames.push_back(fr);
+            is->push_frame(fr, chunk).unwrap();
+            stream_out.insert(stream_out.end(), chunk.begin(), chunk.end());
+        }
+        is->flush(tail);
+        std::vector<float> offline(signal.size() + 2, 0.0f), scratch(offline.size(), 0.0f);
+        istft(frames, window, 2, offline, scratch, fft).unwrap();
+        CHECK(stream_out.size() == signal.size() && std::memcmp(stream_out.data(), offline.data(), signal.size() * 4) == 0);
+        CHECK(tail.size() == 2 && std::memcmp(tail.data(), &offline[signal.size()], 8) == 0);
+        is->flush(tail);
+        CHECK(tail.empty());
+        std::vector<Complex32> short_frame(3);
+        CHECK(is->push_frame(short_frame, chunk) == Result::Err(FftError::MismatchedLengths));
+        IstftStream *bad = nullptr;
+        CHECK(IstftStream::create(4, 0, window, fft, bad) == Result::Err(FftError::InvalidHopSize));
+        delete ss;
+        delete is;
+    }
     std::printf("%d checks, %d failed\n", g_checks, g_fail);
     return g_fail == 0 ? 0 : 1;
 }

@@ -664,3 +664,44 @@ def test_n8192_streaming_paths(fft32, oracle, batch):
     w = oracle.hann(8192)
     frames = -(-sig.size // 2048)
     assert_parity(fft32.stft_into(sig, w, 2048, frames), oracle.stft(sig, w, 2048, frames), "streaming stft win=8192", REL_TOL_F32)
+
+
+def test_istft_stream_reconstructs_and_flushes(fft32, oracle):
+    """tests/istft_stream.rs:4-52 and stft.rs:679-690, against the mirror's IstftStream."""
+    import kofft_amd as K
+
+    signal = np.arange(1, 9, dtype=np.float32)
+    win_len, hop = 4, 2
+    window = np.ones(win_len, np.float32)
+    sstream = K.StftStream(signal, window, hop, fft32)
+    istream = K.IstftStream(win_len, hop, window, fft32)
+    frame = np.zeros(win_len, np.complex64)
+    frames, out_stream = [], []
+    while sstream.next_frame(frame):
+        frames.append(frame.copy())
+        out_stream.append(istream.push_frame(frame))
+    tail = istream.flush()
+    out_stream = np.concatenate(out_stream + [tail])
+    offline = np.zeros(signal.size + win_len - hop, np.float32)
+    scratch = np.zeros_like(offline)
+    K.istft([f.copy() for f in frames], window, hop, offline, scratch, fft32)
+    assert bits_equal(out_stream[:signal.size], offline[:signal.size])
+    assert tail.size == win_len - hop and bits_equal(tail, offline[signal.size:])
+    assert istream.flush().size == 0                      # subsequent calls return an empty slice
+    assert K.IstftStream(win_len, hop, window, fft32).flush().size == 0   # no frames processed
+    with pytest.raises(K.FftError) as e:
+        istream.push_frame(np.zeros(win_len - 1, np.complex64))          # stft.rs:679-690
+    assert e.value.code == K.FftError.MismatchedLengths
+    with pytest.raises(K.FftError) as e:
+        K.IstftStream(win_len, 0, window, fft32)
+    assert e.value.code == K.FftError.InvalidHopSize
+    # a longer stream with a Hann window: equals the batch istft bit for bit where both are defined
+    rng = seeded(3100)
+    sig = rng.uniform(-1, 1, 2000).astype(np.float32)
+    w = oracle.hann(256)
+    nfr = -(-sig.size // 64)
+    spec = oracle.stft(sig, w, 64, nfr)
+    st2 = K.IstftStream(256, 64, w, fft32)
+    got = np.concatenate([st2.push_frame(spec[i]) for i in range(nfr)] + [st2.flush()])
+    want = oracle.istft(spec.copy(), w, 64, got.size)
+    assert bits_equal(got, want)
