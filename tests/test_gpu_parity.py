@@ -705,3 +705,17 @@ def test_istft_stream_reconstructs_and_flushes(fft32, oracle):
     got = np.concatenate([st2.push_frame(spec[i]) for i in range(nfr)] + [st2.flush()])
     want = oracle.istft(spec.copy(), w, 64, got.size)
     assert bits_equal(got, want)
+
+
+@pytest.mark.parametrize("length,win_len,hop", [(12_000_001, 64, 5_000_000), (70_000, 256, 300), (3000, 1024, 1), (100_000, 16, 7),
+                                                (9_000_000, 2048, 4_500_000)])
+def test_stft_unusual_hops(fft32, oracle, length, win_len, hop):
+    """Hops larger than the window (gaps), hop = 1 (maximal overlap), hops that are not a multiple of anything, and hops
+    beyond the reach of a workgroup's 32-bit buffer offsets (the kernels fall back to per-element addressing there)."""
+    rng = seeded(4000 + win_len + hop % 1000)
+    signal = rng.uniform(-1, 1, length).astype(np.float32)
+    window = oracle.hann(win_len)
+    frames = -(-length // hop)
+    got = fft32.stft_into(signal, window, hop, frames)
+    want = oracle.stft(signal, window, hop, frames)
+    assert_parity(got, want, f"stft len={length} win={win_len} hop={hop}", REL_TOL_F32)
