@@ -1,5 +1,5 @@
 // fft_big.hip.h -- power-of-two transforms too large for one workgroup's LDS (n > 16384 f32 / 8192 f64),
-// e.g. BASELINE config #5: 2^20-point Complex64.
+// e.g. BASELINE config #5: 2^20-point Complex64.  Two factors up to 2^21, three (BigMidIO below) from 2^22.
 //
 // The reference runs L = log2(n) radix-2 Stockham stages over the whole array (fft.rs:834-898).  In index bits,
 // stage s maps [k : s bits][b][j] -> [b'][k][j], so the stages split cleanly into two factors, L = LA + LB:
@@ -87,6 +87,38 @@ struct BigRowsIO {
         }
         if (nt) st_stream(out + b * n + ((size_t)q << LA) + K, v);
         else out[b * n + ((size_t)q << LA) + K] = v;
+    }
+};
+
+// Middle factor of a three-factor split (n >= 2^21): global stages S .. S+LS-1.  The index bits at that point read
+// [K : S bits][c : LS bits][j : JB bits] and the stage group maps them to [q : LS][K : S][j : JB] (same algebra as
+// above with both a frequency prefix K and untouched low bits j).  Unit xf = (b, K, j); adjacent units are adjacent j.
+template <typename T>
+struct BigMidIO {
+    static constexpr bool kStreams = false;
+    static constexpr bool kSlotMinor = true;
+    static constexpr bool kPairXcd = true;
+    static constexpr bool kSplitLds = sizeof(T) == 8;
+    static constexpr int kMinWaves = sizeof(T) == 8 ? 4 : 1;
+    const cpx<T> *__restrict__ in;
+    cpx<T> *__restrict__ out;
+    int S, LS, JB;
+    int shift;  // L - LS
+    int kbase;  // L - 1 - S
+    size_t n;
+    __device__ __forceinline__ TwSub tw_map(size_t xf) const
+    {
+        return TwSub{shift, (int)((xf >> JB) & ((size_t(1) << S) - 1)), kbase};
+    }
+    __device__ __forceinline__ cpx<T> load(size_t xf, int c) const
+    {
+        const size_t b = xf >> (S + JB), K = (xf >> JB) & ((size_t(1) << S) - 1), j = xf & ((size_t(1) << JB) - 1);
+        return ld_stream(in + b * n + (K << (LS + JB)) + ((size_t)c << JB) + j);
+    }
+    __device__ __forceinline__ void store(size_t xf, int q, cpx<T> v) const
+    {
+        const size_t b = xf >> (S + JB), K = (xf >> JB) & ((size_t(1) << S) - 1), j = xf & ((size_t(1) << JB) - 1);
+        out[b * n + ((size_t)q << (S + JB)) + (K << JB) + j] = v;
     }
 };
 

@@ -30,6 +30,7 @@ struct kofft_hip_ctx {
     int num_cus = 256;
     bool use_persist = true;  // KOFFT_HIP_NO_PERSIST=1 forces the generic kernels (A/B measurements, tests)
     int persist_grid_pct = 0; // KOFFT_HIP_PERSIST_GRID_PCT: scale the persistent grids (measurements only)
+    bool big_two_only = false; // KOFFT_HIP_BIG_TWO_FACTORS=1: never split into three factors (A/B measurements)
     std::string last_error;
     // planner caches: (kind, n) -> device table.  kind 0/1 = FftPlanner twiddles f32/f64,
     // 2/3 = RfftPlanner post-pass table f32/f64.
@@ -271,11 +272,16 @@ int dispatch(kofft_hip_ctx *ctx, const IO &io, size_t n, size_t batch)
 // ---------------------------------------------------------------------------------
 template <typename T> constexpr int max_log2_big() { return 26; }
 
+// adjacent columns / rows per workgroup: 128-byte segments (16 x c32, 8 x c64) when the LDS budget allows
+// (measured, c32: 2^15..2^19 0.19 -> 0.225 of the roofline, 2^22..2^24 0.12 -> 0.15)
+#ifndef KOFFT_BIG_XPB
+#define KOFFT_BIG_XPB(T) (sizeof(T) == 4 ? 16 : 8)
+#endif
 template <typename T, class IO, int LS>
 constexpr int big_block()
 {
     const int tpt = (1 << LS) >> rl_for(LS);
-    int xpb = 8;
+    int xpb = KOFFT_BIG_XPB(T);
     while (xpb > 1 && (xpb * tpt > 1024 || (size_t)xpb * (1 << LS) * 8 > 80 * 1024)) xpb /= 2;
     int block = xpb * tpt;
     if (block < 64) block = 64;
@@ -287,8 +293,8 @@ template <typename T, class IO>
 int launch_sub(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, int LS, size_t units)
 {
     switch (LS) {
-    // Eight adjacent columns/rows per workgroup (128-byte segments for c64, 64-byte for c32 -- paired across an XCD)
-    // while two workgroups still fit in a CU's LDS; larger sub-transforms fall back to fewer.
+    // 16 (c32) / 8 (c64) adjacent columns or rows per workgroup = 128-byte segments while the tile fits the LDS budget
+    // (sub-transforms up to 2^9 points; 2^10: 8; larger ones fewer still -- big_block).
 #define KOFFT_CASE(LL) \
     case LL: return launch_wg<T, LL, EPI_STORE, IO, big_block<T, IO, LL>()>(ctx, io, tw, units);
         KOFFT_CASE(7)
@@ -303,11 +309,32 @@ int launch_sub(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, int LS, size_
     }
 }
 
+// Sub-transforms of the middle factor are at most 2^9 points (three factors cover 2^21 .. 2^26 with 7..9 bits each).
+template <typename T>
+int launch_mid(kofft_hip_ctx *ctx, const BigMidIO<T> &io, const cpx<T> *tw, int LS, size_t units)
+{
+    switch (LS) {
+    case 7: return launch_wg<T, 7, EPI_STORE, BigMidIO<T>, big_block<T, BigMidIO<T>, 7>()>(ctx, io, tw, units);
+    case 8: return launch_wg<T, 8, EPI_STORE, BigMidIO<T>, big_block<T, BigMidIO<T>, 8>()>(ctx, io, tw, units);
+    case 9: return launch_wg<T, 9, EPI_STORE, BigMidIO<T>, big_block<T, BigMidIO<T>, 9>()>(ctx, io, tw, units);
+    default: return KOFFT_ERR_UNSUPPORTED;
+    }
+}
+
+template <typename T>
+inline int big_rows_per_wg(int LB) { return LB <= 9 ? KOFFT_BIG_XPB(T) : LB == 10 ? 8 : LB == 11 ? 4 : LB == 12 ? 2 : 1; }
+
 template <typename T, bool INVERSE>
 int fft_big_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t batch)
 {
     const int L = ilog2(n);
-    const int LA = L / 2, LB = L - LA;  // both in 7..13 for L in 15..26
+    // Two factors while both stay <= 2^10 points (tiles of 8 adjacent columns / rows, 64..128-byte segments); from 2^22
+    // on, three factors of 7..9 bits: one more pass over HBM, but every pass keeps full-width tiles (two factors of
+    // 11..13 bits shrink the tiles to 4, 2, 1 columns and fall to 0.05..0.16 of the roofline).
+    const bool three = L >= 22 && !ctx->big_two_only;  // measured crossover (2^21: two factors still ahead)
+    const int L1 = three ? (L + 2) / 3 : L / 2;
+    const int L2 = three ? (L - L1 + 1) / 2 : 0;
+    const int L3 = L - L1 - L2;
     const cpx<T> *tw = nullptr;
     int rc = get_table<T>(ctx, Kind<T>::tw, n, &tw);
     if (rc) return rc;
@@ -315,26 +342,36 @@ int fft_big_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t ba
     size_t chunk = ctx->big_chunk_bytes / xf_bytes;
     if (chunk < 1) chunk = 1;
     if (chunk > batch) chunk = batch;
-    if (ctx->big_tmp_bytes < chunk * xf_bytes) {
+    const size_t need = chunk * xf_bytes * (three ? 2 : 1);
+    if (ctx->big_tmp_bytes < need) {
         if (ctx->big_tmp) KOFFT_HIP_TRY(ctx, hipFree(ctx->big_tmp));
         ctx->big_tmp = nullptr;
         ctx->big_tmp_bytes = 0;
-        KOFFT_HIP_TRY(ctx, hipMalloc(&ctx->big_tmp, chunk * xf_bytes));
-        ctx->big_tmp_bytes = chunk * xf_bytes;
+        KOFFT_HIP_TRY(ctx, hipMalloc(&ctx->big_tmp, need));
+        ctx->big_tmp_bytes = need;
     }
     cpx<T> *mid = static_cast<cpx<T> *>(ctx->big_tmp);
+    cpx<T> *mid2 = mid + chunk * n;
     const T scale = (T)1 / (T)(float)n;
     for (size_t b0 = 0; b0 < batch; b0 += chunk) {
         const size_t nb = (batch - b0 < chunk) ? batch - b0 : chunk;
         const cpx<T> *src = reinterpret_cast<const cpx<T> *>(d_in) + b0 * n;
         cpx<T> *dst = reinterpret_cast<cpx<T> *>(d_out) + b0 * n;
-        BigColsIO<T, INVERSE> a{src, mid, LB, L - LA, n};
-        rc = launch_sub<T>(ctx, a, tw, LA, nb << LB);
+        // first factor: stages 0 .. L1-1 down the columns of a 2^L1 x 2^(L-L1) matrix
+        BigColsIO<T, INVERSE> a{src, mid, L - L1, L - L1, n};
+        rc = launch_sub<T>(ctx, a, tw, L1, nb << (L - L1));
         if (rc) return rc;
-        // rows per workgroup of factor B (big_block): short segments are better left to the L2 to merge
-        const int rows_per_wg = LB <= 10 ? 8 : LB == 11 ? 4 : LB == 12 ? 2 : 1;
-        BigRowsIO<T, INVERSE> b{mid, dst, LA, LB, L - LB, L - 1 - LA, n, scale, rows_per_wg * sizeof(cpx<T>) >= 64};
-        rc = launch_sub<T>(ctx, b, tw, LB, nb << LA);
+        const cpx<T> *last_in = mid;
+        if (three) {
+            BigMidIO<T> m{mid, mid2, L1, L2, L3, L - L2, L - 1 - L1, n};
+            rc = launch_mid<T>(ctx, m, tw, L2, nb << (L - L2));
+            if (rc) return rc;
+            last_in = mid2;
+        }
+        // last factor: the remaining L3 stages along contiguous rows, prefix K of L - L3 bits, output transposed
+        const int LP = L - L3;
+        BigRowsIO<T, INVERSE> b{last_in, dst, LP, L3, L - L3, L - 1 - LP, n, scale, big_rows_per_wg<T>(L3) * sizeof(cpx<T>) >= 64};
+        rc = launch_sub<T>(ctx, b, tw, L3, nb << LP);
         if (rc) return rc;
     }
     return KOFFT_OK;
@@ -844,6 +881,7 @@ int kofft_hip_create(int device, kofft_hip_ctx **out)
     ctx->device = device;
     if (const char *e = getenv("KOFFT_HIP_NO_PERSIST")) ctx->use_persist = !(e[0] == '1');
     if (const char *e = getenv("KOFFT_HIP_PERSIST_GRID_PCT")) ctx->persist_grid_pct = atoi(e);
+    if (const char *e = getenv("KOFFT_HIP_BIG_TWO_FACTORS")) ctx->big_two_only = (e[0] == '1');
     if (const char *e = getenv("KOFFT_HIP_BIG_CHUNK_MB")) {
         const long mb = atol(e);
         if (mb > 0) ctx->big_chunk_bytes = (size_t)mb << 20;

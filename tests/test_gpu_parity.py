@@ -377,9 +377,10 @@ def test_stft_1024_streaming_path(fft32, oracle, length, hop):
 
 
 # ---- large n: two-factor path (fft_big.hip.h) ------------------------------------------------------------------
-@pytest.mark.parametrize("log2n,batch", [(15, 3), (16, 2), (17, 2), (20, 2)])
+@pytest.mark.parametrize("log2n,batch", [(15, 3), (16, 2), (17, 2), (20, 2), (21, 2), (22, 1), (23, 3), (24, 1)])
 def test_fft_c32_large_n(fft32, oracle, log2n, batch):
-    """n > 16384 runs as two factors over HBM with the ONE reference table T_n; still the reference's butterflies."""
+    """n > 16384 runs as two (from 2^21: three) factors over HBM with the ONE reference table T_n; still the reference's
+    butterflies.  21..24 cover the three-factor splits 7+7+7, 8+7+7, 8+8+7 and 8+8+8."""
     n = 1 << log2n
     rng = seeded(1100 + log2n)
     x = rand_c(rng, (batch, n))
@@ -391,7 +392,7 @@ def test_fft_c32_large_n(fft32, oracle, log2n, batch):
     assert_parity(y, oracle.ifft(want), f"large ifft c32 n=2^{log2n}", REL_TOL_F32)
 
 
-@pytest.mark.parametrize("log2n,batch", [(14, 3), (15, 2), (18, 2), (20, 3)])
+@pytest.mark.parametrize("log2n,batch", [(14, 3), (15, 2), (18, 2), (20, 3), (21, 1), (22, 2)])
 def test_fft_c64_large_n(fft64, oracle, log2n, batch):
     """BASELINE config #5's transform (2^20-point Complex64) and smaller two-factor sizes, bit for bit."""
     n = 1 << log2n
