@@ -162,7 +162,7 @@ int launch_wg(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t batch)
 // kInvInLds / kTwLastInLds: see fft_persist.hip.h (PersistState).
 template <int L, class IO> struct PersistCfg;
 template <class IO> struct PersistCfgBase {
-    static constexpr int NBUF = 1;
+    static constexpr int NBUF = 1, RL = 4;
     static constexpr bool kInvInLds = IO::kInvInLds, kTwLastInLds = false;
 };
 template <class IO> struct PersistCfg<13, IO> : PersistCfgBase<IO> { static constexpr int BLOCK = 512, MINW = 2, WG_PER_CU = 1; };
@@ -171,18 +171,17 @@ template <class IO> struct PersistCfg<11, IO> : PersistCfgBase<IO> { static cons
 template <class IO> struct PersistCfg<10, IO> : PersistCfgBase<IO> {
     static constexpr int BLOCK = 256, MINW = IO::kLeanRegisters ? 3 : 2, WG_PER_CU = MINW;
 };
-#ifdef KOFFT_EXP_STFT_LEAN
-template <> struct PersistCfg<10, StftIO> {
-    static constexpr int BLOCK = 256, NBUF = 1, MINW = 3, WG_PER_CU = 3;
-    static constexpr bool kInvInLds = true, kTwLastInLds = true;
+// n = 512: 8 points per thread so that a transform is still one wavefront (three passes of three stages)
+template <class IO> struct PersistCfg<9, IO> {
+    static constexpr int BLOCK = 256, NBUF = 1, RL = 3, MINW = 4, WG_PER_CU = 4;
+    static constexpr bool kInvInLds = IO::kInvInLds, kTwLastInLds = false;
 };
-#endif
 
 template <typename T, int L, int EPI, class IO>
 int launch_persist(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t batch)
 {
     using Cfg = PersistCfg<L, IO>;
-    constexpr int RL = 4;
+    constexpr int RL = Cfg::RL;
     constexpr int XPB = Cfg::BLOCK / ((1 << L) >> RL);
     constexpr size_t lds = (size_t)XPB * Cfg::NBUF * lds_elems(1 << L) * sizeof(cpx<T>) +
                            (Cfg::kInvInLds ? (size_t)(1 << L) * sizeof(typename IO::Inv) : 0) +
@@ -246,6 +245,7 @@ int dispatch(kofft_hip_ctx *ctx, const IO &io, size_t n, size_t batch)
         }
         if (L == 11 && batch >= (size_t)ctx->num_cus * 16) return launch_persist<T, 11, EPI>(ctx, io, tw, batch);
         if (L == 10 && batch >= (size_t)ctx->num_cus * 32) return launch_persist<T, 10, EPI>(ctx, io, tw, batch);
+        if (L == 9 && batch >= (size_t)ctx->num_cus * 64) return launch_persist<T, 9, EPI>(ctx, io, tw, batch);
     }
     switch (L) {
 #define KOFFT_CASE(LL) \

@@ -720,3 +720,25 @@ def test_stft_unusual_hops(fft32, oracle, length, win_len, hop):
     got = fft32.stft_into(signal, window, hop, frames)
     want = oracle.stft(signal, window, hop, frames)
     assert_parity(got, want, f"stft len={length} win={win_len} hop={hop}", REL_TOL_F32)
+
+
+@pytest.mark.parametrize("batch", [16384, 16391])
+def test_n512_streaming_paths(fft32, oracle, batch):
+    """n = 512 on the persistent kernel (8 points per thread, one wavefront per transform, three passes of three
+    stages): complex forward / inverse, rfft 1024 (+ window, aligned epilogue with 8 registers) and STFT 512."""
+    rng = seeded(970 + batch)
+    x = rand_c(rng, (batch, 512))
+    y = x.copy()
+    fft32.fft_batch(y)
+    assert_parity(y, oracle.fft(x), f"streaming fft c32 n=512 batch={batch}", REL_TOL_F32)
+    z = x.copy()
+    fft32.fft_batch(z, inverse=True)
+    assert_parity(z, oracle.ifft(x), f"streaming ifft c32 n=512 batch={batch}", REL_TOL_F32)
+    r = rng.uniform(-1, 1, (batch, 1024)).astype(np.float32)
+    win = oracle.hann(1024)
+    assert_parity(fft32.rfft_batch(r, win), oracle.rfft(r, win), f"streaming rfft n=1024 batch={batch}", REL_TOL_F32)
+    assert_parity(fft32.rfft_batch(r), oracle.rfft(r, None), f"streaming rfft n=1024 (no window) batch={batch}", REL_TOL_F32)
+    sig = rng.uniform(-1, 1, 128 * batch + 33).astype(np.float32)
+    w2 = oracle.hann(512)
+    frames = -(-sig.size // 128)
+    assert_parity(fft32.stft_into(sig, w2, 128, frames), oracle.stft(sig, w2, 128, frames), "streaming stft win=512", REL_TOL_F32)
