@@ -195,7 +195,7 @@ __device__ __forceinline__ void persist_transform(const typename IO::Raw *raw, c
 
     if constexpr (EPI == EPI_RFFT) {
         // rfft.rs:450-463: Y in natural order through LDS, then X[k] from Y[k], Y[m-k]
-        static_assert(NP <= 3, "rfft epilogue: the staged tables do not fit next to an 8192-point exchange buffer");
+        static_assert(L <= 12, "rfft epilogue: the staged tables do not fit next to an 8192-point exchange buffer");
         cpx<T> *ybuf = (NP == 3) ? buf0 : buf1;  // not the buffer the last gather read from (when NBUF == 2)
         if (NBUF == 1) exchange_sync<WAVE>();
         persist_lds_scatter<T, L, RL, NP - 1>(cur, ybuf, st.sc);
