@@ -32,6 +32,7 @@ namespace kofft {
 template <typename T, bool INVERSE>
 struct BigColsIO {
     static constexpr bool kStreams = false;
+    static constexpr bool kPersist = false;
     static constexpr bool kSlotMinor = true;
     static constexpr bool kPairXcd = true;
     static constexpr bool kSplitLds = sizeof(T) == 8;  // c64: 8-byte exchange elements (re / im in two rounds), 8-column tiles fit twice per CU
@@ -60,6 +61,7 @@ struct BigColsIO {
 template <typename T, bool INVERSE>
 struct BigRowsIO {
     static constexpr bool kStreams = false;
+    static constexpr bool kPersist = false;
     static constexpr bool kSlotMinor = true;  // lanes run over adjacent rows K: 64-byte segments for loads and stores
     static constexpr bool kPairXcd = true;
     static constexpr bool kSplitLds = sizeof(T) == 8;
@@ -96,6 +98,7 @@ struct BigRowsIO {
 template <typename T>
 struct BigMidIO {
     static constexpr bool kStreams = false;
+    static constexpr bool kPersist = false;
     static constexpr bool kSlotMinor = true;
     static constexpr bool kPairXcd = true;
     static constexpr bool kSplitLds = sizeof(T) == 8;
@@ -129,6 +132,7 @@ struct BigMidIO {
 template <typename T, bool INVERSE>
 struct StridedIO {
     static constexpr bool kStreams = false;
+    static constexpr bool kPersist = false;
     static constexpr bool kSlotMinor = true;
     static constexpr bool kPairXcd = false;
     static constexpr bool kSplitLds = sizeof(T) == 8;

@@ -31,13 +31,15 @@ struct PlainTw {
     static constexpr bool kPairXcd = false;
     static constexpr bool kSplitLds = false;
     static constexpr int kMinWaves = 1;  // __launch_bounds__ second argument (waves per SIMD the kernel must fit)
+    static constexpr int kPersistMaxLog2 = 13;  // largest transform the persistent kernel is built for with this policy
     __device__ __forceinline__ TwPlain tw_map(size_t) const { return {}; }
 };
 
 // FftImpl::fft (fft.rs:1054) / ifft (fft.rs:1134-1174: conj, fft, conj, *scale).
 template <typename T, bool INVERSE>
 struct ComplexIO : PlainTw {
-    static constexpr bool kStreams = true;  // cheap load/store: eligible for the persistent prefetching kernel
+    static constexpr bool kStreams = true;  // descriptor loads in the generic kernels
+    static constexpr bool kPersist = true;  // eligible for the persistent prefetching kernel
     static constexpr bool kInvInLds = false;
     static constexpr bool kLeanRegisters = true;
     using Raw = cpx<T>;
@@ -97,6 +99,7 @@ struct ComplexIO : PlainTw {
 // stft.rs:91-103: frame f starts at start0 + f*hop; x = signal[start+i]*window[i] or 0.
 struct StftIO : PlainTw {
     static constexpr bool kStreams = true;
+    static constexpr bool kPersist = true;
     static constexpr bool kInvInLds = false;  // 16 window samples per thread: registers (LDS staging + 3 waves/SIMD measured slower)
     static constexpr bool kLeanRegisters = false;
     using Raw = float;
@@ -192,6 +195,7 @@ __global__ __launch_bounds__(256) void max_nonneg_kernel(const float *__restrict
 template <typename T>
 struct RfftIO : PlainTw {
     static constexpr bool kStreams = true;
+    static constexpr bool kPersist = true;
     static constexpr bool kInvInLds = true;  // window pairs + post-pass table: staged in LDS once per workgroup
     static constexpr bool kLeanRegisters = false;
     using Raw = cpx<T>;
@@ -270,21 +274,48 @@ struct RfftIO : PlainTw {
 // (conj, fft, conj, *1/m); output[2i], output[2i+1] = scratch[i].re, .im.
 template <typename T>
 struct IrfftIO : PlainTw {
-    static constexpr bool kStreams = false;  // two loads + a table entry per element: too many live registers to prefetch
+    static constexpr bool kStreams = false;  // generic kernels: per-element loads (two row elements + a table entry each)
+    static constexpr bool kPersist = sizeof(T) == 4;  // persistent kernel: both row elements prefetched, table in LDS
+    static constexpr int kPersistMaxLog2 = 11;        // 64 prefetch registers per thread: up to m = 2048
+    static constexpr bool kInvInLds = true;
+    static constexpr bool kLeanRegisters = false;
+    struct Raw { cpx<T> a, rb; };  // input[k], input[m-k]
+    using Inv = cpx<T>;            // W[k] of build_twiddle_table(m)
     const cpx<T> *__restrict__ in;  // batch rows of m+1 complex
     cpx<T> *__restrict__ out;       // batch rows of m complex == 2*m reals
     const cpx<T> *__restrict__ rtab;
     int m;
     T scale;  // 1 / (m as f32 as T)
-    __device__ __forceinline__ cpx<T> load(size_t xf, int k) const
+    int tpt;  // threads per transform of the persistent launch (reversed lane index for input[m-k])
+    // ---- descriptor forms (persistent kernel)
+    static constexpr int kRawBytes = sizeof(cpx<T>);
+    __device__ __forceinline__ rsrc_t in_desc(size_t xf, bool valid) const
     {
-        // Branch-free: k == 0 reads row[0] and row[m] like every other k reads row[k] and row[m-k]; both forms are
-        // evaluated and one is selected (a per-lane branch here would put a wait between consecutive loads).
-        const cpx<T> *row = in + xf * (size_t)(m + 1);
+        return make_rsrc(in + (valid ? xf : 0) * (size_t)(m + 1), valid ? (unsigned)(m + 1) * sizeof(cpx<T>) : 0u);
+    }
+    __device__ __forceinline__ rsrc_t out_desc(size_t xf) const { return make_rsrc(out + xf * (size_t)m, (unsigned)m * sizeof(cpx<T>)); }
+    __device__ __forceinline__ Raw fetch_d(rsrc_t d, int lane_bytes, int iu) const
+    {
+        // k = iu + tau; m - k = (m - iu - tpt + 1) + (tpt - 1 - tau): a non-negative constant plus the reversed lane
+        Raw r;
+        r.a = buf_load_cpx<T, AUX_NT>(d, lane_bytes, iu * (int)sizeof(cpx<T>));
+        r.rb = buf_load_cpx<T, AUX_NT>(d, (tpt - 1) * (int)sizeof(cpx<T>) - lane_bytes, (m - iu - tpt + 1) * (int)sizeof(cpx<T>));
+        return r;
+    }
+    __device__ __forceinline__ void store_d(rsrc_t d, int lane_bytes, int ou, cpx<T> v) const
+    {
+        if (m > 1) {
+            const T im = -v.im;
+            v = mk<T>(v.re * scale, im * scale);
+        }
+        buf_store_cpx<T>(v, d, lane_bytes, ou * (int)sizeof(cpx<T>));
+    }
+    __device__ __forceinline__ Inv invariant(int k) const { return rtab[k]; }
+    __device__ __forceinline__ cpx<T> finish(size_t, int k, Raw r, Inv tw) const { return pre(k, r.a, r.rb, tw); }
+    // scratch[k] of irfft_direct (rfft.rs:487-506) from input[k], input[m-k], W[k]; then ifft's conj on the way in
+    __device__ __forceinline__ cpx<T> pre(int k, cpx<T> a, cpx<T> rb, cpx<T> tw) const
+    {
         const T half = T(0.5f);
-        const cpx<T> a = ld_stream(row + k);
-        const cpx<T> rb = ld_stream(row + (m - k));
-        const cpx<T> tw = rtab[k];
         const cpx<T> b = mk<T>(rb.re, -rb.im);
         const cpx<T> sum = cadd(a, b), diff = csub(a, b);
         const cpx<T> w = mk<T>(tw.re, -tw.im);
@@ -295,6 +326,13 @@ struct IrfftIO : PlainTw {
         cpx<T> s = (k == 0) ? first : general;
         if (m > 1) s.im = -s.im;  // ifft: conj on the way in (fft.rs:1163-1165); n == 1 returns early
         return s;
+    }
+    __device__ __forceinline__ cpx<T> load(size_t xf, int k) const
+    {
+        // Branch-free: k == 0 reads row[0] and row[m] like every other k reads row[k] and row[m-k]; both forms are
+        // evaluated and one is selected (a per-lane branch here would put a wait between consecutive loads).
+        const cpx<T> *row = in + xf * (size_t)(m + 1);
+        return pre(k, ld_stream(row + k), ld_stream(row + (m - k)), rtab[k]);
     }
     __device__ __forceinline__ void store(size_t xf, int o, cpx<T> v) const
     {

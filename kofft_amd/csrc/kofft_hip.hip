@@ -171,6 +171,15 @@ template <class IO> struct PersistCfg<11, IO> : PersistCfgBase<IO> { static cons
 template <class IO> struct PersistCfg<10, IO> : PersistCfgBase<IO> {
     static constexpr int BLOCK = 256, MINW = IO::kLeanRegisters ? 3 : 2, WG_PER_CU = MINW;
 };
+// irfft prefetches two row elements per output: the last pass reads its twiddles from LDS to stay inside 256 VGPRs
+template <> struct PersistCfg<10, IrfftIO<float>> {
+    static constexpr int BLOCK = 256, NBUF = 1, RL = 4, MINW = 2, WG_PER_CU = 2;
+    static constexpr bool kInvInLds = true, kTwLastInLds = true;
+};
+template <> struct PersistCfg<11, IrfftIO<float>> {
+    static constexpr int BLOCK = 256, NBUF = 1, RL = 4, MINW = 2, WG_PER_CU = 2;
+    static constexpr bool kInvInLds = true, kTwLastInLds = true;
+};
 // n = 512: 8 points per thread so that a transform is still one wavefront (three passes of three stages)
 template <class IO> struct PersistCfg<9, IO> {
     static constexpr int BLOCK = 256, NBUF = 1, RL = 3, MINW = 4, WG_PER_CU = 4;
@@ -237,9 +246,9 @@ int dispatch(kofft_hip_ctx *ctx, const IO &io, size_t n, size_t batch)
     if (rc) return rc;
     // n = 32 in f32: still one thread per transform (64 data registers), IO staged through LDS like the small sizes
     if constexpr (sizeof(T) == 4 && !IO::kSlotMinor) if (L == 5) return launch_small<T, 32, EPI>(ctx, io, batch, tw);
-    if constexpr (sizeof(T) == 4 && IO::kStreams) if (ctx->use_persist) {
+    if constexpr (sizeof(T) == 4 && IO::kPersist) if (ctx->use_persist) {
         // streaming sizes: enough transforms to give every resident workgroup several iterations
-        if constexpr (EPI == EPI_STORE) {
+        if constexpr (EPI == EPI_STORE && IO::kPersistMaxLog2 >= 13) {
             if (L == 13 && batch >= (size_t)ctx->num_cus * 4) return launch_persist<T, 13, EPI>(ctx, io, tw, batch);
             if (L == 12 && batch >= (size_t)ctx->num_cus * 4) return launch_persist<T, 12, EPI>(ctx, io, tw, batch);
         }
@@ -557,8 +566,10 @@ int irfft_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t batc
     const cpx<T> *rtab = nullptr;
     int rc = get_table<T>(ctx, Kind<T>::rt, m, &rtab);
     if (rc) return rc;
+    // threads per transform of the persistent kernels (m/16; m/8 at m = 512)
+    const int tpt = (int)(m == 512 ? m / 8 : m / 16);
     IrfftIO<T> io{{}, reinterpret_cast<const cpx<T> *>(d_in), reinterpret_cast<cpx<T> *>(d_out), rtab, (int)m,
-                  (T)1 / (T)(float)m};
+                  (T)1 / (T)(float)m, tpt};
     return dispatch<T, EPI_STORE>(ctx, io, m, batch);
 }
 

@@ -742,3 +742,20 @@ def test_n512_streaming_paths(fft32, oracle, batch):
     w2 = oracle.hann(512)
     frames = -(-sig.size // 128)
     assert_parity(fft32.stft_into(sig, w2, 128, frames), oracle.stft(sig, w2, 128, frames), "streaming stft win=512", REL_TOL_F32)
+
+
+@pytest.mark.parametrize("n,batch", [(1024, 16390), (2048, 8200), (4096, 4101)])
+def test_irfft_streaming_paths(fft32, oracle, n, batch):
+    """irfft on the persistent kernel: input[k] and input[m-k] both prefetched through the row's descriptor (the second
+    with a reversed lane index), the W table in LDS, k = 0 selected branch-free; rows are (m+1)*8 bytes, 8-byte aligned."""
+    rng = seeded(5000 + n)
+    spec = rand_c(rng, (batch, n // 2 + 1))
+    spec[:, 0].imag = 0
+    spec[:, -1].imag = 0
+    got = fft32.irfft_batch(spec, n)
+    want = oracle.irfft(spec, n)
+    assert_parity(got, want, f"streaming irfft n={n} batch={batch}", REL_TOL_F32)
+    # Hermitian-consistent input round-trips through rfft within the table drift
+    x = rng.uniform(-1, 1, (64, n)).astype(np.float32)
+    back = fft32.irfft_batch(fft32.rfft_batch(x), n)
+    assert np.max(np.abs(back - x)) < 5e-4
