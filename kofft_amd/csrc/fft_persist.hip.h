@@ -150,14 +150,17 @@ struct PersistState {
 template <typename T, int L, int RL, int EPI, class CFG, class IO>
 __device__ __forceinline__ void persist_transform(const typename IO::Raw *raw, const PersistState<T, L, RL, EPI, IO, CFG> &st,
                                                   const IO &io, const cpx<T> *__restrict__ tw, cpx<T> *buf0, cpx<T> *buf1,
-                                                  const size_t xf, const bool active, const int tau)
+                                                  const size_t xf0, const int cnt, const int sub, const int tau)
 {
+    // The wavefront's group: cnt (0 .. G) valid transforms starting at xf0; this lane belongs to number `sub`.
     constexpr int NBUF = CFG::NBUF;
     constexpr int N = 1 << L;
     constexpr int R = 1 << RL;
     constexpr int TPT = N / R;
     constexpr int NP = (L + RL - 1) / RL;
-    constexpr bool WAVE = (TPT == 64);
+    constexpr bool WAVE = (TPT <= 64);
+    const size_t xf = xf0 + sub;
+    const bool active = sub < cnt;
     using LastG = PassGeom<L, RL, NP - 1>;
     using FirstG = PassGeom<L, RL, 0>;
 
@@ -210,7 +213,8 @@ __device__ __forceinline__ void persist_transform(const typename IO::Raw *raw, c
             const int a = io.row_misalign(xf) & (LINE - 1);
             const int k0 = tau - a;  // -15 .. TPT-1
             // descriptor based LINE elements before the row, so that every byte offset below is non-negative
-            const rsrc_t od = io.out_desc_back(xf, LINE);
+            const rsrc_t od = io.out_desc_back_n(xf0, cnt, LINE);
+            const int row_off = sub * (int)io.out_row_bytes();
             const cpx<T> y0 = ybuf[lds_pad(0)];
             const cpx<T> *yk = ybuf + (k0 + (k0 >> 4));              // lds_pad(k0 + g*TPT) = lds_pad(k0) + g*PSTEP (also for k0 < 0)
             const cpx<T> *ynk = ybuf + ((N - k0) + ((N - k0) >> 4));  // lds_pad(N - k0 - g*TPT) = lds_pad(N - k0) - g*PSTEP
@@ -218,24 +222,25 @@ __device__ __forceinline__ void persist_transform(const typename IO::Raw *raw, c
             const int lane_bytes = (k0 + LINE) * (int)sizeof(cpx<T>);
             if (k0 >= 0) {  // g = 0: k = k0 (lanes that fall before the row start sit this one out)
                 const cpx<T> p = io.post_w(wk[0], yk[0], ynk[0]);  // k0 == 0 reads cell lds_pad(N): in range, value replaced
-                io.store_d(od, lane_bytes, 0, k0 == 0 ? mk<T>(y0.re + y0.im, T(0)) : p);
+                io.store_d(od, lane_bytes, 0, k0 == 0 ? mk<T>(y0.re + y0.im, T(0)) : p, row_off);
             }
 #pragma unroll
             for (int g = 1; g < R; ++g)
-                io.store_d(od, lane_bytes, g * TPT, io.post_w(wk[g * TPT], yk[g * PSTEP], ynk[-g * PSTEP]));
+                io.store_d(od, lane_bytes, g * TPT, io.post_w(wk[g * TPT], yk[g * PSTEP], ynk[-g * PSTEP]), row_off);
             if (k0 <= 0) {  // g = R: k = N + k0 <= N; k == N is X[N]
                 const int kr = (k0 < 0) ? N + k0 : N - 1;  // clamped for the LDS reads of the lane that holds X[N]
                 const cpx<T> p = io.post_w(st.rt_lds[kr], ybuf[lds_pad(kr)], ybuf[lds_pad(N - kr)]);
-                io.store_d(od, lane_bytes, R * TPT, k0 == 0 ? mk<T>(y0.re - y0.im, T(0)) : p);
+                io.store_d(od, lane_bytes, R * TPT, k0 == 0 ? mk<T>(y0.re - y0.im, T(0)) : p, row_off);
             }
         }
         if (NBUF == 2) exchange_sync<WAVE>();  // ybuf is the next transform's first exchange buffer
     } else {
         if (active) {
-            const rsrc_t od = io.out_desc(xf);
+            const rsrc_t od = io.out_desc_n(xf0, cnt);
             const int lane_bytes = tau * (int)sizeof(cpx<T>);
+            const int row_off = sub * (int)io.out_row_bytes();
 #pragma unroll
-            for (int u = 0; u < R; ++u) io.store_d(od, lane_bytes, LastG::out_index(0, u), cur[u]);
+            for (int u = 0; u < R; ++u) io.store_d(od, lane_bytes, LastG::out_index(0, u), cur[u], row_off);
         }
     }
 }
@@ -253,8 +258,9 @@ __global__ __launch_bounds__(CFG::BLOCK, CFG::MINW) void fft_persist_kernel(cons
     constexpr int TPT = N / R;
     constexpr int XPB = BLOCK / TPT;
     constexpr int NP = (L + RL - 1) / RL;
-    constexpr bool WAVE = (TPT == 64);  // one wavefront per transform
-    static_assert(TPT >= 64 && BLOCK % TPT == 0, "persistent kernel: at least one wavefront per transform");
+    constexpr bool WAVE = (TPT <= 64);          // a transform lives inside one wavefront: wave-synchronous exchanges
+    constexpr int G = TPT >= 64 ? 1 : 64 / TPT;  // transforms per wavefront
+    static_assert(TPT >= 16 && (TPT >= 64 ? TPT % 64 == 0 : 64 % TPT == 0) && BLOCK % 64 == 0 && BLOCK % TPT == 0, "geometry");
     static_assert(NP >= 2 && NP <= 4 && (NP < 4 || NBUF == 1), "persistent kernel is built for 2 to 4 register passes");
     static_assert(NBUF == 1 || (NBUF == 2 && !WAVE), "NBUF");
     using FirstG = PassGeom<L, RL, 0>;
@@ -263,9 +269,12 @@ __global__ __launch_bounds__(CFG::BLOCK, CFG::MINW) void fft_persist_kernel(cons
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int tid = threadIdx.x;
     const int tau = tid % TPT;
-    // TPT is a multiple of the wavefront size, so the slot is wave-uniform: keep it in an SGPR so that the
-    // "is this transform inside the batch" tests below are scalar branches around whole groups of loads.
-    const int slot = __builtin_amdgcn_readfirstlane(tid / TPT);
+    // Transforms of at least a wavefront: the slot is wave-uniform (SGPR).  Smaller ones: a wavefront carries G
+    // consecutive transforms (rows adjacent in memory), addressed through ONE descriptor over the group plus a per-lane
+    // row offset; `wslot` is the group's first slot (uniform), `sub` this lane's transform inside the group.
+    const int sub = (G == 1) ? 0 : (tid & 63) / TPT;
+    const int wslot = (G == 1) ? __builtin_amdgcn_readfirstlane(tid / TPT) : __builtin_amdgcn_readfirstlane(tid >> 6) * G;
+    const int slot = wslot + sub;
     cpx<T> *buf0 = reinterpret_cast<cpx<T> *>(smem_raw) + (size_t)slot * NBUF * lds_elems(N);
     cpx<T> *buf1 = (NBUF == 2) ? buf0 + lds_elems(N) : buf0;
 
@@ -313,10 +322,16 @@ __global__ __launch_bounds__(CFG::BLOCK, CFG::MINW) void fft_persist_kernel(cons
     // held in one set is computed, the other set receives the next transform's loads.
     Raw ra[R], rb[R];
     const int in_lane_bytes = tau * IO::kRawBytes;
+    const int in_row_off = (G == 1) ? 0 : sub * (int)io.in_slot_bytes();
+    // valid transforms of this wavefront's group when the workgroup sits at `b`
+    auto group_cnt = [&](size_t b) -> int {
+        const size_t first = b + wslot;
+        return first >= batch ? 0 : (batch - first < (size_t)G ? (int)(batch - first) : G);
+    };
     {
-        const rsrc_t d = io.in_desc(base + slot, base + slot < batch);
+        const rsrc_t d = io.in_desc_n(base + wslot, group_cnt(base));
 #pragma unroll
-        for (int u = 0; u < R; ++u) ra[u] = io.fetch_d(d, in_lane_bytes, FirstG::in_index(0, u));
+        for (int u = 0; u < R; ++u) ra[u] = io.fetch_d(d, in_lane_bytes, FirstG::in_index(0, u), in_row_off);
     }
 
     // One step: issue the NEXT transform's loads into NXT (unconditionally, through a descriptor that is EMPTY when
@@ -327,11 +342,12 @@ __global__ __launch_bounds__(CFG::BLOCK, CFG::MINW) void fft_persist_kernel(cons
         const size_t nbase = base + step;                                                                            \
         const bool more = nbase < batch; /* workgroup-uniform */                                                     \
         {                                                                                                            \
-            const rsrc_t d = io.in_desc(nbase + slot, nbase + slot < batch);                                         \
-            _Pragma("unroll") for (int u = 0; u < R; ++u) NXT[u] = io.fetch_d(d, in_lane_bytes, FirstG::in_index(0, u)); \
+            const rsrc_t d = io.in_desc_n(nbase + wslot, group_cnt(nbase));                                          \
+            _Pragma("unroll") for (int u = 0; u < R; ++u)                                                            \
+                NXT[u] = io.fetch_d(d, in_lane_bytes, FirstG::in_index(0, u), in_row_off);                           \
         }                                                                                                            \
         __builtin_amdgcn_sched_barrier(0); /* keep the prefetch ahead of CUR's first use */                          \
-        persist_transform<T, L, RL, EPI, CFG>(CUR, st, io, tw, buf0, buf1, base + slot, base + slot < batch, tau);   \
+        persist_transform<T, L, RL, EPI, CFG>(CUR, st, io, tw, buf0, buf1, base + wslot, group_cnt(base), sub, tau);  \
         if (!more) LEAVE;                                                                                            \
         base = nbase;                                                                                                \
     }

@@ -32,6 +32,10 @@ struct PlainTw {
     static constexpr bool kSplitLds = false;
     static constexpr int kMinWaves = 1;  // __launch_bounds__ second argument (waves per SIMD the kernel must fit)
     static constexpr int kPersistMaxLog2 = 13;  // largest transform the persistent kernel is built for with this policy
+    // smallest one it is USED for (measured against the generic kernel, one box: complex n = 128 / 256 lose 5 %, STFT
+    // gains 22 % / 6 %, irfft 16 % / 29 %, rfft n = 512 gains 4 %, n = 256 loses 6 %)
+    static constexpr int kPersistMinLog2 = 9;
+    __host__ __device__ bool group_rows_ok() const { return true; }  // per-lane row offsets fit 32 bits
     __device__ __forceinline__ TwPlain tw_map(size_t) const { return {}; }
 };
 
@@ -56,6 +60,17 @@ struct ComplexIO : PlainTw {
         return make_rsrc(in + (valid ? xf : 0) * (size_t)n, valid ? (unsigned)n * sizeof(cpx<T>) : 0u);
     }
     __device__ __forceinline__ rsrc_t out_desc(size_t xf) const { return make_rsrc(out + xf * (size_t)n, (unsigned)n * sizeof(cpx<T>)); }
+    // group forms (persistent kernel, transforms smaller than a wavefront): cnt consecutive transforms from xf0;
+    // lane offset = row_off (sub-slot * row bytes) + the per-transform offsets of the forms above
+    __device__ __forceinline__ rsrc_t in_desc_n(size_t xf0, int cnt) const
+    {
+        return make_rsrc(in + (cnt > 0 ? xf0 : 0) * (size_t)n, (unsigned)(cnt > 0 ? cnt : 0) * (unsigned)n * (unsigned)sizeof(cpx<T>));
+    }
+    __device__ __forceinline__ rsrc_t out_desc_n(size_t xf0, int cnt) const
+    {
+        return make_rsrc(out + (cnt > 0 ? xf0 : 0) * (size_t)n, (unsigned)(cnt > 0 ? cnt : 0) * (unsigned)n * (unsigned)sizeof(cpx<T>));
+    }
+    __device__ __forceinline__ unsigned out_row_bytes() const { return (unsigned)n * sizeof(cpx<T>); }
     // workgroup forms (fft_wg_kernel, several transforms per wave): one descriptor over the xpb consecutive
     // transforms starting at xf0, cut at the end of the batch; lane offset = slot * in_slot_bytes() + element.
     __device__ __forceinline__ bool wg_desc_ok(int) const { return true; }
@@ -65,18 +80,18 @@ struct ComplexIO : PlainTw {
         const size_t cnt = xf0 < batch ? (batch - xf0 < (size_t)xpb ? batch - xf0 : (size_t)xpb) : 0;
         return make_rsrc(in + (cnt ? xf0 : 0) * (size_t)n, (unsigned)(cnt * n * sizeof(cpx<T>)));
     }
-    __device__ __forceinline__ Raw fetch_d(rsrc_t d, int lane_bytes, int iu) const
+    __device__ __forceinline__ Raw fetch_d(rsrc_t d, int lane_bytes, int iu, int row_off = 0) const
     {
-        return buf_load_cpx<T, AUX_NT>(d, lane_bytes, iu * (int)sizeof(cpx<T>));
+        return buf_load_cpx<T, AUX_NT>(d, row_off + lane_bytes, iu * (int)sizeof(cpx<T>));
     }
-    __device__ __forceinline__ void store_d(rsrc_t d, int lane_bytes, int ou, cpx<T> v) const
+    __device__ __forceinline__ void store_d(rsrc_t d, int lane_bytes, int ou, cpx<T> v, int row_off = 0) const
     {
         if (INVERSE) {
             const T im = -v.im;
             v.re = v.re * scale;
             v.im = im * scale;
         }
-        buf_store_cpx<T>(v, d, lane_bytes, ou * (int)sizeof(cpx<T>));
+        buf_store_cpx<T>(v, d, row_off + lane_bytes, ou * (int)sizeof(cpx<T>));
     }
     __device__ __forceinline__ Inv invariant(int) const { return {}; }
     __device__ __forceinline__ cpx<T> finish(size_t, int, Raw v, Inv) const
@@ -100,6 +115,7 @@ struct ComplexIO : PlainTw {
 struct StftIO : PlainTw {
     static constexpr bool kStreams = true;
     static constexpr bool kPersist = true;
+    static constexpr int kPersistMinLog2 = 7;
     static constexpr bool kInvInLds = false;  // 16 window samples per thread: registers (LDS staging + 3 waves/SIMD measured slower)
     static constexpr bool kLeanRegisters = false;
     using Raw = float;
@@ -109,6 +125,7 @@ struct StftIO : PlainTw {
     cpx<float> *__restrict__ out;
     size_t len, hop, start0;
     int n;
+    __host__ __device__ bool group_rows_ok() const { return hop <= (size_t(1) << 24); }
     __device__ __forceinline__ bool in_range(size_t xf, int i) const { return start0 + xf * hop + (size_t)i < len; }
     __device__ __forceinline__ Raw fetch(size_t xf, int i) const
     {
@@ -136,11 +153,30 @@ struct StftIO : PlainTw {
         if (avail > 0x3fffffffULL) avail = 0x3fffffffULL;
         return make_rsrc(signal + (avail ? start : 0), (unsigned)avail * 4u);
     }
-    __device__ __forceinline__ Raw fetch_d(rsrc_t d, int lane_bytes, int iu) const { return buf_load_f32<AUX_DEFAULT>(d, lane_bytes, iu * 4); }
-    __device__ __forceinline__ void store_d(rsrc_t d, int lane_bytes, int ou, cpx<float> v) const
+    __device__ __forceinline__ Raw fetch_d(rsrc_t d, int lane_bytes, int iu, int row_off = 0) const
     {
-        buf_store_cpx<float>(v, d, lane_bytes, ou * 8);
+        return buf_load_f32<AUX_DEFAULT>(d, row_off + lane_bytes, iu * 4);
     }
+    __device__ __forceinline__ void store_d(rsrc_t d, int lane_bytes, int ou, cpx<float> v, int row_off = 0) const
+    {
+        buf_store_cpx<float>(v, d, row_off + lane_bytes, ou * 8);
+    }
+    // group forms: cnt consecutive frames from xf0 (frame f of the group starts f*hop samples in); the descriptor ends
+    // with the signal, so frames that run off its end read zeros (stft.rs:95-99)
+    __device__ __forceinline__ rsrc_t in_desc_n(size_t xf0, int cnt) const
+    {
+        const size_t start = start0 + xf0 * hop;
+        size_t avail = (cnt > 0 && start < len) ? len - start : 0;
+        const size_t span = cnt > 0 ? (size_t)(cnt - 1) * hop + (size_t)n : 0;
+        if (avail > span) avail = span;
+        if (avail > 0x3fffffffULL) avail = 0x3fffffffULL;
+        return make_rsrc(signal + (avail ? start : 0), (unsigned)avail * 4u);
+    }
+    __device__ __forceinline__ rsrc_t out_desc_n(size_t xf0, int cnt) const
+    {
+        return make_rsrc(out + (cnt > 0 ? xf0 : 0) * (size_t)n, (unsigned)(cnt > 0 ? cnt : 0) * (unsigned)n * 8u);
+    }
+    __device__ __forceinline__ unsigned out_row_bytes() const { return (unsigned)n * 8u; }
     __device__ __forceinline__ Inv invariant(int i) const { return window[i]; }
     __device__ __forceinline__ cpx<float> finish(size_t xf, int i, Raw x, Inv w) const
     {
@@ -165,11 +201,16 @@ struct StftMagIO : StftIO {
         if (o < n / 2) st_stream(mags + xf * (size_t)(n / 2) + o, mag(v));
     }
     __device__ __forceinline__ rsrc_t out_desc(size_t xf) const { return make_rsrc(mags + xf * (size_t)(n / 2), (unsigned)(n / 2) * 4u); }
-    __device__ __forceinline__ void store_d(rsrc_t d, int lane_bytes, int ou, cpx<float> v) const
+    __device__ __forceinline__ void store_d(rsrc_t d, int lane_bytes, int ou, cpx<float> v, int row_off = 0) const
     {
         // lane_bytes = 8 * tau (complex offset); the magnitude row has 4-byte elements
-        if (ou + (lane_bytes >> 3) < n / 2) buf_store_f32(mag(v), d, lane_bytes >> 1, ou * 4);
+        if (ou + (lane_bytes >> 3) < n / 2) buf_store_f32(mag(v), d, row_off + (lane_bytes >> 1), ou * 4);
     }
+    __device__ __forceinline__ rsrc_t out_desc_n(size_t xf0, int cnt) const
+    {
+        return make_rsrc(mags + (cnt > 0 ? xf0 : 0) * (size_t)(n / 2), (unsigned)(cnt > 0 ? cnt : 0) * (unsigned)(n / 2) * 4u);
+    }
+    __device__ __forceinline__ unsigned out_row_bytes() const { return (unsigned)(n / 2) * 4u; }
 };
 
 // max over a non-negative f32 array, NaN never selected (spectrogram.rs:69-71: `if mag > max_mag`): non-negative floats
@@ -196,6 +237,7 @@ template <typename T>
 struct RfftIO : PlainTw {
     static constexpr bool kStreams = true;
     static constexpr bool kPersist = true;
+    static constexpr int kPersistMinLog2 = 8;
     static constexpr bool kInvInLds = true;  // window pairs + post-pass table: staged in LDS once per workgroup
     static constexpr bool kLeanRegisters = false;
     using Raw = cpx<T>;
@@ -235,14 +277,24 @@ struct RfftIO : PlainTw {
         const size_t cnt = xf0 < batch ? (batch - xf0 < (size_t)xpb ? batch - xf0 : (size_t)xpb) : 0;
         return make_rsrc(in + (cnt ? xf0 : 0) * (size_t)(2 * m), (unsigned)(cnt * m * sizeof(cpx<T>)));
     }
-    __device__ __forceinline__ Raw fetch_d(rsrc_t d, int lane_bytes, int iu) const
+    __device__ __forceinline__ Raw fetch_d(rsrc_t d, int lane_bytes, int iu, int row_off = 0) const
     {
-        return buf_load_cpx<T, AUX_NT>(d, lane_bytes, iu * (int)sizeof(cpx<T>));
+        return buf_load_cpx<T, AUX_NT>(d, row_off + lane_bytes, iu * (int)sizeof(cpx<T>));
     }
-    __device__ __forceinline__ void store_d(rsrc_t d, int lane_bytes, int ou, cpx<T> v) const
+    __device__ __forceinline__ void store_d(rsrc_t d, int lane_bytes, int ou, cpx<T> v, int row_off = 0) const
     {
-        buf_store_cpx<T>(v, d, lane_bytes, ou * (int)sizeof(cpx<T>));
+        buf_store_cpx<T>(v, d, row_off + lane_bytes, ou * (int)sizeof(cpx<T>));
     }
+    // group forms: cnt consecutive rows from xf0
+    __device__ __forceinline__ rsrc_t in_desc_n(size_t xf0, int cnt) const
+    {
+        return make_rsrc(in + (cnt > 0 ? xf0 : 0) * (size_t)(2 * m), (unsigned)(cnt > 0 ? cnt : 0) * (unsigned)m * (unsigned)sizeof(cpx<T>));
+    }
+    __device__ __forceinline__ rsrc_t out_desc_back_n(size_t xf0, int cnt, int back) const
+    {
+        return make_rsrc(out + xf0 * (size_t)(m + 1) - back, ((unsigned)cnt * (unsigned)(m + 1) + (unsigned)back) * (unsigned)sizeof(cpx<T>));
+    }
+    __device__ __forceinline__ unsigned out_row_bytes() const { return (unsigned)(m + 1) * sizeof(cpx<T>); }
     // no window: multiply by exactly 1, which leaves every value unchanged bit for bit
     __device__ __forceinline__ Inv invariant(int i) const
     {
@@ -277,6 +329,7 @@ struct IrfftIO : PlainTw {
     static constexpr bool kStreams = false;  // generic kernels: per-element loads (two row elements + a table entry each)
     static constexpr bool kPersist = sizeof(T) == 4;  // persistent kernel: both row elements prefetched, table in LDS
     static constexpr int kPersistMaxLog2 = 11;        // 64 prefetch registers per thread: up to m = 2048
+    static constexpr int kPersistMinLog2 = 7;
     static constexpr bool kInvInLds = true;
     static constexpr bool kLeanRegisters = false;
     struct Raw { cpx<T> a, rb; };  // input[k], input[m-k]
@@ -294,22 +347,33 @@ struct IrfftIO : PlainTw {
         return make_rsrc(in + (valid ? xf : 0) * (size_t)(m + 1), valid ? (unsigned)(m + 1) * sizeof(cpx<T>) : 0u);
     }
     __device__ __forceinline__ rsrc_t out_desc(size_t xf) const { return make_rsrc(out + xf * (size_t)m, (unsigned)m * sizeof(cpx<T>)); }
-    __device__ __forceinline__ Raw fetch_d(rsrc_t d, int lane_bytes, int iu) const
+    __device__ __forceinline__ Raw fetch_d(rsrc_t d, int lane_bytes, int iu, int row_off = 0) const
     {
         // k = iu + tau; m - k = (m - iu - tpt + 1) + (tpt - 1 - tau): a non-negative constant plus the reversed lane
         Raw r;
-        r.a = buf_load_cpx<T, AUX_NT>(d, lane_bytes, iu * (int)sizeof(cpx<T>));
-        r.rb = buf_load_cpx<T, AUX_NT>(d, (tpt - 1) * (int)sizeof(cpx<T>) - lane_bytes, (m - iu - tpt + 1) * (int)sizeof(cpx<T>));
+        r.a = buf_load_cpx<T, AUX_NT>(d, row_off + lane_bytes, iu * (int)sizeof(cpx<T>));
+        r.rb = buf_load_cpx<T, AUX_NT>(d, row_off + (tpt - 1) * (int)sizeof(cpx<T>) - lane_bytes, (m - iu - tpt + 1) * (int)sizeof(cpx<T>));
         return r;
     }
-    __device__ __forceinline__ void store_d(rsrc_t d, int lane_bytes, int ou, cpx<T> v) const
+    __device__ __forceinline__ void store_d(rsrc_t d, int lane_bytes, int ou, cpx<T> v, int row_off = 0) const
     {
         if (m > 1) {
             const T im = -v.im;
             v = mk<T>(v.re * scale, im * scale);
         }
-        buf_store_cpx<T>(v, d, lane_bytes, ou * (int)sizeof(cpx<T>));
+        buf_store_cpx<T>(v, d, row_off + lane_bytes, ou * (int)sizeof(cpx<T>));
     }
+    // group forms: cnt consecutive rows from xf0
+    __device__ __forceinline__ rsrc_t in_desc_n(size_t xf0, int cnt) const
+    {
+        return make_rsrc(in + (cnt > 0 ? xf0 : 0) * (size_t)(m + 1), (unsigned)(cnt > 0 ? cnt : 0) * (unsigned)(m + 1) * (unsigned)sizeof(cpx<T>));
+    }
+    __device__ __forceinline__ rsrc_t out_desc_n(size_t xf0, int cnt) const
+    {
+        return make_rsrc(out + (cnt > 0 ? xf0 : 0) * (size_t)m, (unsigned)(cnt > 0 ? cnt : 0) * (unsigned)m * (unsigned)sizeof(cpx<T>));
+    }
+    __device__ __forceinline__ unsigned in_slot_bytes() const { return (unsigned)(m + 1) * sizeof(cpx<T>); }
+    __device__ __forceinline__ unsigned out_row_bytes() const { return (unsigned)m * sizeof(cpx<T>); }
     __device__ __forceinline__ Inv invariant(int k) const { return rtab[k]; }
     __device__ __forceinline__ cpx<T> finish(size_t, int k, Raw r, Inv tw) const { return pre(k, r.a, r.rb, tw); }
     // scratch[k] of irfft_direct (rfft.rs:487-506) from input[k], input[m-k], W[k]; then ifft's conj on the way in

@@ -31,6 +31,7 @@ struct kofft_hip_ctx {
     bool use_persist = true;  // KOFFT_HIP_NO_PERSIST=1 forces the generic kernels (A/B measurements, tests)
     int persist_grid_pct = 0; // KOFFT_HIP_PERSIST_GRID_PCT: scale the persistent grids (measurements only)
     bool big_two_only = false; // KOFFT_HIP_BIG_TWO_FACTORS=1: never split into three factors (A/B measurements)
+    bool persist_small = true; // KOFFT_HIP_PERSIST_SMALL=0: n = 128, 256 on the generic kernels (A/B measurements)
     std::string last_error;
     // planner caches: (kind, n) -> device table.  kind 0/1 = FftPlanner twiddles f32/f64,
     // 2/3 = RfftPlanner post-pass table f32/f64.
@@ -180,6 +181,15 @@ template <> struct PersistCfg<11, IrfftIO<float>> {
     static constexpr int BLOCK = 256, NBUF = 1, RL = 4, MINW = 2, WG_PER_CU = 2;
     static constexpr bool kInvInLds = true, kTwLastInLds = true;
 };
+// n = 256, 128: 8 points per thread, 32 / 16 threads per transform -> 2 / 4 transforms per wavefront
+template <class IO> struct PersistCfg<8, IO> {
+    static constexpr int BLOCK = 256, NBUF = 1, RL = 3, MINW = 4, WG_PER_CU = 4;
+    static constexpr bool kInvInLds = IO::kInvInLds, kTwLastInLds = false;
+};
+template <class IO> struct PersistCfg<7, IO> {
+    static constexpr int BLOCK = 256, NBUF = 1, RL = 3, MINW = 4, WG_PER_CU = 4;
+    static constexpr bool kInvInLds = IO::kInvInLds, kTwLastInLds = false;
+};
 // n = 512: 8 points per thread so that a transform is still one wavefront (three passes of three stages)
 template <class IO> struct PersistCfg<9, IO> {
     static constexpr int BLOCK = 256, NBUF = 1, RL = 3, MINW = 4, WG_PER_CU = 4;
@@ -255,6 +265,12 @@ int dispatch(kofft_hip_ctx *ctx, const IO &io, size_t n, size_t batch)
         if (L == 11 && batch >= (size_t)ctx->num_cus * 16) return launch_persist<T, 11, EPI>(ctx, io, tw, batch);
         if (L == 10 && batch >= (size_t)ctx->num_cus * 32) return launch_persist<T, 10, EPI>(ctx, io, tw, batch);
         if (L == 9 && batch >= (size_t)ctx->num_cus * 64) return launch_persist<T, 9, EPI>(ctx, io, tw, batch);
+        if (ctx->persist_small && io.group_rows_ok()) {
+            if constexpr (IO::kPersistMinLog2 <= 8)
+                if (L == 8 && batch >= (size_t)ctx->num_cus * 128) return launch_persist<T, 8, EPI>(ctx, io, tw, batch);
+            if constexpr (IO::kPersistMinLog2 <= 7)
+                if (L == 7 && batch >= (size_t)ctx->num_cus * 256) return launch_persist<T, 7, EPI>(ctx, io, tw, batch);
+        }
     }
     switch (L) {
 #define KOFFT_CASE(LL) \
@@ -566,8 +582,8 @@ int irfft_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t batc
     const cpx<T> *rtab = nullptr;
     int rc = get_table<T>(ctx, Kind<T>::rt, m, &rtab);
     if (rc) return rc;
-    // threads per transform of the persistent kernels (m/16; m/8 at m = 512)
-    const int tpt = (int)(m == 512 ? m / 8 : m / 16);
+    // threads per transform of the persistent kernels (m/16; m/8 up to m = 512)
+    const int tpt = (int)(m <= 512 ? m / 8 : m / 16);
     IrfftIO<T> io{{}, reinterpret_cast<const cpx<T> *>(d_in), reinterpret_cast<cpx<T> *>(d_out), rtab, (int)m,
                   (T)1 / (T)(float)m, tpt};
     return dispatch<T, EPI_STORE>(ctx, io, m, batch);
@@ -893,6 +909,7 @@ int kofft_hip_create(int device, kofft_hip_ctx **out)
     if (const char *e = getenv("KOFFT_HIP_NO_PERSIST")) ctx->use_persist = !(e[0] == '1');
     if (const char *e = getenv("KOFFT_HIP_PERSIST_GRID_PCT")) ctx->persist_grid_pct = atoi(e);
     if (const char *e = getenv("KOFFT_HIP_BIG_TWO_FACTORS")) ctx->big_two_only = (e[0] == '1');
+    if (const char *e = getenv("KOFFT_HIP_PERSIST_SMALL")) ctx->persist_small = !(e[0] == '0');
     if (const char *e = getenv("KOFFT_HIP_BIG_CHUNK_MB")) {
         const long mb = atol(e);
         if (mb > 0) ctx->big_chunk_bytes = (size_t)mb << 20;

@@ -759,3 +759,35 @@ def test_irfft_streaming_paths(fft32, oracle, n, batch):
     x = rng.uniform(-1, 1, (64, n)).astype(np.float32)
     back = fft32.irfft_batch(fft32.rfft_batch(x), n)
     assert np.max(np.abs(back - x)) < 5e-4
+
+
+@pytest.mark.parametrize("n,batch", [(256, 32768), (256, 32771), (128, 65536), (128, 65539)])
+def test_small_n_streaming_paths(fft32, oracle, n, batch):
+    """n = 256 / 128 on the persistent kernel: 2 / 4 transforms per wavefront behind one group descriptor (batches that
+    are not a multiple of the group leave a partly filled last group): complex, rfft (+ window, aligned epilogue with
+    per-lane row offsets), irfft (reversed second load) and STFT."""
+    rng = seeded(6000 + n + batch % 7)
+    x = rand_c(rng, (batch, n))
+    y = x.copy()
+    fft32.fft_batch(y)
+    assert_parity(y, oracle.fft(x), f"streaming fft c32 n={n} batch={batch}", REL_TOL_F32)
+    z = x.copy()
+    fft32.fft_batch(z, inverse=True)
+    assert_parity(z, oracle.ifft(x), f"streaming ifft c32 n={n} batch={batch}", REL_TOL_F32)
+    r = rng.uniform(-1, 1, (batch, 2 * n)).astype(np.float32)
+    win = oracle.hann(2 * n)
+    assert_parity(fft32.rfft_batch(r, win), oracle.rfft(r, win), f"streaming rfft n={2 * n} batch={batch}", REL_TOL_F32)
+    spec = rand_c(rng, (batch, n + 1))
+    assert_parity(fft32.irfft_batch(spec, 2 * n), oracle.irfft(spec, 2 * n), f"streaming irfft n={2 * n} batch={batch}", REL_TOL_F32)
+    hop = n // 4
+    sig = rng.uniform(-1, 1, hop * batch + 5).astype(np.float32)
+    w2 = oracle.hann(n)
+    frames = -(-sig.size // hop) + 1
+    assert_parity(fft32.stft_into(sig, w2, hop, frames, check_frames=False), oracle.stft_range(sig, w2, hop, 0, frames),
+                  f"streaming stft win={n}", REL_TOL_F32)
+    part = sig[:hop * 33000 + 3]
+    nfr = -(-part.size // hop)
+    mags, mx = fft32.stft_magnitudes(part, n, hop)
+    full = oracle.stft_range(part, w2, hop, 0, nfr)[:, :n // 2]
+    want = np.sqrt(full.real * full.real + full.imag * full.imag, dtype=np.float32)
+    assert bits_equal(mags, want) and mx == want.max()
