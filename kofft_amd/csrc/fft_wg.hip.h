@@ -33,7 +33,7 @@ struct PlainTw {
     static constexpr int kMinWaves = 1;  // __launch_bounds__ second argument (waves per SIMD the kernel must fit)
     static constexpr int kPersistMaxLog2 = 13;  // largest transform the persistent kernel is built for with this policy
     // smallest one it is USED for (measured against the generic kernel, one box: complex n = 128 / 256 lose 5 %, STFT
-    // gains 22 % / 6 %, irfft 16 % / 29 %, rfft n = 512 gains 4 %, n = 256 loses 6 %)
+    // gains 22 % / 6 % (n = 64: 20 %), irfft 16 % / 29 % (m = 64: 5 %), rfft n = 512 gains 4 %, n = 256 loses 5 %)
     static constexpr int kPersistMinLog2 = 9;
     __host__ __device__ bool group_rows_ok() const { return true; }  // per-lane row offsets fit 32 bits
     __device__ __forceinline__ TwPlain tw_map(size_t) const { return {}; }
@@ -115,7 +115,7 @@ struct ComplexIO : PlainTw {
 struct StftIO : PlainTw {
     static constexpr bool kStreams = true;
     static constexpr bool kPersist = true;
-    static constexpr int kPersistMinLog2 = 7;
+    static constexpr int kPersistMinLog2 = 6;
     static constexpr bool kInvInLds = false;  // 16 window samples per thread: registers (LDS staging + 3 waves/SIMD measured slower)
     static constexpr bool kLeanRegisters = false;
     using Raw = float;
@@ -329,7 +329,7 @@ struct IrfftIO : PlainTw {
     static constexpr bool kStreams = false;  // generic kernels: per-element loads (two row elements + a table entry each)
     static constexpr bool kPersist = sizeof(T) == 4;  // persistent kernel: both row elements prefetched, table in LDS
     static constexpr int kPersistMaxLog2 = 11;        // 64 prefetch registers per thread: up to m = 2048
-    static constexpr int kPersistMinLog2 = 7;
+    static constexpr int kPersistMinLog2 = 6;
     static constexpr bool kInvInLds = true;
     static constexpr bool kLeanRegisters = false;
     struct Raw { cpx<T> a, rb; };  // input[k], input[m-k]

@@ -181,6 +181,11 @@ template <> struct PersistCfg<11, IrfftIO<float>> {
     static constexpr int BLOCK = 256, NBUF = 1, RL = 4, MINW = 2, WG_PER_CU = 2;
     static constexpr bool kInvInLds = true, kTwLastInLds = true;
 };
+// n = 64: 4 points per thread, 16 threads per transform, three passes of two stages
+template <class IO> struct PersistCfg<6, IO> {
+    static constexpr int BLOCK = 256, NBUF = 1, RL = 2, MINW = 4, WG_PER_CU = 4;
+    static constexpr bool kInvInLds = IO::kInvInLds, kTwLastInLds = false;
+};
 // n = 256, 128: 8 points per thread, 32 / 16 threads per transform -> 2 / 4 transforms per wavefront
 template <class IO> struct PersistCfg<8, IO> {
     static constexpr int BLOCK = 256, NBUF = 1, RL = 3, MINW = 4, WG_PER_CU = 4;
@@ -270,6 +275,8 @@ int dispatch(kofft_hip_ctx *ctx, const IO &io, size_t n, size_t batch)
                 if (L == 8 && batch >= (size_t)ctx->num_cus * 128) return launch_persist<T, 8, EPI>(ctx, io, tw, batch);
             if constexpr (IO::kPersistMinLog2 <= 7)
                 if (L == 7 && batch >= (size_t)ctx->num_cus * 256) return launch_persist<T, 7, EPI>(ctx, io, tw, batch);
+            if constexpr (IO::kPersistMinLog2 <= 6)
+                if (L == 6 && batch >= (size_t)ctx->num_cus * 512) return launch_persist<T, 6, EPI>(ctx, io, tw, batch);
         }
     }
     switch (L) {
@@ -583,7 +590,7 @@ int irfft_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t batc
     int rc = get_table<T>(ctx, Kind<T>::rt, m, &rtab);
     if (rc) return rc;
     // threads per transform of the persistent kernels (m/16; m/8 up to m = 512)
-    const int tpt = (int)(m <= 512 ? m / 8 : m / 16);
+    const int tpt = (int)(m <= 64 ? m / 4 : m <= 512 ? m / 8 : m / 16);
     IrfftIO<T> io{{}, reinterpret_cast<const cpx<T> *>(d_in), reinterpret_cast<cpx<T> *>(d_out), rtab, (int)m,
                   (T)1 / (T)(float)m, tpt};
     return dispatch<T, EPI_STORE>(ctx, io, m, batch);

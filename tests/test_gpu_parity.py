@@ -761,9 +761,9 @@ def test_irfft_streaming_paths(fft32, oracle, n, batch):
     assert np.max(np.abs(back - x)) < 5e-4
 
 
-@pytest.mark.parametrize("n,batch", [(256, 32768), (256, 32771), (128, 65536), (128, 65539)])
+@pytest.mark.parametrize("n,batch", [(256, 32768), (256, 32771), (128, 65536), (128, 65539), (64, 131075)])
 def test_small_n_streaming_paths(fft32, oracle, n, batch):
-    """n = 256 / 128 on the persistent kernel: 2 / 4 transforms per wavefront behind one group descriptor (batches that
+    """n = 256 / 128 / 64 on the persistent kernel: 2 / 4 / 4 transforms per wavefront behind one group descriptor (batches that
     are not a multiple of the group leave a partly filled last group): complex, rfft (+ window, aligned epilogue with
     per-lane row offsets), irfft (reversed second load) and STFT."""
     rng = seeded(6000 + n + batch % 7)
