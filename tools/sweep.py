@@ -81,6 +81,24 @@ def main():
                         rows.append(dict(kind=name, n=mb, batch=1, ms=ms, gbs=gbs, frac=gbs / 8000))
                         print(f"{name:7s} {mb:5d} MiB {ms:8.4f} ms {gbs:8.1f} GB/s frac {gbs/8000:.3f}", flush=True)
                     del x, y
+            elif kind in ("rfft64", "irfft64"):
+                fft = kofft_amd.HipFftImpl(np.float64, device=0)
+                fft.set_stream(stream.cuda_stream)
+                for L in range(2, 15):
+                    n = 1 << L
+                    if (args.only_n and n != args.only_n) or (args.max_n and n > args.max_n):
+                        continue
+                    batch = max(1, (args.mb << 20) // (8 * n))
+                    re = torch.empty((batch, n), dtype=torch.float64, device=dev).uniform_(-1, 1)
+                    cx = torch.empty((batch, n // 2 + 1, 2), dtype=torch.float64, device=dev).uniform_(-1, 1)
+                    if kind == "rfft64":
+                        ms = timeit(stream, lambda: fft.rfft_dev(re.data_ptr(), cx.data_ptr(), None, n, batch))
+                    else:
+                        ms = timeit(stream, lambda: fft.irfft_dev(cx.data_ptr(), re.data_ptr(), n, batch))
+                    gbs = batch * (8 * n + 16 * (n // 2 + 1)) / ms / 1e6
+                    rows.append(dict(kind=kind, n=n, batch=batch, ms=ms, gbs=gbs, frac=gbs / 8000))
+                    print(f"{kind:7s} n={n:9d} batch={batch:9d} {ms:8.4f} ms {gbs:8.1f} GB/s frac {gbs/8000:.3f}", flush=True)
+                    del re, cx
             elif kind == "rfft32":
                 fft = kofft_amd.HipFftImpl(np.float32, device=0)
                 fft.set_stream(stream.cuda_stream)
