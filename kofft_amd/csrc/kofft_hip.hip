@@ -181,6 +181,16 @@ template <> struct PersistCfg<11, IrfftIO<float>> {
     static constexpr int BLOCK = 256, NBUF = 1, RL = 4, MINW = 2, WG_PER_CU = 2;
     static constexpr bool kInvInLds = true, kTwLastInLds = true;
 };
+// STFT n = 2048 / 4096 is compute-limited (more stages per point): with the window in LDS the kernel fits 3 waves/SIMD
+// (158 VGPRs), measured +5.5 % / +3.5 % (the memory-limited complex kernel LOSES 4 % with a third workgroup per CU).
+template <class IO> struct PersistCfgStftBig {
+    static constexpr int BLOCK = 256, NBUF = 1, RL = 4, MINW = 3, WG_PER_CU = 3;
+    static constexpr bool kInvInLds = true, kTwLastInLds = false;
+};
+template <> struct PersistCfg<12, StftIO> : PersistCfgStftBig<StftIO> {};
+template <> struct PersistCfg<11, StftIO> : PersistCfgStftBig<StftIO> {};
+template <> struct PersistCfg<12, StftMagIO> : PersistCfgStftBig<StftMagIO> {};
+template <> struct PersistCfg<11, StftMagIO> : PersistCfgStftBig<StftMagIO> {};
 // n = 64: 4 points per thread, 16 threads per transform, three passes of two stages
 template <class IO> struct PersistCfg<6, IO> {
     static constexpr int BLOCK = 256, NBUF = 1, RL = 2, MINW = 4, WG_PER_CU = 4;
