@@ -191,6 +191,11 @@ template <> struct PersistCfg<12, StftIO> : PersistCfgStftBig<StftIO> {};
 template <> struct PersistCfg<11, StftIO> : PersistCfgStftBig<StftIO> {};
 template <> struct PersistCfg<12, StftMagIO> : PersistCfgStftBig<StftMagIO> {};
 template <> struct PersistCfg<11, StftMagIO> : PersistCfgStftBig<StftMagIO> {};
+// rfft 8192 (m = 4096): window pairs in registers so that two workgroups (exchange buffer + post-pass table) fit a CU
+template <> struct PersistCfg<12, RfftIO<float>> {
+    static constexpr int BLOCK = 256, NBUF = 1, RL = 4, MINW = 2, WG_PER_CU = 2;
+    static constexpr bool kInvInLds = false, kTwLastInLds = false;
+};
 // n = 64: 4 points per thread, 16 threads per transform, three passes of two stages
 template <class IO> struct PersistCfg<6, IO> {
     static constexpr int BLOCK = 256, NBUF = 1, RL = 2, MINW = 4, WG_PER_CU = 4;
@@ -275,6 +280,9 @@ int dispatch(kofft_hip_ctx *ctx, const IO &io, size_t n, size_t batch)
         // streaming sizes: enough transforms to give every resident workgroup several iterations
         if constexpr (EPI == EPI_STORE && IO::kPersistMaxLog2 >= 13) {
             if (L == 13 && batch >= (size_t)ctx->num_cus * 4) return launch_persist<T, 13, EPI>(ctx, io, tw, batch);
+            if (L == 12 && batch >= (size_t)ctx->num_cus * 4) return launch_persist<T, 12, EPI>(ctx, io, tw, batch);
+        }
+        if constexpr (EPI == EPI_RFFT) {
             if (L == 12 && batch >= (size_t)ctx->num_cus * 4) return launch_persist<T, 12, EPI>(ctx, io, tw, batch);
         }
         if (L == 11 && batch >= (size_t)ctx->num_cus * 16) return launch_persist<T, 11, EPI>(ctx, io, tw, batch);

@@ -791,3 +791,13 @@ def test_small_n_streaming_paths(fft32, oracle, n, batch):
     full = oracle.stft_range(part, w2, hop, 0, nfr)[:, :n // 2]
     want = np.sqrt(full.real * full.real + full.imag * full.imag, dtype=np.float32)
     assert bits_equal(mags, want) and mx == want.max()
+
+
+@pytest.mark.parametrize("batch,windowed", [(1024, True), (1027, False)])
+def test_rfft_8192_streaming_path(fft32, oracle, batch, windowed):
+    """rfft n = 8192 (inner 4096-point transform) on the persistent kernel: window pairs in registers, post-pass table in
+    LDS, line-aligned epilogue with 256 threads per row."""
+    rng = seeded(7000 + batch)
+    x = rng.uniform(-1, 1, (batch, 8192)).astype(np.float32)
+    win = oracle.hann(8192) if windowed else None
+    assert_parity(fft32.rfft_batch(x, win), oracle.rfft(x, win), f"streaming rfft n=8192 batch={batch}", REL_TOL_F32)
