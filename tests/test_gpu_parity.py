@@ -744,7 +744,7 @@ def test_n512_streaming_paths(fft32, oracle, batch):
     assert_parity(fft32.stft_into(sig, w2, 128, frames), oracle.stft(sig, w2, 128, frames), "streaming stft win=512", REL_TOL_F32)
 
 
-@pytest.mark.parametrize("n,batch", [(1024, 16390), (2048, 8200), (4096, 4101)])
+@pytest.mark.parametrize("n,batch", [(1024, 16390), (2048, 8200), (4096, 4101), (8192, 1029)])
 def test_irfft_streaming_paths(fft32, oracle, n, batch):
     """irfft on the persistent kernel: input[k] and input[m-k] both prefetched through the row's descriptor (the second
     with a reversed lane index), the W table in LDS, k = 0 selected branch-free; rows are (m+1)*8 bytes, 8-byte aligned."""
