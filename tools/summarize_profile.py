@@ -17,6 +17,13 @@ def short(name: str) -> str:
     return name if len(name) < 160 else name[:157] + "..."
 
 
+def newest(pattern):
+    """gpurun merges every run's files into the same local directory: keep only the latest run's file."""
+    import os
+    files = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)
+    return files[-1:]
+
+
 def main():
     src, name, workload = Path(sys.argv[1]), sys.argv[2], sys.argv[3]
     out_dir = Path(__file__).resolve().parent.parent / "profiles"
@@ -26,7 +33,7 @@ def main():
              "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline ...`",
              "(PMC counters in separate passes: `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, `--pmc SQ_*`; tools/profile.sh)", "",
              "## Kernel stats (--kernel-trace --stats)", "", "| kernel | calls | avg us | min us | max us | % |", "|---|---|---|---|---|---|"]
-    for f in glob.glob(str(src / "trace" / "**" / "*_kernel_stats.csv"), recursive=True):
+    for f in newest(str(src / "trace" / "**" / "*_kernel_stats.csv")):
         for r in csv.DictReader(open(f)):
             k = {"name": short(r["Name"]), "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
                  "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"]), "pct": float(r["Percentage"])}
@@ -35,7 +42,7 @@ def main():
                 lines.append(f"| `{k['name']}` | {k['calls']} | {k['avg_ns'] / 1e3:.1f} | {k['min_ns'] / 1e3:.1f} | "
                              f"{k['max_ns'] / 1e3:.1f} | {k['pct']:.2f} |")
     # per-dispatch resources from the kernel trace
-    for f in glob.glob(str(src / "trace" / "**" / "*_kernel_trace.csv"), recursive=True):
+    for f in newest(str(src / "trace" / "**" / "*_kernel_trace.csv")):
         seen = set()
         for r in csv.DictReader(open(f)):
             if "kofft" in r["Kernel_Name"] and r["Kernel_Name"] not in seen:
@@ -45,7 +52,7 @@ def main():
                           f"VGPR {r.get('VGPR_Count', '?')}, SGPR {r.get('SGPR_Count', '?')}, scratch {r.get('Scratch_Size', '?')} B"]
     agg = defaultdict(list)
     for tag in ("pmc_fetch", "pmc_write", "pmc_sq"):
-        for f in glob.glob(str(src / tag / "**" / "*_counter_collection.csv"), recursive=True):
+        for f in newest(str(src / tag / "**" / "*_counter_collection.csv")):
             for r in csv.DictReader(open(f)):
                 if "kofft" in r["Kernel_Name"]:
                     agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
