@@ -1,0 +1,20 @@
+import sys, os
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+os.chdir('/root/repo')
+import numpy as np
+import test_gpu_fuzz as F
+import kofft_amd
+from oracle import pyoracle as oracle
+oracle.build()
+f32 = kofft_amd.HipFftImpl(np.float32); f64 = kofft_amd.HipFftImpl(np.float64)
+import conftest
+bad = 0
+for seed in range(100, 160):
+    for fn, args in ((F.test_fuzz_complex.__wrapped__ if hasattr(F.test_fuzz_complex,'__wrapped__') else F.test_fuzz_complex, (f32, f64, oracle, seed)),
+                     (F.test_fuzz_real, (f32, f64, oracle, seed)), (F.test_fuzz_stft, (f32, oracle, seed))):
+        try:
+            fn(*args)
+        except AssertionError as e:
+            bad += 1
+            print("FAIL", fn.__name__, seed, e, flush=True)
+print("soak done, failures:", bad)
