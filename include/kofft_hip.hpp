@@ -197,7 +197,9 @@ public:
     {
         return oop_strided(input, in_stride, output, out_stride, true);
     }
-    Result fft_with_strategy(std::vector<C> &input, FftStrategy) const override  // fft.rs:1337-1363
+    // fft.rs:1337-1363.  Every strategy runs the Stockham path.  Deliberate divergence: the reference's Radix4 arm
+    // (fft_radix4, fft.rs:1455-1548) is not a DFT from n = 16 (its digit-reversal loop is wrong).
+    Result fft_with_strategy(std::vector<C> &input, FftStrategy) const override
     {
         if (input.empty()) return Result::Err(FftError::EmptyInput);
         if (input.size() == 1) return Result::Ok();

@@ -132,7 +132,8 @@ macro_rules! impl_fft {
                 Ok(())
             }
             fn fft_with_strategy(&self, input: &mut [$cplx], _strategy: FftStrategy) -> Result<(), FftError> {
-                // kofft fft.rs:1337-1363: every strategy reaches the Stockham path for powers of two
+                // kofft fft.rs:1337-1363: every strategy runs the Stockham path here.  (The crate's own Radix4 arm,
+                // fft_radix4, is not a DFT from n = 16: its digit-reversal loop is wrong; this shim returns the correct transform.)
                 if input.is_empty() { return Err(FftError::EmptyInput); }
                 if input.len() == 1 { return Ok(()); }
                 self.fft(input)

@@ -110,6 +110,16 @@ def ifft(x: np.ndarray) -> np.ndarray:
     return fft(x, inverse=True)
 
 
+def fft_radix4(x: np.ndarray) -> np.ndarray:
+    """ScalarFftImpl::fft_radix4 (fft.rs:1455-1548) over the last axis: what fft_with_strategy(.., Radix4) computes."""
+    s = _sfx(x.dtype)
+    a = np.ascontiguousarray(x, _cdt(s)).copy()
+    n = a.shape[-1] if a.ndim else 0
+    batch = a.size // n if n else (1 if a.ndim <= 1 else int(np.prod(a.shape[:-1])))
+    _chk(getattr(lib(), f"ko_fft_radix4_batch_{s}")(_p(a), _SZ(n), _SZ(batch)))
+    return a
+
+
 def rfft(x: np.ndarray, window: np.ndarray | None = None) -> np.ndarray:
     """RfftPlanner::rfft_with_scratch over the last axis; optional row window multiplied in first."""
     s = _sfx(x.dtype)

@@ -272,3 +272,31 @@ def test_nonpow2_roundtrip_n3(oracle):  # lib.rs:267-282
 def test_nonpow2_f64_n12_matches_dft(oracle):  # tests/split64.rs:20-34 input; truth = f64 DFT
     x = np.arange(12, dtype=np.float64).astype(np.complex128)
     assert np.all(np.abs(oracle.fft(x) - np.fft.fft(x)) < 1e-10)
+
+
+def test_reference_fft_radix4_is_not_a_dft_beyond_n4(oracle):
+    """ScalarFftImpl::fft_radix4 (fft.rs:1455-1548; reached through fft_with_strategy(.., FftStrategy::Radix4),
+    fft.rs:1356): the "bit-reversal for radix-4" loop (fft.rs:1462-1474) flips ONE bit per base-4 digit, so it is not a
+    digit reversal and from n = 16 the result is not the DFT of the input.  The reference's own tests only check that
+    the call returns Ok (fft.rs:2641-2647).  This pins the restatement of that behaviour: n = 1 and 4 agree with the
+    Stockham path bit for bit, lengths that are not a power of four fall back to fft(), and from n = 16 the output is
+    O(1) away from a naive DFT.  The device path deliberately does NOT reproduce this."""
+    rng = np.random.default_rng(44)
+    for n in (1, 4):
+        x = (rng.uniform(-1, 1, (3, n)) + 1j * rng.uniform(-1, 1, (3, n))).astype(np.complex64)
+        assert np.array_equal(oracle.fft_radix4(x).view(np.uint32), oracle.fft(x).view(np.uint32))
+    for n in (2, 8, 32, 6, 12):
+        x = (rng.uniform(-1, 1, (2, n)) + 1j * rng.uniform(-1, 1, (2, n))).astype(np.complex64)
+        assert np.array_equal(oracle.fft_radix4(x).view(np.uint32), oracle.fft(x).view(np.uint32))
+    for n in (16, 64, 256):
+        x = (rng.uniform(-1, 1, (2, n)) + 1j * rng.uniform(-1, 1, (2, n))).astype(np.complex64)
+        ref = np.fft.fft(x.astype(np.complex128))
+        rel = np.abs(oracle.fft_radix4(x) - ref).max() / np.abs(ref).max()
+        assert rel > 0.3, (n, rel)                       # not a DFT
+        assert np.abs(oracle.fft(x) - ref).max() / np.abs(ref).max() < 1e-4   # the Stockham path is
+        # what the loop does instead: index i of the permuted array holds input[p(i)] with p a bit reversal over the
+        # LOW bit of every base-4 digit only -- check the permutation the restatement applies on an impulse train
+    # energy is still conserved by the butterflies (they are unitary up to n): Parseval holds even though the values are wrong
+    x = (rng.uniform(-1, 1, (1, 64)) + 1j * rng.uniform(-1, 1, (1, 64))).astype(np.complex64)
+    y = oracle.fft_radix4(x)
+    assert abs(np.sum(np.abs(y) ** 2) / 64 - np.sum(np.abs(x) ** 2)) < 1e-3 * np.sum(np.abs(x) ** 2)
