@@ -300,6 +300,41 @@ public:
     }
 };
 
+// fft::FftPlan (fft.rs:1989-2094): a length and a strategy bound to an implementation; every arm is the device transform
+template <typename T>
+class FftPlan {
+public:
+    size_t n;
+    FftStrategy strategy;
+    FftPlan(size_t n_, FftStrategy s, const HipFftImpl<T> &f) : n(n_), strategy(s), fft_(f) {}
+    Result fft(std::vector<Complex<T>> &input) const
+    {
+        if (input.size() != n) return Result::Err(FftError::MismatchedLengths);
+        return fft_.fft_with_strategy(input, strategy);
+    }
+    Result ifft(std::vector<Complex<T>> &input) const  // conj, fft, conj, * 1/(n as f32): ifft's arithmetic
+    {
+        if (input.size() != n) return Result::Err(FftError::MismatchedLengths);
+        if (n <= 1) return fft_.fft_with_strategy(input, strategy);
+        return fft_.ifft(input);
+    }
+    Result fft_out_of_place(const std::vector<Complex<T>> &input, std::vector<Complex<T>> &output) const
+    {
+        if (input.size() != n || output.size() != n) return Result::Err(FftError::MismatchedLengths);
+        output = input;
+        return fft(output);
+    }
+    Result ifft_out_of_place(const std::vector<Complex<T>> &input, std::vector<Complex<T>> &output) const
+    {
+        if (input.size() != n || output.size() != n) return Result::Err(FftError::MismatchedLengths);
+        output = input;
+        return ifft(output);
+    }
+
+private:
+    const HipFftImpl<T> &fft_;
+};
+
 // fft::batch / batch_inverse / multi_channel (fft.rs:2156-2191): serial semantics, first error wins
 template <typename T>
 Result batch(const FftImpl<T> &fft, std::vector<std::vector<Complex<T>>> &batches)

@@ -288,6 +288,28 @@ int main()
         delete ss;
         delete is;
     }
+    {   // fft.rs:2361-2387 plan fft / ifft / out of place; 2581-2610 length mismatches
+        FftPlan<float> plan(4, FftStrategy::SplitRadix, fft);
+        std::vector<Complex32> data = {{1, 0}, {2, 0}, {3, 0}, {4, 0}}, orig = data;
+        plan.fft(data).unwrap();
+        CHECK(same_bits(data, oracle_fft(orig)));
+        plan.ifft(data).unwrap();
+        for (size_t i = 0; i < 4; ++i) CHECK(std::fabs(data[i].re - orig[i].re) < 1e-4f);
+        std::vector<Complex32> ones(4, Complex32(1, 0)), out(4), out2(4), three(3);
+        plan.fft_out_of_place(ones, out).unwrap();
+        plan.ifft_out_of_place(out, out2).unwrap();
+        CHECK(same_bits(out2, oracle_fft(out, true)));
+        FftPlan<float> p2(4, FftStrategy::Radix2, fft);
+        CHECK(p2.fft(three) == Result::Err(FftError::MismatchedLengths));
+        CHECK(p2.ifft(three) == Result::Err(FftError::MismatchedLengths));
+        CHECK(p2.fft_out_of_place(ones, three) == Result::Err(FftError::MismatchedLengths));
+        CHECK(p2.ifft_out_of_place(three, out) == Result::Err(FftError::MismatchedLengths));
+        std::vector<Complex32> x64(64);
+        for (size_t i = 0; i < 64; ++i) x64[i] = Complex32(std::sin(0.3f * (float)i), std::cos(1.1f * (float)i));
+        auto want = oracle_fft(x64);
+        FftPlan<float>(64, FftStrategy::Radix4, fft).fft(x64).unwrap();  // the correct transform
+        CHECK(same_bits(x64, want));
+    }
     std::printf("%d checks, %d failed\n", g_checks, g_fail);
     return g_fail == 0 ? 0 : 1;
 }

@@ -801,3 +801,42 @@ def test_rfft_8192_streaming_path(fft32, oracle, batch, windowed):
     x = rng.uniform(-1, 1, (batch, 8192)).astype(np.float32)
     win = oracle.hann(8192) if windowed else None
     assert_parity(fft32.rfft_batch(x, win), oracle.rfft(x, win), f"streaming rfft n=8192 batch={batch}", REL_TOL_F32)
+
+
+def test_fft_plan(fft32, fft64, oracle):
+    """fft.rs:2361-2387 (plan fft/ifft, out of place), 2581-2610 (length mismatches), over the mirror's FftPlan."""
+    import kofft_amd as K
+
+    plan = K.FftPlan(4, K.FftStrategy.SplitRadix, fft32)
+    data = np.array([1, 2, 3, 4], np.complex64)
+    orig = data.copy()
+    plan.fft(data)
+    assert bits_equal(data, oracle.fft(orig))
+    plan.ifft(data)
+    assert np.all(np.abs(data.real - orig.real) < 1e-4)
+    out = np.zeros(4, np.complex64)
+    plan.fft_out_of_place(np.ones(4, np.complex64), out)
+    assert bits_equal(out, oracle.fft(np.ones(4, np.complex64)))
+    out2 = np.zeros(4, np.complex64)
+    plan.ifft_out_of_place(out, out2)
+    assert bits_equal(out2, oracle.ifft(out))
+    p2 = K.FftPlan(4, K.FftStrategy.Radix2, fft32)
+    for call in (lambda: p2.fft(np.zeros(3, np.complex64)), lambda: p2.ifft(np.zeros(3, np.complex64)),
+                 lambda: p2.fft_out_of_place(np.zeros(4, np.complex64), np.zeros(3, np.complex64)),
+                 lambda: p2.ifft_out_of_place(np.zeros(3, np.complex64), np.zeros(4, np.complex64))):
+        with pytest.raises(K.FftError) as e:
+            call()
+        assert e.value.code == K.FftError.MismatchedLengths
+    # every strategy returns the (correct) Stockham result on the device, for f32 and f64, including Radix4 at n = 64
+    rng = seeded(8100)
+    x = rand_c(rng, (64,))
+    want = oracle.fft(x)
+    for strat in (K.FftStrategy.Radix2, K.FftStrategy.Radix4, K.FftStrategy.SplitRadix, K.FftStrategy.Auto):
+        y = x.copy()
+        K.FftPlan(64, strat, fft32).fft(y)
+        assert bits_equal(y, want)
+    xd = rand_c(rng, (256,), np.complex128)
+    yd = xd.copy()
+    K.FftPlan(256, K.FftStrategy.Radix4, fft64).fft(yd)
+    assert bits_equal(yd, oracle.fft(xd))
+    assert np.abs(yd - np.fft.fft(xd)).max() < 1e-10  # ... which IS the DFT, unlike the reference's radix-4 arm
