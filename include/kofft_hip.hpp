@@ -335,6 +335,20 @@ private:
     const HipFftImpl<T> &fft_;
 };
 
+// rfft::rfft_packed / irfft_packed (rfft.rs:341-420): the same checks and arithmetic as rfft_direct / irfft_direct
+template <typename T>
+Result rfft_packed(RfftPlanner<T> &, const HipFftImpl<T> &fft, std::vector<T> &input, std::vector<Complex<T>> &output,
+                   std::vector<Complex<T>> &scratch)
+{
+    return fft.rfft_with_scratch(input, output, scratch);
+}
+template <typename T>
+Result irfft_packed(RfftPlanner<T> &, const HipFftImpl<T> &fft, std::vector<Complex<T>> &input, std::vector<T> &output,
+                    std::vector<Complex<T>> &scratch)
+{
+    return fft.irfft_with_scratch(input, output, scratch);
+}
+
 // fft::batch / batch_inverse / multi_channel (fft.rs:2156-2191): serial semantics, first error wins
 template <typename T>
 Result batch(const FftImpl<T> &fft, std::vector<std::vector<Complex<T>>> &batches)

@@ -5,10 +5,10 @@ The product is ``kofft_amd/lib/libkofft_hip.so`` (hand-written HIP kernels behin
 interface on top of it.  There is no CPU fallback: without the library every call raises.
 """
 from .api import (DeviceError, fft2d_inplace, fft3d_inplace, flatten_2d, FftError, FftPlan, FftPlanner, FftStrategy, HipFftImpl, IstftStream, RfftPlanner, StftStream, batch,
-                  batch_inverse, frame, hann, inverse_frame, inverse_parallel, istft, multi_channel, multi_channel_inverse, new_fft_impl, parallel, stft, stft_magnitudes)
+                  batch_inverse, frame, hann, inverse_frame, inverse_parallel, irfft_packed, istft, multi_channel, multi_channel_inverse, new_fft_impl, parallel, rfft_packed, stft, stft_magnitudes)
 from ._lib import LibraryMissing, load as load_library
 
 __all__ = ["DeviceError", "fft2d_inplace", "fft3d_inplace", "flatten_2d", "FftError", "FftPlan", "FftPlanner", "FftStrategy", "HipFftImpl", "IstftStream", "RfftPlanner", "StftStream",
-           "batch", "batch_inverse", "frame", "hann", "inverse_frame", "inverse_parallel", "istft", "multi_channel", "multi_channel_inverse", "new_fft_impl",
-           "parallel", "stft", "stft_magnitudes", "LibraryMissing", "load_library"]
+           "batch", "batch_inverse", "frame", "hann", "inverse_frame", "inverse_parallel", "irfft_packed", "istft", "multi_channel", "multi_channel_inverse", "new_fft_impl",
+           "parallel", "rfft_packed", "stft", "stft_magnitudes", "LibraryMissing", "load_library"]
 __version__ = "0.1.0"
