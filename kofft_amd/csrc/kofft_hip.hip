@@ -216,6 +216,19 @@ template <class IO> struct PersistCfg<9, IO> {
     static constexpr bool kInvInLds = IO::kInvInLds, kTwLastInLds = false;
 };
 
+// Workgroups per CU actually launched.  The rfft kernels (misaligned 8200-byte output rows, an extra LDS round trip)
+// stream better with FEWER concurrent rows once the batch no longer fits the 256 MiB Infinity Cache: measured at 4 GiB
+// of input, n = 512 / 1024 / 2048: +6 % / +4 % / +4 % with half the grid (config 3: 3.49 -> 3.37 ms); at 512 MiB the
+// 2048-point kernel loses 10 % with half the grid, the two smaller ones still gain.  STFT and complex want the full grid.
+template <int L, class IO> struct PersistGrid {
+    static int wg_per_cu(int base, size_t) { return base; }
+};
+template <> struct PersistGrid<8, RfftIO<float>> { static int wg_per_cu(int base, size_t) { return base / 2; } };
+template <> struct PersistGrid<9, RfftIO<float>> { static int wg_per_cu(int base, size_t) { return base / 2; } };
+template <> struct PersistGrid<10, RfftIO<float>> {
+    static int wg_per_cu(int base, size_t input_bytes) { return input_bytes > (size_t(1) << 30) ? base / 2 : base; }
+};
+
 template <typename T, int L, int EPI, class IO>
 int launch_persist(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t batch)
 {
@@ -230,7 +243,7 @@ int launch_persist(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t ba
     auto kern = fft_persist_kernel<T, L, RL, EPI, IO, Cfg>;
     KOFFT_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    size_t blocks = (size_t)ctx->num_cus * Cfg::WG_PER_CU;
+    size_t blocks = (size_t)ctx->num_cus * PersistGrid<L, IO>::wg_per_cu(Cfg::WG_PER_CU, batch * sizeof(cpx<T>) << L);
     if (ctx->persist_grid_pct > 0) blocks = blocks * (size_t)ctx->persist_grid_pct / 100;  // measurement knob
     if (blocks < 1) blocks = 1;
     const size_t need = (batch + XPB - 1) / XPB;
