@@ -153,14 +153,13 @@ int launch_wg(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t batch)
     return KOFFT_OK;
 }
 
-// Persistent, prefetching kernels (fft_persist.hip.h): the streaming path for large batches.
-// n = 4096: 256 threads per transform, two workgroups per CU, two LDS exchange buffers each.
-// n = 1024: one wavefront per transform (wave-synchronous exchanges), four per workgroup.
-// Every workgroup walks the batch with a stride of the grid size and keeps the next transform's
-// loads in flight while it computes.
-// Waves per SIMD are set per IO policy: the plain complex n = 1024 kernel fits 3 waves/SIMD (156 VGPRs); the STFT
-// and rfft variants carry window / post-pass operands and spill at 168, so they run 2 waves/SIMD.
-// kInvInLds / kTwLastInLds: see fft_persist.hip.h (PersistState).
+// Persistent, prefetching kernels (fft_persist.hip.h): the streaming path for large batches.  Every workgroup walks the
+// batch with a stride of the grid size and keeps the next transform's loads in flight while it computes.
+// PersistCfg<L, IO> is the per-(size, policy) configuration, each value chosen by same-box A/B measurement:
+//   BLOCK / RL      threads per workgroup, log2 of the points per thread (threads per transform = n >> RL)
+//   MINW            waves per SIMD the kernel must fit (register budget); WG_PER_CU = workgroups launched per CU
+//   kInvInLds       window samples / irfft table in one LDS copy per workgroup instead of registers
+//   kTwLastInLds    the last pass reads its twiddles from an LDS copy of the table (frees 24..30 VGPRs)
 template <int L, class IO> struct PersistCfg;
 template <class IO> struct PersistCfgBase {
     static constexpr int NBUF = 1, RL = 4;
