@@ -840,3 +840,24 @@ def test_fft_plan(fft32, fft64, oracle):
     K.FftPlan(256, K.FftStrategy.Radix4, fft64).fft(yd)
     assert bits_equal(yd, oracle.fft(xd))
     assert np.abs(yd - np.fft.fft(xd)).max() < 1e-10  # ... which IS the DFT, unlike the reference's radix-4 arm
+
+
+def test_host_pointer_pipeline_large_batches(fft32, fft64, oracle):
+    """Host-pointer batches of >= 128 MiB go through the device in eight overlapped chunks (upload / kernel / download
+    on three streams, downloads from a helper thread): results must be those of one pass.  Ragged last chunk included."""
+    rng = seeded(9500)
+    x = rand_c(rng, (16387, 1024))                       # 134 MB each way, 8 chunks of 2049 rows (last: 2044)
+    y = x.copy()
+    fft32.fft_batch(y)
+    assert_parity(y, oracle.fft(x), "pipelined host fft c32", REL_TOL_F32)
+    fft32.fft_batch(y, inverse=True)
+    assert_parity(y, oracle.ifft(oracle.fft(x)), "pipelined host ifft c32", REL_TOL_F32)
+    r = rng.uniform(-1, 1, (12301, 4096)).astype(np.float32)   # 201 MB in, 202 MB out
+    win = oracle.hann(4096)
+    spec = fft32.rfft_batch(r, win)
+    assert_parity(spec, oracle.rfft(r, win), "pipelined host rfft", REL_TOL_F32)
+    assert_parity(fft32.irfft_batch(spec, 4096), oracle.irfft(spec, 4096), "pipelined host irfft", REL_TOL_F32)
+    xd = rand_c(rng, (4099, 2048), np.complex128)        # 134 MB each way in f64
+    yd = xd.copy()
+    fft64.fft_batch(yd)
+    assert_parity(yd, oracle.fft(xd), "pipelined host fft c64", REL_TOL_F64)
