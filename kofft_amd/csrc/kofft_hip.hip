@@ -33,6 +33,7 @@ struct kofft_hip_ctx {
     bool use_persist = true;  // KOFFT_HIP_NO_PERSIST=1 forces the generic kernels (A/B measurements, tests)
     int persist_grid_pct = 0; // KOFFT_HIP_PERSIST_GRID_PCT: scale the persistent grids (measurements only)
     bool big_two_only = false; // KOFFT_HIP_BIG_TWO_FACTORS=1: never split into three factors (A/B measurements)
+    bool zero_copy = true;     // KOFFT_HIP_ZERO_COPY=0: small host calls through staged copies like large ones
     bool host_pipeline = true; // KOFFT_HIP_HOST_PIPELINE=0: host-pointer batches in one upload / kernel / download
     int host_chunks = 0;       // KOFFT_HIP_HOST_CHUNKS: pieces of a pipelined host batch (default 8)
     bool persist_small = true; // KOFFT_HIP_PERSIST_SMALL=0: n = 128, 256 on the generic kernels (A/B measurements)
@@ -46,6 +47,11 @@ struct kofft_hip_ctx {
     // intermediate of the two-factor large-n path (fft_big.hip.h): `big_chunk` transforms at a time
     void *big_tmp = nullptr;
     size_t big_tmp_bytes = 0;
+    // small host-pointer calls (one frame, one transform): a pinned, device-mapped buffer the kernels read and write
+    // directly over PCIe -- one launch and one synchronisation instead of two staged copies around them
+    void *pinned = nullptr;      // host address
+    void *pinned_dev = nullptr;  // the same memory as the device sees it
+    size_t pinned_bytes = 0;
     void *blue_tmp = nullptr;  // zero-padded work buffer of the Bluestein arm
     size_t blue_tmp_bytes = 0;
     size_t big_chunk_bytes = size_t(2048) << 20;  // KOFFT_HIP_BIG_CHUNK_MB; measured: small chunks do not profit from the Infinity Cache, larger launches overlap better
@@ -104,6 +110,31 @@ int get_table(kofft_hip_ctx *ctx, int kind, size_t n, const cpx<T> **out)
     }
     ctx->tables[key] = d;
     *out = static_cast<const cpx<T> *>(d);
+    return KOFFT_OK;
+}
+
+constexpr size_t kZeroCopyMax = size_t(512) << 10;  // bytes per direction up to which a host call goes zero-copy
+// (measured per-call latency, host memory: n = 64 31 -> 17 us, 1024 33 -> 20, 4096 36 -> 22, 65536 95 -> 79; 1 MiB: no gain)
+
+int ensure_pinned(kofft_hip_ctx *ctx, size_t bytes)
+{
+    if (ctx->pinned_bytes >= bytes) return KOFFT_OK;
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    ctx->pinned = ctx->pinned_dev = nullptr;
+    ctx->pinned_bytes = 0;
+    const size_t want = bytes < (size_t(1) << 20) ? (size_t(1) << 20) : bytes;
+    if (hipHostMalloc(&ctx->pinned, want, hipHostMallocMapped) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->pinned = nullptr;
+        return KOFFT_ERR_ALLOC;
+    }
+    if (hipHostGetDevicePointer(&ctx->pinned_dev, ctx->pinned, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipHostFree(ctx->pinned);
+        ctx->pinned = nullptr;
+        return KOFFT_ERR_ALLOC;
+    }
+    ctx->pinned_bytes = want;
     return KOFFT_OK;
 }
 
@@ -633,6 +664,14 @@ int fft_host(kofft_hip_ctx *ctx, T *data, size_t n, size_t batch, int inverse)
     if (!ctx || !data) return KOFFT_ERR_NULL;
     KOFFT_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t bytes = batch * n * 2 * sizeof(T);
+    if (ctx->zero_copy && bytes <= kZeroCopyMax && is_pow2(n) && ensure_pinned(ctx, bytes) == KOFFT_OK) {
+        std::memcpy(ctx->pinned, data, bytes);
+        int zrc = fft_dev<T>(ctx, static_cast<T *>(ctx->pinned_dev), static_cast<T *>(ctx->pinned_dev), n, batch, inverse);
+        if (zrc) return zrc;
+        KOFFT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        std::memcpy(data, ctx->pinned, bytes);
+        return KOFFT_OK;
+    }
     int rc = ensure_stage(ctx, 0, bytes);
     if (rc) return rc;
     T *d = static_cast<T *>(ctx->stage[0]);
@@ -723,6 +762,20 @@ int rfft_host(kofft_hip_ctx *ctx, const T *in, T *out, const T *window, size_t n
     if (!ctx || !in || !out) return KOFFT_ERR_NULL;
     KOFFT_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t in_bytes = batch * n * sizeof(T), out_bytes = batch * (m + 1) * 2 * sizeof(T);
+    if (ctx->zero_copy && in_bytes + out_bytes + n * sizeof(T) <= kZeroCopyMax &&
+        ensure_pinned(ctx, in_bytes + out_bytes + n * sizeof(T) + 512) == KOFFT_OK) {
+        // [input | window | output] in the pinned, device-mapped buffer (256-byte aligned pieces)
+        const size_t o_win = (in_bytes + 255) & ~size_t(255), o_out = (o_win + n * sizeof(T) + 255) & ~size_t(255);
+        char *h = static_cast<char *>(ctx->pinned), *dd = static_cast<char *>(ctx->pinned_dev);
+        std::memcpy(h, in, in_bytes);
+        if (window) std::memcpy(h + o_win, window, n * sizeof(T));
+        int zrc = rfft_dev<T>(ctx, reinterpret_cast<const T *>(dd), reinterpret_cast<T *>(dd + o_out),
+                              window ? reinterpret_cast<const T *>(dd + o_win) : nullptr, n, batch);
+        if (zrc) return zrc;
+        KOFFT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        std::memcpy(out, h + o_out, out_bytes);
+        return KOFFT_OK;
+    }
     int rc = ensure_stage(ctx, 0, in_bytes);
     if (rc) return rc;
     rc = ensure_stage(ctx, 1, out_bytes);
@@ -763,6 +816,16 @@ int irfft_host(kofft_hip_ctx *ctx, const T *in, T *out, size_t n, size_t batch)
     if (!ctx || !in || !out) return KOFFT_ERR_NULL;
     KOFFT_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t in_bytes = batch * (m + 1) * 2 * sizeof(T), out_bytes = batch * n * sizeof(T);
+    if (ctx->zero_copy && in_bytes + out_bytes <= kZeroCopyMax && ensure_pinned(ctx, in_bytes + out_bytes + 256) == KOFFT_OK) {
+        const size_t o_out = (in_bytes + 255) & ~size_t(255);
+        char *h = static_cast<char *>(ctx->pinned), *dd = static_cast<char *>(ctx->pinned_dev);
+        std::memcpy(h, in, in_bytes);
+        int zrc = irfft_dev<T>(ctx, reinterpret_cast<const T *>(dd), reinterpret_cast<T *>(dd + o_out), n, batch);
+        if (zrc) return zrc;
+        KOFFT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        std::memcpy(out, h + o_out, out_bytes);
+        return KOFFT_OK;
+    }
     int rc = ensure_stage(ctx, 0, in_bytes);
     if (rc) return rc;
     rc = ensure_stage(ctx, 1, out_bytes);
@@ -813,6 +876,20 @@ int stft_host(kofft_hip_ctx *ctx, const float *signal, size_t len, const float *
     if (hi < lo) hi = lo;
     const size_t span = hi - lo;
     const size_t out_bytes = count * win_len * 2 * sizeof(float);
+    if (ctx->zero_copy && (span + win_len) * sizeof(float) + out_bytes <= kZeroCopyMax &&
+        ensure_pinned(ctx, (span + win_len) * sizeof(float) + out_bytes + 768) == KOFFT_OK) {
+        // frame() / StftStream / short signals: [samples | window | spectra] in the pinned, device-mapped buffer
+        const size_t o_win = (span * sizeof(float) + 255) & ~size_t(255), o_out = (o_win + win_len * sizeof(float) + 255) & ~size_t(255);
+        char *h = static_cast<char *>(ctx->pinned), *dd = static_cast<char *>(ctx->pinned_dev);
+        if (span) std::memcpy(h, signal + lo, span * sizeof(float));
+        std::memcpy(h + o_win, window, win_len * sizeof(float));
+        int zrc = stft_dev(ctx, reinterpret_cast<const float *>(dd), span, reinterpret_cast<const float *>(dd + o_win), win_len,
+                           start0 - lo, hop, reinterpret_cast<float *>(dd + o_out), count);
+        if (zrc) return zrc;
+        KOFFT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        std::memcpy(out, h + o_out, out_bytes);
+        return KOFFT_OK;
+    }
     int rc = ensure_stage(ctx, 0, (span ? span : 1) * sizeof(float));
     if (rc) return rc;
     rc = ensure_stage(ctx, 1, out_bytes);
@@ -879,6 +956,24 @@ int istft_host(kofft_hip_ctx *ctx, float *frames_data, size_t frames, const floa
     // one staging allocation: [frames | output | scratch | window]
     const size_t a0 = 0, a1 = (fr_bytes + 255) & ~size_t(255), a2 = a1 + ((o_bytes + 255) & ~size_t(255)),
                  a3 = a2 + ((o_bytes + 255) & ~size_t(255)), total = a3 + win_len * sizeof(float) + 256;
+    if (ctx->zero_copy && total <= kZeroCopyMax && ensure_pinned(ctx, total) == KOFFT_OK) {
+        // one frame (IstftStream, inverse_frame) or a short batch: the kernels work on the pinned, device-mapped buffer
+        char *h = static_cast<char *>(ctx->pinned), *dd = static_cast<char *>(ctx->pinned_dev);
+        if (fr_bytes) std::memcpy(h + a0, frames_data, fr_bytes);
+        if (o_bytes) std::memcpy(h + a1, output, o_bytes);
+        if (win_len) std::memcpy(h + a3, window, win_len * sizeof(float));
+        int zrc = istft_dev(ctx, reinterpret_cast<float *>(dd + a0), frames, reinterpret_cast<const float *>(dd + a3), win_len, hop,
+                            reinterpret_cast<float *>(dd + a1), out_len, reinterpret_cast<float *>(dd + a2),
+                            mode == 1 ? scratch_len : out_len, mode, start0);
+        if (zrc) return zrc;
+        KOFFT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (fr_bytes && copy_frames_back) std::memcpy(frames_data, h + a0, fr_bytes);
+        if (o_bytes) {
+            std::memcpy(output, h + a1, o_bytes);
+            if (mode == 1 && scratch) std::memcpy(scratch, h + a2, o_bytes);
+        }
+        return KOFFT_OK;
+    }
     int rc = ensure_stage(ctx, 0, total);
     if (rc) return rc;
     char *base = static_cast<char *>(ctx->stage[0]);
@@ -1054,6 +1149,7 @@ int kofft_hip_create(int device, kofft_hip_ctx **out)
     if (const char *e = getenv("KOFFT_HIP_BIG_TWO_FACTORS")) ctx->big_two_only = (e[0] == '1');
     if (const char *e = getenv("KOFFT_HIP_PERSIST_SMALL")) ctx->persist_small = !(e[0] == '0');
     if (const char *e = getenv("KOFFT_HIP_HOST_PIPELINE")) ctx->host_pipeline = !(e[0] == '0');
+    if (const char *e = getenv("KOFFT_HIP_ZERO_COPY")) ctx->zero_copy = !(e[0] == '0');
     if (const char *e = getenv("KOFFT_HIP_HOST_CHUNKS")) ctx->host_chunks = atoi(e);
     if (const char *e = getenv("KOFFT_HIP_BIG_CHUNK_MB")) {
         const long mb = atol(e);
@@ -1083,6 +1179,7 @@ int kofft_hip_destroy(kofft_hip_ctx *ctx)
         if (ctx->stage[i]) (void)hipFree(ctx->stage[i]);
     if (ctx->big_tmp) (void)hipFree(ctx->big_tmp);
     if (ctx->blue_tmp) (void)hipFree(ctx->blue_tmp);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return KOFFT_OK;
