@@ -158,6 +158,33 @@ struct StridedIO {
     }
 };
 
+// ---- tiled transpose for the long strided axes of ndfft ------------------------------------------------------------
+// dst[b][c][r] = src[b][r][c] for r < rows, c < cols: 32 x 32 tiles through LDS (row padded by one cell), both sides
+// coalesced.  Leading dimensions and per-batch strides in elements.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const cpx<T> *__restrict__ src, cpx<T> *__restrict__ dst, const size_t rows,
+                                                        const size_t cols, const size_t src_ld, const size_t dst_ld,
+                                                        const size_t src_bs, const size_t dst_bs)
+{
+    __shared__ cpx<T> tile[32][33];
+    const size_t b = blockIdx.z;
+    const cpx<T> *s = src + b * src_bs;
+    cpx<T> *d = dst + b * dst_bs;
+    const size_t c0 = (size_t)blockIdx.x * 32, r0 = (size_t)blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+    for (int k = 0; k < 32; k += 8) {
+        const size_t r = r0 + ty + k, c = c0 + tx;
+        if (r < rows && c < cols) tile[ty + k][tx] = ld_stream(s + r * src_ld + c);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 32; k += 8) {
+        const size_t c = c0 + ty + k, r = r0 + tx;
+        if (r < rows && c < cols) st_stream(d + c * dst_ld + r, tile[tx][ty + k]);
+    }
+}
+
 // ---- Bluestein arm for non-power-of-two lengths (fft.rs:1088-1132) --------------------------------
 // a = x * chirp (zero-padded to m = next_pow2(2n-1)); fft_m; a *= fft(b); conj; fft_m; conj; * 1/m; out = a * chirp.
 // The three pointwise steps below use Complex::mul's un-fused form; the two m-point transforms are the ordinary

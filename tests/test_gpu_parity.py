@@ -861,3 +861,22 @@ def test_host_pointer_pipeline_large_batches(fft32, fft64, oracle):
     yd = xd.copy()
     fft64.fft_batch(yd)
     assert_parity(yd, oracle.fft(xd), "pipelined host fft c64", REL_TOL_F64)
+
+
+@pytest.mark.parametrize("depth,rows,cols", [(1, 2048, 16), (1, 1024, 64), (1, 4096, 128), (1024, 2, 8), (4, 1024, 32), (2, 2048, 4)])
+def test_ndfft_long_strided_axes(fft32, fft64, oracle, depth, rows, cols):
+    """Axes of >= 1024 points that are not contiguous go through transpose -> batched transform -> transpose back
+    (panels of lines, several outer blocks per launch); every line is still the reference's 1-D transform."""
+    rng = seeded(1700 + depth + rows + cols)
+    for impl, dt, tol in ((fft32, np.complex64, REL_TOL_F32), (fft64, np.complex128, REL_TOL_F64)):
+        x = rand_c(rng, (depth, rows, cols), dt)
+        if depth > 1:   # z, y, x (ndfft.rs:131-151)
+            want = _oracle_axis(oracle, _oracle_axis(oracle, _oracle_axis(oracle, x, 0), 1), 2)
+        else:           # rows, then columns (ndfft.rs:89-98)
+            want = _oracle_axis(oracle, _oracle_axis(oracle, x, 2), 1)
+        data = x.reshape(-1).copy()
+        impl.fftnd(data, depth, rows, cols)
+        assert_parity(data.reshape(depth, rows, cols), want, f"fftnd {depth}x{rows}x{cols} {np.dtype(dt).name}", tol)
+        impl.fftnd(data, depth, rows, cols, inverse=True)
+        # (the f64 kernels for n <= 16 carry the reference's f32-literal constants: 1e-7, not 1e-13)
+        assert np.max(np.abs(data.reshape(depth, rows, cols) - x)) < (2e-3 if dt == np.complex64 else 1e-6)
