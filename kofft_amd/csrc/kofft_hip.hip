@@ -605,7 +605,9 @@ int pipeline_chunks(kofft_hip_ctx *ctx, size_t nchunks, Up up, Run run, Down dow
     std::atomic<size_t> launched{0};
     std::atomic<int> failed{0};
     const int device = ctx->device;
-    std::thread downloader([&]() {
+    std::thread downloader;
+    try {
+        downloader = std::thread([&]() {
         (void)hipSetDevice(device);
         for (size_t c = 0; c < nchunks; ++c) {
             while (launched.load(std::memory_order_acquire) <= c && !failed.load()) std::this_thread::yield();
@@ -616,7 +618,16 @@ int pipeline_chunks(kofft_hip_ctx *ctx, size_t nchunks, Up up, Run run, Down dow
                 return;
             }
         }
-    });
+        });
+    } catch (...) {  // no helper thread available: the caller falls back to the serial path
+        for (size_t c = 0; c < nchunks; ++c) {
+            (void)hipEventDestroy(uploaded[c]);
+            (void)hipEventDestroy(done[c]);
+        }
+        (void)hipStreamDestroy(s_in);
+        (void)hipStreamDestroy(s_out);
+        return KOFFT_ERR_ALLOC;
+    }
     int rc = KOFFT_OK;
     for (size_t c = 0; c < nchunks && rc == KOFFT_OK && !failed.load(); ++c) {
         if (up(c, s_in) != hipSuccess || hipEventRecord(uploaded[c], s_in) != hipSuccess ||
@@ -680,11 +691,12 @@ int fft_host(kofft_hip_ctx *ctx, T *data, size_t n, size_t batch, int inverse)
     if (use_host_pipeline(ctx, 2 * bytes, batch, n * 2 * sizeof(T))) {
         const size_t chunk = host_chunk_rows(ctx, batch), row = n * 2;
         auto rows = [&](size_t c) { return (batch - c * chunk < chunk) ? batch - c * chunk : chunk; };
-        return pipeline_chunks(
+        const int prc = pipeline_chunks(
             ctx, (batch + chunk - 1) / chunk,
             [&](size_t c, hipStream_t st) { return hipMemcpyAsync(d + c * chunk * row, data + c * chunk * row, rows(c) * row * sizeof(T), hipMemcpyHostToDevice, st); },
             [&](size_t c) { return fft_dev<T>(ctx, d + c * chunk * row, d + c * chunk * row, n, rows(c), inverse); },
             [&](size_t c, hipStream_t st) { return hipMemcpyAsync(data + c * chunk * row, d + c * chunk * row, rows(c) * row * sizeof(T), hipMemcpyDeviceToHost, st); });
+        if (prc != KOFFT_ERR_ALLOC) return prc;  // (no helper thread: serial path below)
     }
     KOFFT_HIP_TRY(ctx, hipMemcpyAsync(d, data, bytes, hipMemcpyHostToDevice, ctx->stream));
     rc = fft_dev<T>(ctx, d, d, n, batch, inverse);
@@ -793,11 +805,12 @@ int rfft_host(kofft_hip_ctx *ctx, const T *in, T *out, const T *window, size_t n
         const size_t chunk = host_chunk_rows(ctx, batch), orow = (m + 1) * 2;
         T *d_in = static_cast<T *>(ctx->stage[0]), *d_out = static_cast<T *>(ctx->stage[1]);
         auto rows = [&](size_t c) { return (batch - c * chunk < chunk) ? batch - c * chunk : chunk; };
-        return pipeline_chunks(
+        const int prc = pipeline_chunks(
             ctx, (batch + chunk - 1) / chunk,
             [&](size_t c, hipStream_t st) { return hipMemcpyAsync(d_in + c * chunk * n, in + c * chunk * n, rows(c) * n * sizeof(T), hipMemcpyHostToDevice, st); },
             [&](size_t c) { return rfft_dev<T>(ctx, d_in + c * chunk * n, d_out + c * chunk * orow, d_win, n, rows(c)); },
             [&](size_t c, hipStream_t st) { return hipMemcpyAsync(out + c * chunk * orow, d_out + c * chunk * orow, rows(c) * orow * sizeof(T), hipMemcpyDeviceToHost, st); });
+        if (prc != KOFFT_ERR_ALLOC) return prc;
     }
     KOFFT_HIP_TRY(ctx, hipMemcpyAsync(ctx->stage[0], in, in_bytes, hipMemcpyHostToDevice, ctx->stream));
     rc = rfft_dev<T>(ctx, static_cast<const T *>(ctx->stage[0]), static_cast<T *>(ctx->stage[1]), d_win, n, batch);
@@ -836,11 +849,12 @@ int irfft_host(kofft_hip_ctx *ctx, const T *in, T *out, size_t n, size_t batch)
         const size_t chunk = host_chunk_rows(ctx, batch), irow = (m + 1) * 2;
         T *d_in = static_cast<T *>(ctx->stage[0]), *d_out = static_cast<T *>(ctx->stage[1]);
         auto rows = [&](size_t c) { return (batch - c * chunk < chunk) ? batch - c * chunk : chunk; };
-        return pipeline_chunks(
+        const int prc = pipeline_chunks(
             ctx, (batch + chunk - 1) / chunk,
             [&](size_t c, hipStream_t st) { return hipMemcpyAsync(d_in + c * chunk * irow, in + c * chunk * irow, rows(c) * irow * sizeof(T), hipMemcpyHostToDevice, st); },
             [&](size_t c) { return irfft_dev<T>(ctx, d_in + c * chunk * irow, d_out + c * chunk * n, n, rows(c)); },
             [&](size_t c, hipStream_t st) { return hipMemcpyAsync(out + c * chunk * n, d_out + c * chunk * n, rows(c) * n * sizeof(T), hipMemcpyDeviceToHost, st); });
+        if (prc != KOFFT_ERR_ALLOC) return prc;
     }
     KOFFT_HIP_TRY(ctx, hipMemcpyAsync(ctx->stage[0], in, in_bytes, hipMemcpyHostToDevice, ctx->stream));
     rc = irfft_dev<T>(ctx, static_cast<const T *>(ctx->stage[0]), static_cast<T *>(ctx->stage[1]), n, batch);
