@@ -33,7 +33,8 @@ struct PlainTw {
     static constexpr int kMinWaves = 1;  // __launch_bounds__ second argument (waves per SIMD the kernel must fit)
     static constexpr int kPersistMaxLog2 = 13;  // largest transform the persistent kernel is built for with this policy
     // smallest one it is USED for (measured against the generic kernel, one box: complex n = 128 / 256 lose 5 %, STFT
-    // gains 22 % / 6 % (n = 64: 20 %), irfft 16 % / 29 % (m = 64: 5 %), rfft n = 512 gains 4 %, n = 256 loses 5 %)
+    // gains 22 % / 6 % (n = 64: 20 %), irfft 16 % / 29 % (m = 64: 5 %), rfft n = 128 .. 512 gains 4 .. 10 % once its grid
+    // is halved -- PersistGrid in kofft_hip.hip)
     static constexpr int kPersistMinLog2 = 9;
     __host__ __device__ bool group_rows_ok() const { return true; }  // per-lane row offsets fit 32 bits
     __device__ __forceinline__ TwPlain tw_map(size_t) const { return {}; }
@@ -237,7 +238,7 @@ template <typename T>
 struct RfftIO : PlainTw {
     static constexpr bool kStreams = true;
     static constexpr bool kPersist = true;
-    static constexpr int kPersistMinLog2 = 8;
+    static constexpr int kPersistMinLog2 = 6;
     static constexpr bool kInvInLds = true;  // window pairs + post-pass table: staged in LDS once per workgroup
     static constexpr bool kLeanRegisters = false;
     using Raw = cpx<T>;

@@ -254,11 +254,14 @@ template <class IO> struct PersistCfg<9, IO> {
 
 // Workgroups per CU actually launched.  The rfft kernels (misaligned 8200-byte output rows, an extra LDS round trip)
 // stream better with FEWER concurrent rows once the batch no longer fits the 256 MiB Infinity Cache: measured at 4 GiB
-// of input, n = 512 / 1024 / 2048: +6 % / +4 % / +4 % with half the grid (config 3: 3.49 -> 3.37 ms); at 512 MiB the
+// of input, n = 512 / 1024 / 2048: +6 % / +4 % / +4 % with half the grid (config 3: 3.49 -> 3.37 ms; n = 128 / 256: the
+// persistent kernel only beats the generic one, by 10 %, with half the grid); at 512 MiB the
 // 2048-point kernel loses 10 % with half the grid, the two smaller ones still gain.  STFT and complex want the full grid.
 template <int L, class IO> struct PersistGrid {
     static int wg_per_cu(int base, size_t) { return base; }
 };
+template <> struct PersistGrid<6, RfftIO<float>> { static int wg_per_cu(int base, size_t) { return base / 2; } };
+template <> struct PersistGrid<7, RfftIO<float>> { static int wg_per_cu(int base, size_t) { return base / 2; } };
 template <> struct PersistGrid<8, RfftIO<float>> { static int wg_per_cu(int base, size_t) { return base / 2; } };
 template <> struct PersistGrid<9, RfftIO<float>> { static int wg_per_cu(int base, size_t) { return base / 2; } };
 template <> struct PersistGrid<10, RfftIO<float>> {
