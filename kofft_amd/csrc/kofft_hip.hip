@@ -308,6 +308,22 @@ int launch_small(kofft_hip_ctx *ctx, const IO &io, size_t batch, const cpx<T> *t
     return KOFFT_OK;
 }
 
+// adjacent columns / rows per workgroup: 128-byte segments (16 x c32, 8 x c64) when the LDS budget allows
+// (measured, c32: 2^15..2^19 0.19 -> 0.225 of the roofline, 2^22..2^24 0.12 -> 0.15)
+#ifndef KOFFT_BIG_XPB
+#define KOFFT_BIG_XPB(T) (sizeof(T) == 4 ? 16 : 8)
+#endif
+template <typename T, class IO, int LS>
+constexpr int big_block()
+{
+    const int tpt = (1 << LS) >> rl_for(LS);
+    int xpb = KOFFT_BIG_XPB(T);
+    while (xpb > 1 && (xpb * tpt > 1024 || (size_t)xpb * (1 << LS) * 8 > 80 * 1024)) xpb /= 2;
+    int block = xpb * tpt;
+    if (block < 64) block = 64;
+    return block;
+}
+
 // Run the n-point transform described by `io` (n a power of two >= 1) over `batch` units.
 template <typename T, int EPI, class IO>
 int dispatch(kofft_hip_ctx *ctx, const IO &io, size_t n, size_t batch)
@@ -350,8 +366,9 @@ int dispatch(kofft_hip_ctx *ctx, const IO &io, size_t n, size_t batch)
         }
     }
     switch (L) {
+    // lane-over-lines policies (strided axes): as many adjacent lines per workgroup as big_block allows (128-byte segments)
 #define KOFFT_CASE(LL) \
-    case LL: return launch_wg<T, LL, EPI>(ctx, io, tw, batch);
+    case LL: return launch_wg<T, LL, EPI, IO, (IO::kSlotMinor ? big_block<T, IO, LL>() : 0)>(ctx, io, tw, batch);
         KOFFT_CASE(5)
         KOFFT_CASE(6)
         KOFFT_CASE(7)
@@ -373,22 +390,6 @@ int dispatch(kofft_hip_ctx *ctx, const IO &io, size_t n, size_t batch)
 // large n: two factors (fft_big.hip.h)
 // ---------------------------------------------------------------------------------
 template <typename T> constexpr int max_log2_big() { return 26; }
-
-// adjacent columns / rows per workgroup: 128-byte segments (16 x c32, 8 x c64) when the LDS budget allows
-// (measured, c32: 2^15..2^19 0.19 -> 0.225 of the roofline, 2^22..2^24 0.12 -> 0.15)
-#ifndef KOFFT_BIG_XPB
-#define KOFFT_BIG_XPB(T) (sizeof(T) == 4 ? 16 : 8)
-#endif
-template <typename T, class IO, int LS>
-constexpr int big_block()
-{
-    const int tpt = (1 << LS) >> rl_for(LS);
-    int xpb = KOFFT_BIG_XPB(T);
-    while (xpb > 1 && (xpb * tpt > 1024 || (size_t)xpb * (1 << LS) * 8 > 80 * 1024)) xpb /= 2;
-    int block = xpb * tpt;
-    if (block < 64) block = 64;
-    return block;
-}
 
 // Launch the generic kernel for a sub-transform of log2 size LS with an arbitrary IO policy.
 template <typename T, class IO>
