@@ -34,7 +34,7 @@ struct kofft_hip_ctx {
     int persist_grid_pct = 0; // KOFFT_HIP_PERSIST_GRID_PCT: scale the persistent grids (measurements only)
     bool big_two_only = false; // KOFFT_HIP_BIG_TWO_FACTORS=1: never split into three factors (A/B measurements)
     bool nd_transpose = true;  // KOFFT_HIP_ND_TRANSPOSE=0: long strided axes through the strided kernel
-    int nd_transpose_min = 1024;  // KOFFT_HIP_ND_TRANSPOSE_MIN: shortest axis that takes the transpose route
+    int nd_transpose_min = 4096;  // KOFFT_HIP_ND_TRANSPOSE_MIN: shortest axis that takes the transpose route (measured: 1024 loses, 2048 ties)
     bool zero_copy = true;     // KOFFT_HIP_ZERO_COPY=0: small host calls through staged copies like large ones
     bool host_pipeline = true; // KOFFT_HIP_HOST_PIPELINE=0: host-pointer batches in one upload / kernel / download
     int host_chunks = 0;       // KOFFT_HIP_HOST_CHUNKS: pieces of a pipelined host batch (default 8)
@@ -1065,8 +1065,8 @@ int fft_axis_dev(kofft_hip_ctx *ctx, T *d_data, size_t len, size_t lines, size_t
                  int inverse)
 {
     if (len <= 1 || lines == 0) return KOFFT_OK;  // fft of one element: nothing to do (fft.rs:1059)
-    // Long axes: the strided kernel can hold only 8, 4, 2, 1 adjacent lines of 2^10 .. 2^13 points in LDS, i.e. 64- to
-    // 8-byte segments.  Instead: transpose a panel of lines into contiguous rows, run the batched (persistent) kernels
+    // Long axes: the strided kernel can hold only 2 or 1 adjacent lines of 2^12 / 2^13 points in LDS, i.e. 16- and 8-byte
+    // segments (8 lines at 2^10 still beat this route, 4 lines at 2^11 tie with it).  Instead: transpose a panel of lines into contiguous rows, run the batched (persistent) kernels
     // on it, transpose back -- four coalesced passes instead of two scattered ones (4096 x 4096 c32: 0.45 -> 0.2x ms).
     // Every line still goes through the same 1-D transform, so the results are unchanged.
     if (ctx->nd_transpose && len >= (size_t)ctx->nd_transpose_min && stride == inner && lines * len * sizeof(cpx<T>) >= (size_t(16) << 20)) {

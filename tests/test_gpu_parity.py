@@ -863,10 +863,12 @@ def test_host_pointer_pipeline_large_batches(fft32, fft64, oracle):
     assert_parity(yd, oracle.fft(xd), "pipelined host fft c64", REL_TOL_F64)
 
 
-@pytest.mark.parametrize("depth,rows,cols", [(1, 2048, 16), (1, 1024, 64), (1, 4096, 128), (1024, 2, 8), (4, 1024, 32), (2, 2048, 4)])
+@pytest.mark.parametrize("depth,rows,cols", [(1, 2048, 16), (1, 1024, 64), (1, 4096, 128), (1024, 2, 8), (4, 1024, 32), (2, 2048, 4),
+                                             (1, 4096, 512), (2, 4096, 256), (4096, 2, 256)])
 def test_ndfft_long_strided_axes(fft32, fft64, oracle, depth, rows, cols):
-    """Axes of >= 1024 points that are not contiguous go through transpose -> batched transform -> transpose back
-    (panels of lines, several outer blocks per launch); every line is still the reference's 1-D transform."""
+    """Long axes that are not contiguous: the strided kernel up to 2048 points; from 4096 points (and 16 MiB of data: the
+    last three cases, one with two outer blocks) transpose -> batched transform -> transpose back.  Every line is still
+    the reference's 1-D transform."""
     rng = seeded(1700 + depth + rows + cols)
     for impl, dt, tol in ((fft32, np.complex64, REL_TOL_F32), (fft64, np.complex128, REL_TOL_F64)):
         x = rand_c(rng, (depth, rows, cols), dt)

@@ -24,5 +24,7 @@ def run(depth, rows, cols):
     axes = 2 if depth == 1 else 3
     gbs = axes * 2 * x.numel() * 4 / ms / 1e6
     print(f"{depth} x {rows} x {cols}: {ms:8.3f} ms, {gbs:7.0f} GB/s over {axes} axis passes = {gbs/8000:.3f} of the roofline per pass")
-for shape in ((1, 4096, 4096), (1, 1024, 1024), (1, 8192, 2048), (1, 512, 16384), (256, 256, 256), (64, 512, 512)):
+import os
+shapes = ((1, 4096, 4096), (1, 1024, 1024), (1, 8192, 2048), (1, 512, 16384), (256, 256, 256), (64, 512, 512), (1, 1024, 16384), (1, 2048, 8192), (1024, 128, 128))
+for shape in shapes:
     run(*shape)
