@@ -189,6 +189,58 @@ __global__ __launch_bounds__(256) void transpose_kernel(const cpx<T> *__restrict
 // a = x * chirp (zero-padded to m = next_pow2(2n-1)); fft_m; a *= fft(b); conj; fft_m; conj; * 1/m; out = a * chirp.
 // The three pointwise steps below use Complex::mul's un-fused form; the two m-point transforms are the ordinary
 // power-of-two kernels.  INVERSE folds ifft's conj-in / conj-scale-out (fft.rs:1163-1172) around the same steps.
+// Fused forms for m <= one workgroup's transform (n <= 8192 f32 / 4096 f64): the three pointwise steps ride on the two
+// m-point transforms' loads and stores -- x is read once (n values), the padded intermediate is written and read once
+// (m values), the result is written once (n values): 2n + 2m complex values of traffic instead of 2n + 8m.
+// Same operations per element in the same order as the kernels below.
+template <typename T, bool INVERSE>
+struct BlueFirstIO : PlainTw {  // load: a = x * chirp, zero-padded to m; store: (a * fft(b)), conjugated (ifft's way in)
+    static constexpr bool kStreams = false;
+    static constexpr bool kPersist = false;
+    const cpx<T> *__restrict__ in;
+    cpx<T> *__restrict__ tmp;
+    const cpx<T> *__restrict__ chirp;
+    const cpx<T> *__restrict__ bfft;
+    int n, m;
+    __device__ __forceinline__ cpx<T> load(size_t xf, int i) const
+    {
+        const int ic = i < n ? i : n - 1;  // branch-free: clamp the address, select the value
+        cpx<T> x = ld_stream(in + xf * (size_t)n + ic);
+        if (INVERSE) x.im = -x.im;
+        const cpx<T> v = cmul(x, chirp[ic]);
+        return i < n ? v : mk<T>(T(0), T(0));
+    }
+    __device__ __forceinline__ void store(size_t xf, int o, cpx<T> v) const
+    {
+        cpx<T> w = cmul(v, bfft[o]);
+        w.im = -w.im;
+        tmp[xf * (size_t)m + o] = w;  // read back by the second transform: plain store
+    }
+};
+template <typename T, bool INVERSE>
+struct BlueSecondIO : PlainTw {  // store: conj, * 1/m (ifft's way out), * chirp; only the first n values exist
+    static constexpr bool kStreams = false;
+    static constexpr bool kPersist = false;
+    const cpx<T> *__restrict__ tmp;
+    cpx<T> *__restrict__ out;
+    const cpx<T> *__restrict__ chirp;
+    int n, m;
+    T scale_m, scale_n;
+    __device__ __forceinline__ cpx<T> load(size_t xf, int i) const { return ld_stream(tmp + xf * (size_t)m + i); }
+    __device__ __forceinline__ void store(size_t xf, int o, cpx<T> v) const
+    {
+        if (o >= n) return;
+        v.im = -v.im;
+        v = mk<T>(v.re * scale_m, v.im * scale_m);
+        cpx<T> r = cmul(v, chirp[o]);
+        if (INVERSE) {
+            const T im = -r.im;
+            r = mk<T>(r.re * scale_n, im * scale_n);
+        }
+        st_stream(out + xf * (size_t)n + o, r);
+    }
+};
+
 template <typename T, bool INVERSE>
 __global__ __launch_bounds__(256) void bluestein_pre_kernel(const cpx<T> *__restrict__ in, cpx<T> *__restrict__ a,
                                                             const cpx<T> *__restrict__ chirp, const size_t n, const size_t m,

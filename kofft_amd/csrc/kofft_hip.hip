@@ -33,6 +33,7 @@ struct kofft_hip_ctx {
     bool use_persist = true;  // KOFFT_HIP_NO_PERSIST=1 forces the generic kernels (A/B measurements, tests)
     int persist_grid_pct = 0; // KOFFT_HIP_PERSIST_GRID_PCT: scale the persistent grids (measurements only)
     bool big_two_only = false; // KOFFT_HIP_BIG_TWO_FACTORS=1: never split into three factors (A/B measurements)
+    bool blue_fused = true;    // KOFFT_HIP_BLUESTEIN_FUSED=0: pointwise steps as separate kernels at every size
     bool nd_transpose = true;  // KOFFT_HIP_ND_TRANSPOSE=0: long strided axes through the strided kernel
     int nd_transpose_min = 4096;  // KOFFT_HIP_ND_TRANSPOSE_MIN: shortest axis that takes the transpose route (measured: 1024 loses, 2048 ties)
     bool zero_copy = true;     // KOFFT_HIP_ZERO_COPY=0: small host calls through staged copies like large ones
@@ -540,6 +541,15 @@ int fft_bluestein_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, siz
         const size_t nb = (batch - b0 < chunk) ? batch - b0 : chunk;
         const cpx<T> *src = reinterpret_cast<const cpx<T> *>(d_in) + b0 * n;
         cpx<T> *dst = reinterpret_cast<cpx<T> *>(d_out) + b0 * n;
+        if (ctx->blue_fused && m <= (size_t(1) << max_log2<T>())) {
+            BlueFirstIO<T, INVERSE> io1{{}, src, a, chirp, bfft, (int)n, (int)m};
+            rc = dispatch<T, EPI_STORE>(ctx, io1, m, nb);
+            if (rc) return rc;
+            BlueSecondIO<T, INVERSE> io2{{}, a, dst, chirp, (int)n, (int)m, scale_m, scale_n};
+            rc = dispatch<T, EPI_STORE>(ctx, io2, m, nb);
+            if (rc) return rc;
+            continue;
+        }
         const size_t tm = nb * m, tn = nb * n;
         hipLaunchKernelGGL((bluestein_pre_kernel<T, INVERSE>), dim3((unsigned)((tm + 255) / 256)), dim3(256), 0, ctx->stream, src, a,
                            chirp, n, m, tm);
@@ -1216,6 +1226,7 @@ int kofft_hip_create(int device, kofft_hip_ctx **out)
     if (const char *e = getenv("KOFFT_HIP_HOST_PIPELINE")) ctx->host_pipeline = !(e[0] == '0');
     if (const char *e = getenv("KOFFT_HIP_ZERO_COPY")) ctx->zero_copy = !(e[0] == '0');
     if (const char *e = getenv("KOFFT_HIP_ND_TRANSPOSE")) ctx->nd_transpose = !(e[0] == '0');
+    if (const char *e = getenv("KOFFT_HIP_BLUESTEIN_FUSED")) ctx->blue_fused = !(e[0] == '0');
     if (const char *e = getenv("KOFFT_HIP_ND_TRANSPOSE_MIN")) ctx->nd_transpose_min = atoi(e);
     if (const char *e = getenv("KOFFT_HIP_HOST_CHUNKS")) ctx->host_chunks = atoi(e);
     if (const char *e = getenv("KOFFT_HIP_BIG_CHUNK_MB")) {
