@@ -165,11 +165,20 @@ __device__ __forceinline__ void persist_transform(const typename IO::Raw *raw, c
     using FirstG = PassGeom<L, RL, 0>;
 
     cpx<T> cur[R];
+    constexpr int GRP = TPT >= 64 ? 1 : 64 / TPT;
+    if (io.inside(xf0 + (GRP - 1))) {  // wave-uniform: every frame of the group lies inside the signal -> no range select
 #pragma unroll
-    for (int u = 0; u < R; ++u) {
-        const int i = FirstG::in_index(0, u) + tau;
-        if constexpr (CFG::kInvInLds) cur[u] = io.finish(xf, i, raw[u], (st.inv_lds + tau)[FirstG::in_index(0, u)]);
-        else cur[u] = io.finish(xf, i, raw[u], st.inv[u]);
+        for (int u = 0; u < R; ++u) {
+            if constexpr (CFG::kInvInLds) cur[u] = io.finish_in(raw[u], (st.inv_lds + tau)[FirstG::in_index(0, u)]);
+            else cur[u] = io.finish_in(raw[u], st.inv[u]);
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const int i = FirstG::in_index(0, u) + tau;
+            if constexpr (CFG::kInvInLds) cur[u] = io.finish(xf, i, raw[u], (st.inv_lds + tau)[FirstG::in_index(0, u)]);
+            else cur[u] = io.finish(xf, i, raw[u], st.inv[u]);
+        }
     }
 
     persist_compute_p0<T, L, RL>(cur, tw);

@@ -100,6 +100,8 @@ struct ComplexIO : PlainTw {
         if (INVERSE) v.im = -v.im;
         return v;
     }
+    __device__ __forceinline__ bool inside(size_t) const { return true; }
+    __device__ __forceinline__ cpx<T> finish_in(Raw v, Inv w) const { return finish(0, 0, v, w); }
     __device__ __forceinline__ cpx<T> load(size_t xf, int i) const { return finish(xf, i, fetch(xf, i), {}); }
     __device__ __forceinline__ void store(size_t xf, int o, cpx<T> v) const
     {
@@ -183,6 +185,9 @@ struct StftIO : PlainTw {
     {
         return mk<float>(in_range(xf, i) ? x * w : 0.0f, 0.0f);  // past the end: exactly +0, whatever the window holds
     }
+    // a frame that lies wholly inside the signal needs no per-sample range test (4 VALU instructions per sample)
+    __device__ __forceinline__ bool inside(size_t xf) const { return start0 + xf * hop + (size_t)n <= len; }
+    __device__ __forceinline__ cpx<float> finish_in(Raw x, Inv w) const { return mk<float>(x * w, 0.0f); }
     __device__ __forceinline__ cpx<float> load(size_t xf, int i) const { return finish(xf, i, fetch(xf, i), invariant(i)); }
     __device__ __forceinline__ void store(size_t xf, int o, cpx<float> v) const
     {
@@ -302,6 +307,8 @@ struct RfftIO : PlainTw {
         return window ? reinterpret_cast<const cpx<T> *>(window)[i] : mk<T>(T(1), T(1));
     }
     __device__ __forceinline__ cpx<T> finish(size_t, int, Raw v, Inv w) const { return mk<T>(v.re * w.re, v.im * w.im); }
+    __device__ __forceinline__ bool inside(size_t) const { return true; }
+    __device__ __forceinline__ cpx<T> finish_in(Raw v, Inv w) const { return finish(0, 0, v, w); }
     __device__ __forceinline__ cpx<T> load(size_t xf, int i) const { return finish(xf, i, fetch(xf, i), invariant(i)); }
     // X[k] for 1 <= k < m from Y[k], Y[m-k] and W[k]  (rfft.rs:454-463)
     __device__ __forceinline__ cpx<T> post_w(cpx<T> w, cpx<T> a, cpx<T> ymk) const
@@ -377,6 +384,8 @@ struct IrfftIO : PlainTw {
     __device__ __forceinline__ unsigned out_row_bytes() const { return (unsigned)m * sizeof(cpx<T>); }
     __device__ __forceinline__ Inv invariant(int k) const { return rtab[k]; }
     __device__ __forceinline__ cpx<T> finish(size_t, int k, Raw r, Inv tw) const { return pre(k, r.a, r.rb, tw); }
+    __device__ __forceinline__ bool inside(size_t) const { return false; }  // finish needs the element index: one form only
+    __device__ __forceinline__ cpx<T> finish_in(Raw r, Inv tw) const { return pre(1, r.a, r.rb, tw); }
     // scratch[k] of irfft_direct (rfft.rs:487-506) from input[k], input[m-k], W[k]; then ifft's conj on the way in
     __device__ __forceinline__ cpx<T> pre(int k, cpx<T> a, cpx<T> rb, cpx<T> tw) const
     {
@@ -556,10 +565,15 @@ __global__ __launch_bounds__(BLOCK, (IO::kMinWaves > 1 && BLOCK == 512 && L >= 9
                 typename IO::Raw raw[R];
 #pragma unroll
                 for (int u = 0; u < R; ++u) raw[u] = io.fetch_d(d, lane_bytes, G0::in_index(0, u));
+                if (io.inside(blk * XPB + (XPB - 1))) {  // workgroup-uniform: every frame of the workgroup is complete
 #pragma unroll
-                for (int u = 0; u < R; ++u) {
-                    const int i = G0::in_index(tau, u);
-                    v[u] = io.finish(xf, i, raw[u], io.invariant(i));
+                    for (int u = 0; u < R; ++u) v[u] = io.finish_in(raw[u], io.invariant(G0::in_index(tau, u)));
+                } else {
+#pragma unroll
+                    for (int u = 0; u < R; ++u) {
+                        const int i = G0::in_index(tau, u);
+                        v[u] = io.finish(xf, i, raw[u], io.invariant(i));
+                    }
                 }
                 fetched = true;
             }
