@@ -4,26 +4,39 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Both forms run N ranks, one per GPU.  Without WORLD_SIZE in the environment and with --gpus N > 1 this
+script is the launcher: BEFORE importing torch or touching the GPU it starts N fresh child processes of
+itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set), waits for them, relays rank 0's
+JSON line and exits non-zero if any child failed.  Nothing is ever exec'ed from a process that has
+initialised the GPU.
+
 A "step" is one pass of the hot path over one batch: every rank transforms its own 65 536 x 4096
 c32 batch (BASELINE config #2, 2 GiB, resident in HBM), reading a pristine input buffer and writing
 the spectra to a second buffer (same kernel and bytes as the in-place call, but repeated steps do
 not overflow f32).  Batches shard across ranks with no data-path collective (weak scaling); the only
 collectives are the barriers of the timing protocol and a MAX over ranks of the elapsed time.
 
-One JSON line is printed by rank 0; see DESIGN.md "Measurement" for how each field is produced.
-torch is plumbing only (device memory, streams, torch.distributed); the transform is libkofft_hip.so.
+Timing: W warm-up steps, then blocks of EXACTLY K steps, each block bracketed by barrier +
+torch.cuda.synchronize() on both sides and reduced with MAX over ranks.  One block is the contract; the
+block is repeated until --min-seconds of timed work have run (so that utilisation sampling from outside
+sees a busy GPU) and the line reports the MEDIAN block (`blocks_ms_per_step` lists all of them).
+
+One JSON line is printed by rank 0.  At N = 1 it also carries `workloads`: BASELINE configs #3, #4, #5
+measured in the same process with the same protocol (at N > 1: config #4 with its RCCL all-gather).
+See DESIGN.md "Measurement" for how each field is produced.  torch is plumbing only (device memory,
+streams, torch.distributed); the transform is libkofft_hip.so.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
 from pathlib import Path
-
-import numpy as np
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
@@ -31,7 +44,6 @@ sys.path.insert(0, str(ROOT))
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec per GPU
 
 WORKLOADS = {
-    # name: (description, n, batch, algorithmic bytes per unit, unit of `value`)
     "fft4096": "batched 65536 x 4096-pt Complex32 forward FFT (BASELINE config #2)",
     "rfft2048": "batched 2^20 x 2048-pt f32 rfft + Hann (BASELINE config #3)",
     "stft1024": "STFT 28.8M-sample f32 stream, 1024-pt Hann, hop 256 (BASELINE config #4, frames sharded)",
@@ -39,7 +51,7 @@ WORKLOADS = {
 }
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -49,10 +61,94 @@ def parse():
                          "(measured: per-launch time falls 1.17 -> 0.81 ms over the first ~40 ms of load)")
     ap.add_argument("--workload", default="fft4096", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override per-GPU batch (debug only; invalidates the metric)")
+    ap.add_argument("--min-seconds", type=float, default=2.0,
+                    help="repeat the K-step block until this much timed work has run (0: exactly one block)")
+    ap.add_argument("--all-workloads", dest="extras", action="store_true", default=None,
+                    help="also measure the other BASELINE configs into `workloads` (default at --workload fft4096)")
+    ap.add_argument("--no-extra-workloads", dest="extras", action="store_false")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inplace", action="store_true", help="fft4096 only: transform the buffer in place (values overflow after ~10 steps; timing study only)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work for the cpu_baseline sample")
-    return ap.parse_args()
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launcher self-test: every rank prints its rendezvous environment and exits without touching a GPU")
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` with no WORLD_SIZE starts the N ranks itself
+# ---------------------------------------------------------------------------------------------------
+RANK_ENV = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")
+
+
+def free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return int(s.getsockname()[1])
+
+
+def launch_ranks(n: int, argv: list[str]) -> int:
+    """Start n children of this script, one per GPU.  The parent makes no GPU call (it never imports torch)."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "KOFFT_BENCH_LAUNCHED": "1"})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this host driver
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + argv, env=env,
+                                      stdout=subprocess.PIPE, stderr=None, text=True))
+    outs: list[str] = [""] * n
+
+    def drain(i):
+        outs[i] = procs[i].stdout.read()
+
+    ths = [threading.Thread(target=drain, args=(i,)) for i in range(n)]
+    for t in ths:
+        t.start()
+    # one failed rank would leave the others waiting in a collective: stop them once any child has failed
+    rcs = [None] * n
+    while any(rc is None for rc in rcs):
+        for i, p in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = p.poll()
+        if any(rc not in (None, 0) for rc in rcs):
+            time.sleep(5.0)
+            for i, p in enumerate(procs):
+                if rcs[i] is None and p.poll() is None:
+                    p.terminate()  # exactly the children started above
+            for i, p in enumerate(procs):
+                if rcs[i] is None:
+                    try:
+                        rcs[i] = p.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        rcs[i] = p.wait()
+            break
+        time.sleep(0.05)
+    for t in ths:
+        t.join()
+    for i in range(1, n):  # other ranks' stdout is diagnostics only
+        if outs[i].strip():
+            sys.stderr.write("".join(f"[rank {i}] {ln}\n" for ln in outs[i].splitlines()))
+    lines = [ln for ln in outs[0].splitlines() if ln.startswith("{")]
+    for ln in outs[0].splitlines():
+        if not ln.startswith("{"):
+            sys.stderr.write(f"[rank 0] {ln}\n")
+    bad = [i for i, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        sys.stderr.write(f"bench.py launcher: ranks {bad} failed (exit codes {[rcs[i] for i in bad]})\n")
+        return 1
+    if not lines:
+        sys.stderr.write("bench.py launcher: rank 0 printed no JSON line\n")
+        return 1
+    print(lines[-1], flush=True)
+    return 0
+
+
+def dry_rank() -> None:
+    """--dry-launch: what this rank was given, no GPU call, no torch import."""
+    print(json.dumps({"dry_launch": True, **{k: os.environ.get(k) for k in RANK_ENV},
+                      "pid": os.getpid(), "torch_imported": "torch" in sys.modules}), flush=True)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -71,6 +167,8 @@ def host_cores() -> int:
 
 
 def cpu_baseline_fft4096(target_seconds: float):
+    import numpy as np
+
     from oracle import pyoracle as ko
 
     n = 4096
@@ -116,130 +214,99 @@ def cpu_baseline_fft4096(target_seconds: float):
         "kind": "port",
         "sample": f"{transforms} x 4096-pt c32 transforms ({cores} threads x {reps} calls x {chunk}, one planner per call), "
                   f"oracle/ C restatement of kofft's Stockham path (-O2, no FMA), busiest thread {dt:.1f} s",
+        "reference_published": "kofft's own benchmarks/README.md:27: 1.046 ms per 4096-pt transform, one thread = 0.0039 GPoints/s "
+                               "(other hardware; the port above is ~36x faster per core)",
     }
 
 
-def main():
-    args = parse()
-    import torch
-    import torch.distributed as dist
+# ---------------------------------------------------------------------------------------------------
+# one rank
+# ---------------------------------------------------------------------------------------------------
+class Workload:
+    """Device-resident inputs and the launch closure of one BASELINE configuration."""
 
-    import kofft_amd
+    def __init__(self, name, args, rank, world, dev, stream, fft32, fft64, batch_override=0):
+        import numpy as np
+        import torch
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP library is the only implementation of this path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    if args.gpus != world and rank == 0:
-        print(f"# note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+        import kofft_amd
 
-    fft = kofft_amd.HipFftImpl(np.float32, device=local_rank)
-    # A dedicated (non-default) torch stream: the library launches on it and the HIP events below are
-    # recorded on the same stream, so each event pair brackets exactly one launch.
-    stream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(stream)
-    assert stream.cuda_stream != 0
-    fft.set_stream(stream.cuda_stream)
+        self.name = name
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(0x6B6F666674 + 2 + rank)
+        self.allgather = None
+        if name == "fft4096":
+            n, batch = 4096, batch_override or 65536
+            src = torch.empty((batch, n, 2), dtype=torch.float32, device=dev).uniform_(-1.0, 1.0, generator=gen)
+            dst = torch.empty_like(src)
+            self.units_per_step = batch * n                      # complex points
+            self.alg_bytes = 16 * self.units_per_step            # 8 B read + 8 B written per point (SURVEY 8d)
+            self.unit = "GPoints/s"
+            self.metric = "batched 4096-pt c32 FFT throughput, GPoints/s (achieved HBM GB/s: roofline.achieved)"
+            self.launch = lambda: fft32.fft_dev_oop(src.data_ptr(), dst.data_ptr(), n, batch, False)
+            if args.inplace:
+                self.launch = lambda: fft32.fft_dev(src.data_ptr(), n, batch, False)
+            self.cfg = {"workload": WORKLOADS[name], "n": n, "batch_per_gpu": batch, "layout": "interleaved re/im, contiguous",
+                        "direction": "forward", "sharding": f"batch x{world}, no collective"}
+            self.dtype, self.scaling = "f32", "weak"
+            self.kernels_per_step = 1
+        elif name == "rfft2048":
+            n, batch = 2048, batch_override or (1 << 20)
+            src = torch.empty((batch, n), dtype=torch.float32, device=dev).uniform_(-1.0, 1.0, generator=gen)
+            dst = torch.empty((batch, n // 2 + 1, 2), dtype=torch.float32, device=dev)
+            win = torch.from_numpy(kofft_amd.hann(n)).to(dev)
+            self.units_per_step = batch * n                      # real samples
+            self.alg_bytes = batch * (4 * n + 8 * (n // 2 + 1))
+            self.unit = "GSamples/s"
+            self.metric = "batched 2048-pt f32 rfft + Hann throughput"
+            self.launch = lambda: fft32.rfft_dev(src.data_ptr(), dst.data_ptr(), win.data_ptr(), n, batch)
+            self.cfg = {"workload": WORKLOADS[name], "n": n, "batch_per_gpu": batch, "sharding": f"batch x{world}, no collective"}
+            self.dtype, self.scaling = "f32", "weak"
+            self.kernels_per_step = 1
+        elif name == "c64_2p20":
+            n, batch = 1 << 20, batch_override or 1024
+            src = torch.empty((batch, n, 2), dtype=torch.float64, device=dev).uniform_(-1.0, 1.0, generator=gen)
+            dst = torch.empty_like(src)
+            self.units_per_step = batch * n
+            self.alg_bytes = 32 * self.units_per_step            # 16 B read + 16 B written per point (SURVEY 8d)
+            self.unit = "GPoints/s"
+            self.metric = "batched 2^20-pt Complex64 forward FFT throughput"
+            self.launch = lambda: fft64.fft_dev_oop(src.data_ptr(), dst.data_ptr(), n, batch, False)
+            self.cfg = {"workload": WORKLOADS[name], "n": n, "batch_per_gpu": batch, "sharding": f"batch x{world}, no collective",
+                        "passes_over_hbm": 2}
+            self.dtype, self.scaling = "f64", "weak"
+            self.kernels_per_step = None  # several kernels per step: see roofline.kernels_per_step in the line
+        else:
+            total_len, win_len, hop = 28_800_000, 1024, 256
+            from kofft_amd.dist import frames_required, shard_range
 
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(0x6B6F666674 + 2 + rank)
+            frames_total = frames_required(total_len, hop)
+            f0, f1 = shard_range(frames_total, rank, world)
+            sgen = torch.Generator(device=dev)
+            sgen.manual_seed(0x6B6F666674 + 4)  # ONE signal, identical on every rank (frames of the same stream are sharded)
+            t = torch.arange(total_len, dtype=torch.float32, device=dev)
+            sig = 0.5 * torch.sin(2 * np.pi * 440.0 * t / 48000.0) + 0.25 * torch.empty_like(t).uniform_(-1, 1, generator=sgen)
+            del t
+            win = torch.from_numpy(kofft_amd.hann(win_len)).to(dev)
+            count = f1 - f0
+            dst = torch.empty((count, win_len, 2), dtype=torch.float32, device=dev)
+            self.units_per_step = count * win_len                # output complex points of this rank
+            self.alg_bytes = 4 * min(total_len - f0 * hop, (count - 1) * hop + win_len) + 8 * self.units_per_step
+            self.unit = "GPoints/s"
+            self.metric = "STFT 1024-pt Hann hop-256 throughput (output points, compute only)"
+            self.launch = lambda: fft32.stft_dev(sig.data_ptr(), total_len, win.data_ptr(), win_len, hop, dst.data_ptr(), f0, count)
+            self.cfg = {"workload": WORKLOADS[name], "signal_len": total_len, "win_len": win_len, "hop": hop,
+                        "frames_total": frames_total, "sharding": f"frames x{world}, strong", "collective": "none in the timed region"}
+            self.dtype, self.scaling = "f32", "strong"
+            self.kernels_per_step = 1
+            self._gather = (frames_total, win_len, count, dst)
+        self._keep = (src, dst) if name != "stft1024" else (sig, win, dst)
 
-    if args.workload == "fft4096":
-        n, batch = 4096, args.batch or 65536
-        src = torch.empty((batch, n, 2), dtype=torch.float32, device=dev).uniform_(-1.0, 1.0, generator=gen)
-        dst = torch.empty_like(src)
-        units_per_step = batch * n                      # complex points
-        alg_bytes = 16 * units_per_step                 # 8 B read + 8 B written per point
-        unit = "GPoints/s"
-        metric = "batched 4096-pt c32 FFT throughput, GPoints/s (achieved HBM GB/s: roofline.achieved)"
-        launch = lambda: fft.fft_dev_oop(src.data_ptr(), dst.data_ptr(), n, batch, False)  # noqa: E731
-        if args.inplace:
-            launch = lambda: fft.fft_dev(src.data_ptr(), n, batch, False)  # noqa: E731
-        cfg = {"workload": WORKLOADS["fft4096"], "n": n, "batch_per_gpu": batch, "layout": "interleaved re/im, contiguous",
-               "direction": "forward", "sharding": f"batch x{world}, no collective"}
-    elif args.workload == "rfft2048":
-        n, batch = 2048, args.batch or (1 << 20)
-        src = torch.empty((batch, n), dtype=torch.float32, device=dev).uniform_(-1.0, 1.0, generator=gen)
-        dst = torch.empty((batch, n // 2 + 1, 2), dtype=torch.float32, device=dev)
-        win = torch.from_numpy(kofft_amd.hann(n)).to(dev)
-        units_per_step = batch * n                      # real samples
-        alg_bytes = batch * (4 * n + 8 * (n // 2 + 1))
-        unit = "GSamples/s"
-        metric = "batched 2048-pt f32 rfft + Hann throughput"
-        launch = lambda: fft.rfft_dev(src.data_ptr(), dst.data_ptr(), win.data_ptr(), n, batch)  # noqa: E731
-        cfg = {"workload": WORKLOADS["rfft2048"], "n": n, "batch_per_gpu": batch, "sharding": f"batch x{world}, no collective"}
-    elif args.workload == "c64_2p20":
-        n, batch = 1 << 20, args.batch or 1024
-        fft64 = kofft_amd.HipFftImpl(np.float64, device=local_rank)
-        fft64.set_stream(stream.cuda_stream)
-        src = torch.empty((batch, n, 2), dtype=torch.float64, device=dev).uniform_(-1.0, 1.0, generator=gen)
-        dst = torch.empty_like(src)
-        units_per_step = batch * n
-        alg_bytes = 32 * units_per_step                 # 16 B read + 16 B written per point
-        unit = "GPoints/s"
-        metric = "batched 2^20-pt Complex64 forward FFT throughput"
-        launch = lambda: fft64.fft_dev_oop(src.data_ptr(), dst.data_ptr(), n, batch, False)  # noqa: E731
-        cfg = {"workload": WORKLOADS["c64_2p20"], "n": n, "batch_per_gpu": batch, "sharding": f"batch x{world}, no collective",
-               "passes_over_hbm": 2}
-    else:
-        total_len, win_len, hop = 28_800_000, 1024, 256
-        from kofft_amd.dist import frames_required, shard_range
+    def time_allgather(self, dist, dev, world, barrier):
+        """BASELINE config #4's exchange step (RCCL all-gather of the spectra), timed apart from the compute."""
+        import torch
 
-        frames_total = frames_required(total_len, hop)
-        f0, f1 = shard_range(frames_total, rank, world)
-        t = torch.arange(total_len, dtype=torch.float32, device=dev)
-        sig = 0.5 * torch.sin(2 * np.pi * 440.0 * t / 48000.0) + 0.25 * torch.empty_like(t).uniform_(-1, 1, generator=gen)
-        del t
-        win = torch.from_numpy(kofft_amd.hann(win_len)).to(dev)
-        count = f1 - f0
-        dst = torch.empty((count, win_len, 2), dtype=torch.float32, device=dev)
-        units_per_step = count * win_len                # output complex points of this rank
-        alg_bytes = 4 * min(total_len - f0 * hop, (count - 1) * hop + win_len) + 8 * units_per_step
-        unit = "GPoints/s"
-        metric = "STFT 1024-pt Hann hop-256 throughput (output points, compute only)"
-        launch = lambda: fft.stft_dev(sig.data_ptr(), total_len, win.data_ptr(), win_len, hop, dst.data_ptr(), f0, count)  # noqa: E731
-        cfg = {"workload": WORKLOADS["stft1024"], "signal_len": total_len, "win_len": win_len, "hop": hop,
-               "frames_total": frames_total, "sharding": f"frames x{world}, strong", "collective": "none in the timed region"}
-
-    def barrier():
-        if world > 1:
-            dist.barrier(device_ids=[local_rank])
-
-    # clock ramp (untimed, not counted as warm-up steps), then the W warm-up steps of the contract
-    t_ramp = time.perf_counter()
-    while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:
-        for _ in range(8):
-            launch()
-        torch.cuda.synchronize(dev)
-    for _ in range(args.warmup):
-        launch()
-    torch.cuda.synchronize(dev)
-
-    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        starts[i].record(stream)   # HIP events on the stream the kernel is launched on
-        launch()
-        ends[i].record(stream)
-    torch.cuda.synchronize(dev)
-    barrier()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-
-    kern_ms = [s.elapsed_time(e) for s, e in zip(starts, ends)]
-
-    # BASELINE config #4's exchange step, timed apart from the compute (it dominates: SURVEY 8e)
-    allgather_ms = None
-    if args.workload == "stft1024" and world > 1:
+        frames_total, win_len, count, dst = self._gather
         per = -(-frames_total // world)
         slot = torch.zeros((per, win_len, 2), dtype=torch.float32, device=dev)
         slot[:count] = dst
@@ -253,58 +320,199 @@ def main():
             dist.all_gather_into_tensor(full, slot)
         torch.cuda.synchronize(dev)
         barrier()
-        allgather_ms = (time.perf_counter() - tg) / 10 * 1e3
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    units = torch.tensor([float(units_per_step)], dtype=torch.float64, device=dev)
+        ms = (time.perf_counter() - tg) / 10 * 1e3
+        return {"ms_per_step": ms, "bytes_gathered_per_rank": int(full.numel() * 4),
+                "algbw_GBps": full.numel() * 4 / (ms * 1e-3) / 1e9,
+                "backend": "nccl (RCCL over xGMI), all_gather_into_tensor"}
+
+
+def measure(w: Workload, steps, warmup, ramp_ms, min_seconds, dev, stream, barrier, reduce_max, reduce_sum, count_launches=None):
+    """The timing protocol on one workload.  Returns the fields of the JSON line that depend on it."""
+    import numpy as np
+    import torch
+
+    launches = 0
+    t_ramp = time.perf_counter()
+    while (time.perf_counter() - t_ramp) * 1e3 < ramp_ms:  # clock ramp (untimed, not counted as warm-up steps)
+        for _ in range(8):
+            w.launch()
+            launches += 1
+        torch.cuda.synchronize(dev)
+    for _ in range(warmup):
+        w.launch()
+        launches += 1
+    torch.cuda.synchronize(dev)
+
+    blocks, kern_ms_all = [], []
+    total = 0.0
+    while True:
+        starts = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+        ends = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+        barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            starts[i].record(stream)   # HIP events on the stream the kernels are launched on
+            w.launch()
+            ends[i].record(stream)
+        torch.cuda.synchronize(dev)
+        barrier()
+        torch.cuda.synchronize(dev)
+        elapsed = reduce_max(time.perf_counter() - t0)   # identical on every rank: all ranks leave the loop together
+        launches += steps
+        blocks.append(elapsed)
+        kern_ms_all.append([s.elapsed_time(e) for s, e in zip(starts, ends)])
+        total += elapsed
+        if total >= min_seconds or len(blocks) >= 2000:
+            break
+    order = sorted(range(len(blocks)), key=lambda i: blocks[i])
+    mid = order[len(order) // 2]
+    elapsed = blocks[mid]
+    kern_ms = kern_ms_all[mid]
+    total_units = reduce_sum(float(w.units_per_step)) * steps
+    avg_kernel_s = float(np.mean(kern_ms)) / 1e3
+    achieved = w.alg_bytes / avg_kernel_s / 1e9
+    traffic, traffic_from = None, None
+    tfile = ROOT / "profiles" / f"traffic_{w.name}.json"
+    if tfile.exists():
+        try:
+            tj = json.loads(tfile.read_text())
+            if tj.get("workload") == w.name:
+                traffic = tj.get("hbm_bytes_per_step", tj.get("hbm_bytes_per_launch"))
+                traffic_from = tj.get("from")
+        except Exception:
+            traffic = None
+    if count_launches is not None:
+        count_launches.append(launches)
+    return {
+        "metric": w.metric,
+        "value": total_units / elapsed / 1e9,
+        "unit": w.unit,
+        "ms_per_step": elapsed / steps * 1e3,
+        "blocks": len(blocks),
+        "blocks_ms_per_step": [round(b / steps * 1e3, 4) for b in blocks[:64]],
+        "scaling": w.scaling,
+        "dtype": w.dtype,
+        "config": w.cfg,
+        "roofline": {
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic,
+            "traffic_from": traffic_from,
+            "kernel_ms_avg": avg_kernel_s * 1e3,
+            "kernel_ms_min": float(np.min(kern_ms)),
+            "algorithmic_bytes_per_launch": w.alg_bytes,
+            "launch": "one step = one C-ABI call" + ("" if w.kernels_per_step == 1 else " (several kernels: every chunk's factor passes)"),
+        },
+    }
+
+
+def run_rank(args) -> None:
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import kofft_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP library is the only implementation of this path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    n_seen = 1
     if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        dist.all_reduce(units, op=dist.ReduceOp.SUM)
-    elapsed = float(el.item())
-    total_units = float(units.item()) * args.steps
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        ones = torch.ones(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(ones)  # a real collective: n_gpus below is the number of ranks RCCL actually connected
+        n_seen = int(round(float(ones.item())))
+        assert n_seen == dist.get_world_size()
+    if args.gpus != world and rank == 0:
+        print(f"# note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+
+    fft32 = kofft_amd.HipFftImpl(np.float32, device=local_rank)
+    fft64 = kofft_amd.HipFftImpl(np.float64, device=local_rank)
+    # A dedicated (non-default) torch stream: the library launches on it and the HIP events are
+    # recorded on the same stream, so each event pair brackets exactly one step.
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
+    fft32.set_stream(stream.cuda_stream)
+    fft64.set_stream(stream.cuda_stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+
+    def reduce_max(x: float) -> float:
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def reduce_sum(x: float) -> float:
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t.item())
+
+    launches: list[int] = []
+    w = Workload(args.workload, args, rank, world, dev, stream, fft32, fft64, args.batch)
+    head = measure(w, args.steps, args.warmup, args.ramp_ms, args.min_seconds, dev, stream, barrier, reduce_max, reduce_sum, launches)
+    allgather = w.time_allgather(dist, dev, world, barrier) if (args.workload == "stft1024" and world > 1) else None
+    del w
+    torch.cuda.empty_cache()
+
+    extras_on = args.extras if args.extras is not None else (args.workload == "fft4096" and not args.batch and not args.inplace)
+    extra_names = []
+    if extras_on:
+        extra_names = [k for k in ("rfft2048", "stft1024", "c64_2p20") if k != args.workload] if world == 1 else \
+                      [k for k in ("stft1024",) if k != args.workload]
+    extras = {}
+    for name in extra_names:
+        try:
+            we = Workload(name, args, rank, world, dev, stream, fft32, fft64)
+            steps_e = max(5, min(args.steps, 20)) if name == "c64_2p20" else args.steps
+            r = measure(we, steps_e, min(args.warmup, 5), args.ramp_ms, min(args.min_seconds, 1.0), dev, stream, barrier, reduce_max, reduce_sum)
+            r["steps"] = steps_e
+            if name == "stft1024" and world > 1:
+                r["allgather"] = we.time_allgather(dist, dev, world, barrier)
+            extras[name] = r
+            del we
+        except Exception as e:  # the headline must survive a failing extra
+            extras[name] = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
 
     if rank == 0:
-        if os.environ.get("KOFFT_BENCH_VERBOSE"):
-            print("# per-launch ms: " + " ".join(f"{m:.3f}" for m in kern_ms), file=sys.stderr)
-        avg_kernel_s = float(np.mean(kern_ms)) / 1e3
-        achieved = alg_bytes / avg_kernel_s / 1e9
-        traffic = None
-        tfile = ROOT / "profiles" / f"traffic_{args.workload}.json"
-        if tfile.exists():
-            try:
-                tj = json.loads(tfile.read_text())
-                if tj.get("workload") == args.workload:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
         out = {
-            "metric": metric,
-            "value": total_units / elapsed / 1e9,
-            "unit": unit,
-            "n_gpus": world,
+            "metric": head["metric"],
+            "value": head["value"],
+            "unit": head["unit"],
+            "n_gpus": n_seen,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": head["ms_per_step"],
             "higher_is_better": True,
-            "scaling": "strong" if args.workload == "stft1024" else "weak",
+            "scaling": head["scaling"],
             "vs_baseline": None,
-            "dtype": "f64" if args.workload == "c64_2p20" else "f32",
+            "dtype": head["dtype"],
             "data": "synthetic",
-            "config": cfg,
-            "roofline": {
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "kernel_ms_avg": avg_kernel_s * 1e3,
-                "kernel_ms_min": float(np.min(kern_ms)),
-                "algorithmic_bytes_per_launch": alg_bytes,
-            },
+            "config": head["config"],
+            "roofline": head["roofline"],
+            "blocks": head["blocks"],
+            "blocks_ms_per_step": head["blocks_ms_per_step"],
+            "launches_total": launches[0],
+            "launcher": "self" if os.environ.get("KOFFT_BENCH_LAUNCHED") else ("torchrun" if world > 1 else "single"),
         }
-        if allgather_ms is not None:
-            out["allgather"] = {"ms_per_step": allgather_ms, "bytes_gathered_per_rank": int(full.numel() * 4),
-                                "backend": "nccl (RCCL over xGMI), all_gather_into_tensor"}
+        if allgather is not None:
+            out["allgather"] = allgather
+        if extras:
+            out["workloads"] = extras
         if args.workload == "fft4096" and not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline_fft4096(args.cpu_seconds)
         elif args.workload == "fft4096" and world > 1:
@@ -312,7 +520,19 @@ def main():
         print(json.dumps(out), flush=True)
 
     if world > 1:
+        dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus, argv))  # the parent: no torch, no GPU call
+    if args.dry_launch:
+        dry_rank()
+        return
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -51,25 +51,46 @@ def main():
                           f"workgroup {r.get('Workgroup_Size_X', r.get('Workgroup_Size', '?'))}, LDS {r.get('LDS_Block_Size', '?')} B, "
                           f"VGPR {r.get('VGPR_Count', '?')}, SGPR {r.get('SGPR_Count', '?')}, scratch {r.get('Scratch_Size', '?')} B"]
     agg = defaultdict(list)
+    per_kernel = defaultdict(lambda: defaultdict(list))
+    steps_launched = {}
     for tag in ("pmc_fetch", "pmc_write", "pmc_sq"):
+        log = src / f"{tag}.log"
+        if log.exists():  # the bench line of that pass says how many steps (C-ABI calls) it launched
+            js = [ln for ln in log.read_text().splitlines() if ln.startswith("{")]
+            if js:
+                steps_launched[tag] = json.loads(js[-1]).get("launches_total")
         for f in newest(str(src / tag / "**" / "*_counter_collection.csv")):
             for r in csv.DictReader(open(f)):
                 if "kofft" in r["Kernel_Name"]:
                     agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    lines += ["", "## PMC (mean per launch of the kofft kernel)", "", "| counter | launches | mean |", "|---|---|---|"]
+                    per_kernel[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    lines += ["", "## PMC (mean per launch of a kofft kernel)", "", "| counter | launches | mean |", "|---|---|---|"]
     for k, v in sorted(agg.items()):
         summary["pmc"][k] = sum(v) / len(v)
         lines.append(f"| {k} | {len(v)} | {sum(v) / len(v):.6g} |")
+    if len(per_kernel) > 1:
+        lines += ["", "Per kernel:", ""]
+        summary["pmc_per_kernel"] = {}
+        for kn, d in sorted(per_kernel.items()):
+            summary["pmc_per_kernel"][kn] = {c: sum(v) / len(v) for c, v in d.items()}
+            lines.append(f"* `{kn}`: " + ", ".join(f"{c} {sum(v) / len(v):.6g} (n={len(v)})" for c, v in sorted(d.items())))
     if "FETCH_SIZE" in agg and "WRITE_SIZE" in agg:
-        fetch = summary["pmc"]["FETCH_SIZE"] * 1024 * 2  # gfx950: half-counted coalesced reads (guide section HBM)
-        write = summary["pmc"]["WRITE_SIZE"] * 1024
-        summary["hbm_bytes_per_launch"] = fetch + write
+        # one bench step = one C-ABI call = possibly several kernels: sum over every kofft kernel of the pass, divided by the
+        # steps the pass launched (falls back to the per-kernel mean when the log has no launches_total)
+        nf = steps_launched.get("pmc_fetch") or len(agg["FETCH_SIZE"])
+        nw = steps_launched.get("pmc_write") or len(agg["WRITE_SIZE"])
+        fetch = sum(agg["FETCH_SIZE"]) / nf * 1024 * 2  # gfx950: half-counted coalesced reads (guide section HBM)
+        write = sum(agg["WRITE_SIZE"]) / nw * 1024
+        summary["hbm_bytes_per_step"] = fetch + write
         summary["hbm_read_bytes"] = fetch
         summary["hbm_write_bytes"] = write
-        lines += ["", f"HBM traffic per launch (guide's gfx950 correction: FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024): "
+        summary["kernels_per_step"] = len(agg["FETCH_SIZE"]) / nf
+        lines += ["", f"HBM traffic per bench step ({len(agg['FETCH_SIZE']) / nf:.2f} kernel launches per step; guide's gfx950 correction: "
+                  f"FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024): "
                   f"read {fetch / 1e9:.4f} GB + write {write / 1e9:.4f} GB = **{(fetch + write) / 1e9:.4f} GB**"]
         (out_dir / f"traffic_{workload}.json").write_text(json.dumps(
-            {"workload": workload, "hbm_bytes_per_launch": fetch + write, "from": f"profiles/{name}.md"}) + "\n")
+            {"workload": workload, "hbm_bytes_per_step": fetch + write, "read_bytes": fetch, "write_bytes": write,
+             "kernels_per_step": len(agg["FETCH_SIZE"]) / nf, "from": f"profiles/{name}.md"}) + "\n")
     if "SQ_LDS_BANK_CONFLICT" in agg:
         lines += ["", f"LDS bank-conflict cycles / LDS active cycles: {summary['pmc']['SQ_LDS_BANK_CONFLICT']:.0f} / "
                   f"{summary['pmc'].get('SQ_LDS_IDX_ACTIVE', 0):.0f}"]
