@@ -53,6 +53,7 @@ extern "C" {
 #define KOFFT_ERR_UNSUPPORTED (-2) /* length not supported by the device path */
 #define KOFFT_ERR_NULL (-3)        /* null context / pointer */
 #define KOFFT_ERR_ALLOC (-4)       /* host or device allocation failed */
+#define KOFFT_ERR_RCCL (-5)        /* RCCL unavailable or a collective failed; see kofft_hip_multi_last_error */
 
 typedef struct kofft_hip_ctx kofft_hip_ctx;
 
@@ -204,6 +205,38 @@ int kofft_hip_fftnd_c32(kofft_hip_ctx *ctx, float *data, size_t depth, size_t ro
 int kofft_hip_fftnd_c64(kofft_hip_ctx *ctx, double *data, size_t depth, size_t rows, size_t cols, int inverse);
 int kofft_hip_fftnd_c32_dev(kofft_hip_ctx *ctx, float *d_data, size_t depth, size_t rows, size_t cols, int inverse);
 int kofft_hip_fftnd_c64_dev(kofft_hip_ctx *ctx, double *d_data, size_t depth, size_t rows, size_t cols, int inverse);
+
+/* ---- multi-GPU ------------------------------------------------------
+ * stft::parallel (stft.rs:232-263) runs rayon over frames; frames are the parallel unit.  The device analogue is ONE
+ * process that owns `ngpu` devices (one context + one stream per device, all running concurrently): device r computes
+ * the contiguous frame range [r*ceil(F/G), min((r+1)*ceil(F/G), F)) from its own slice of the host signal (slice plus the
+ * win_len-hop halo, cut on the host: no halo exchange).  `allgather` != 0 adds BASELINE config #4's exchange: one RCCL
+ * ncclAllGather per device (ncclCommInitAll communicators, ncclGroupStart/End, in place) after which every device holds
+ * the whole spectrogram in ceil(F/G)-frame slots.  RCCL is bound at run time (dlopen); without it allgather returns
+ * KOFFT_ERR_RCCL and everything else still works.
+ *
+ * kofft_hip_stft_f32_multi: one call, host pointers in and out; checks = stft::stft's (hop == 0 -> INVALID_HOP_SIZE,
+ * frames < ceil(len/hop) -> MISMATCHED_LENGTHS, win_len == 0 -> EMPTY_INPUT), ngpu <= 0 -> INVALID_VALUE.
+ * out: frames * win_len complex.  The handle form keeps contexts, buffers and communicators across calls:
+ *   kofft_hip_multi_create(ngpu, devices (NULL: 0..ngpu-1), &m)
+ *   kofft_hip_multi_stft_f32(m, ..., out (host or NULL), frames, allgather, d_out_per_gpu (NULL or ngpu slots))
+ *     d_out_per_gpu[r] receives device r's buffer (owned by m, valid until the next call): its shard, or with allgather
+ *     the gathered [G*ceil(F/G), win_len] spectrogram (first `frames` rows are the STFT, the rest zero).
+ *   kofft_hip_multi_shard(m, total, rank, &first, &count): the partition above, for callers that place their own data.
+ *   kofft_hip_multi_last_timing: slowest device's upload+kernel time and the gather time of the last call (HIP events).
+ *   kofft_hip_multi_fft_c32: fft::batch (fft.rs:2156-2175) with the batch in G contiguous blocks, no exchange. */
+typedef struct kofft_hip_multi kofft_hip_multi;
+int kofft_hip_multi_create(int ngpu, const int *devices, kofft_hip_multi **out);
+int kofft_hip_multi_destroy(kofft_hip_multi *m);
+const char *kofft_hip_multi_last_error(const kofft_hip_multi *m);
+int kofft_hip_multi_ngpu(const kofft_hip_multi *m);
+int kofft_hip_multi_shard(const kofft_hip_multi *m, size_t total, int rank, size_t *first, size_t *count);
+int kofft_hip_multi_last_timing(const kofft_hip_multi *m, float *compute_ms, float *gather_ms);
+int kofft_hip_multi_stft_f32(kofft_hip_multi *m, const float *signal, size_t len, const float *window, size_t win_len,
+                             size_t hop, float *out, size_t frames, int allgather, float **d_out_per_gpu);
+int kofft_hip_stft_f32_multi(int ngpu, const float *signal, size_t len, const float *window, size_t win_len,
+                             size_t hop, float *out, size_t frames, int allgather);
+int kofft_hip_multi_fft_c32(kofft_hip_multi *m, float *data, size_t n, size_t batch, int inverse);
 
 #ifdef __cplusplus
 }

@@ -469,6 +469,39 @@ Result fft3d_inplace(std::vector<Complex<T>> &data, size_t depth, size_t rows, s
     return fft.st(detail::Abi<T>::fftnd(fft.raw(), reinterpret_cast<T *>(data.data()), depth, rows, cols, 0));
 }
 
+// Multi-GPU STFT: frames sharded over the devices of one process, optional RCCL all-gather of the
+// spectra -- the device analogue of stft::parallel's rayon-over-frames (stft.rs:232-263).
+class HipMulti {
+public:
+    explicit HipMulti(int ngpu, const int *devices = nullptr)
+    {
+        const int rc = kofft_hip_multi_create(ngpu, devices, &h_);
+        if (rc > 0) throw std::invalid_argument("kofft_hip_multi_create: invalid device count");
+        if (rc != 0) throw DeviceError(rc, "kofft_hip_multi_create");
+    }
+    ~HipMulti() { if (h_) kofft_hip_multi_destroy(h_); }
+    HipMulti(const HipMulti &) = delete;
+    HipMulti &operator=(const HipMulti &) = delete;
+    int ngpu() const { return kofft_hip_multi_ngpu(h_); }
+    // stft::stft's checks and result; frames [r*ceil(F/G), ...) computed by device r
+    Result stft(const std::vector<float> &signal, const std::vector<float> &window, size_t hop_size,
+                std::vector<std::vector<Complex32>> &output, bool allgather = false)
+    {
+        const size_t frames = output.size(), wl = window.size();
+        std::vector<Complex32> flat(frames * wl);
+        const int rc = kofft_hip_multi_stft_f32(h_, signal.data(), signal.size(), window.data(), wl, hop_size,
+                                                reinterpret_cast<float *>(flat.data()), frames, allgather ? 1 : 0, nullptr);
+        if (rc > 0) return Result::Err(static_cast<FftError>(rc));
+        if (rc != 0) throw DeviceError(rc, kofft_hip_multi_last_error(h_));
+        for (size_t f = 0; f < frames; ++f) output[f].assign(flat.begin() + f * wl, flat.begin() + (f + 1) * wl);
+        return Result::Ok();
+    }
+    kofft_hip_multi *raw() const { return h_; }
+
+private:
+    kofft_hip_multi *h_ = nullptr;
+};
+
 // stft::parallel (stft.rs:232-263): only hop == 0 is rejected
 inline Result parallel(const std::vector<float> &signal, const std::vector<float> &window, size_t hop_size,
                        std::vector<std::vector<Complex32>> &output, const HipFftImpl<float> &fft)

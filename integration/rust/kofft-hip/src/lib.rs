@@ -38,6 +38,19 @@ extern "C" {
                                      mags: *mut f32, frames: usize, max_mag: *mut f32) -> c_int;
     fn kofft_hip_fftnd_c32(ctx: *mut KofftHipCtx, data: *mut f32, depth: usize, rows: usize, cols: usize, inverse: c_int) -> c_int;
     fn kofft_hip_fftnd_c64(ctx: *mut KofftHipCtx, data: *mut f64, depth: usize, rows: usize, cols: usize, inverse: c_int) -> c_int;
+    // multi-GPU: one process, one context per device, optional RCCL all-gather (include/kofft_hip.h, "multi-GPU")
+    fn kofft_hip_multi_create(ngpu: c_int, devices: *const c_int, out: *mut *mut KofftHipMulti) -> c_int;
+    fn kofft_hip_multi_destroy(m: *mut KofftHipMulti) -> c_int;
+    fn kofft_hip_multi_last_error(m: *const KofftHipMulti) -> *const c_char;
+    fn kofft_hip_multi_stft_f32(m: *mut KofftHipMulti, signal: *const f32, len: usize, window: *const f32, win_len: usize,
+                                hop: usize, out: *mut f32, frames: usize, allgather: c_int, d_out_per_gpu: *mut *mut f32) -> c_int;
+    fn kofft_hip_stft_f32_multi(ngpu: c_int, signal: *const f32, len: usize, window: *const f32, win_len: usize, hop: usize,
+                                out: *mut f32, frames: usize, allgather: c_int) -> c_int;
+}
+
+#[repr(C)]
+pub struct KofftHipMulti {
+    _private: [u8; 0],
 }
 
 /// 0 = Ok, 1..=6 = FftError in declaration order (kofft fft.rs:447-454).  FftError has no variant for a
@@ -251,6 +264,58 @@ impl HipFftImpl<f32> {
             kofft_hip_stft_magnitudes_f32(self.ctx, samples.as_ptr(), samples.len(), win_len, hop, flat.as_mut_ptr(), frames, &mut max_mag)
         })?;
         Ok((flat.chunks(half.max(1)).take(frames).map(|c| c.to_vec()).collect(), max_mag))
+    }
+}
+
+/// `stft::parallel` (kofft stft.rs:232-263) across `ngpu` devices of this process: frames are the parallel unit, device
+/// `r` computes `[r*ceil(F/G), ...)`; `allgather` adds the RCCL all-gather of BASELINE config #4.  Same checks as
+/// `stft::stft` (stft.rs:83-87).  One call: contexts are created and torn down inside (see `HipMulti` to keep them).
+pub fn stft_multi(ngpu: usize, signal: &[f32], window: &[f32], hop_size: usize, output: &mut [Vec<Complex32>], allgather: bool)
+    -> Result<(), FftError> {
+    let (frames, wl) = (output.len(), window.len());
+    let mut flat = vec![Complex32::new(0.0, 0.0); frames * wl];
+    let rc = unsafe {
+        kofft_hip_stft_f32_multi(ngpu as c_int, signal.as_ptr(), signal.len(), window.as_ptr(), wl, hop_size,
+                                 flat.as_mut_ptr() as *mut f32, frames, allgather as c_int)
+    };
+    status(core::ptr::null(), rc)?;
+    for (f, frame) in output.iter_mut().enumerate() {
+        frame.clear();
+        frame.extend_from_slice(&flat[f * wl..(f + 1) * wl]);
+    }
+    Ok(())
+}
+
+/// Handle form of the above: per-device contexts, buffers and RCCL communicators live as long as the value.
+pub struct HipMulti {
+    h: *mut KofftHipMulti,
+}
+
+impl HipMulti {
+    pub fn new(ngpu: usize) -> Result<Self, FftError> {
+        let mut h = core::ptr::null_mut();
+        status(core::ptr::null(), unsafe { kofft_hip_multi_create(ngpu as c_int, core::ptr::null(), &mut h) })?;
+        Ok(Self { h })
+    }
+
+    pub fn stft_contiguous(&self, signal: &[f32], window: &[f32], hop_size: usize, out: &mut [Complex32], allgather: bool)
+        -> Result<(), FftError> {
+        let frames = if window.is_empty() { 0 } else { out.len() / window.len() };
+        let rc = unsafe {
+            kofft_hip_multi_stft_f32(self.h, signal.as_ptr(), signal.len(), window.as_ptr(), window.len(), hop_size,
+                                     out.as_mut_ptr() as *mut f32, frames, allgather as c_int, core::ptr::null_mut())
+        };
+        if rc < 0 {
+            let msg = unsafe { std::ffi::CStr::from_ptr(kofft_hip_multi_last_error(self.h)) }.to_string_lossy().into_owned();
+            panic!("kofft-hip multi-GPU error {rc}: {msg}");
+        }
+        status(core::ptr::null(), rc)
+    }
+}
+
+impl Drop for HipMulti {
+    fn drop(&mut self) {
+        unsafe { kofft_hip_multi_destroy(self.h) };
     }
 }
 

@@ -71,6 +71,16 @@ SIGNATURES = {
     "kofft_hip_fftnd_c32_dev": (C.c_int, [_ctx, C.c_void_p, _sz, _sz, _sz, C.c_int]),
     "kofft_hip_fftnd_c64_dev": (C.c_int, [_ctx, C.c_void_p, _sz, _sz, _sz, C.c_int]),
     "kofft_hip_stft_f32_dev": (C.c_int, [_ctx, C.c_void_p, _sz, C.c_void_p, _sz, _sz, C.c_void_p, _sz, _sz]),
+    # multi-GPU (single process, one context per device; RCCL bound at run time)
+    "kofft_hip_multi_create": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(_ctx)]),
+    "kofft_hip_multi_destroy": (C.c_int, [_ctx]),
+    "kofft_hip_multi_last_error": (C.c_char_p, [_ctx]),
+    "kofft_hip_multi_ngpu": (C.c_int, [_ctx]),
+    "kofft_hip_multi_shard": (C.c_int, [_ctx, _sz, C.c_int, C.POINTER(_sz), C.POINTER(_sz)]),
+    "kofft_hip_multi_last_timing": (C.c_int, [_ctx, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "kofft_hip_multi_stft_f32": (C.c_int, [_ctx, C.c_void_p, _sz, C.c_void_p, _sz, _sz, C.c_void_p, _sz, C.c_int, C.POINTER(C.c_void_p)]),
+    "kofft_hip_stft_f32_multi": (C.c_int, [C.c_int, C.c_void_p, _sz, C.c_void_p, _sz, _sz, C.c_void_p, _sz, C.c_int]),
+    "kofft_hip_multi_fft_c32": (C.c_int, [_ctx, C.c_void_p, _sz, _sz, C.c_int]),
 }
 
 _lib = None

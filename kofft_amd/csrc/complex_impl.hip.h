@@ -1,0 +1,242 @@
+// complex_impl.hip.h -- FftImpl::fft / ifft on device pointers for one element type: the power-of-two kernels, the
+// two- / three-factor path for large n and the Bluestein arm.  Included by k_complex_f32.hip / k_complex_f64.hip.
+#pragma once
+
+#include "host_common.hip.h"
+
+namespace kofft {
+namespace host {
+
+// ---------------------------------------------------------------------------------
+// large n: two factors (fft_big.hip.h)
+// ---------------------------------------------------------------------------------
+
+// Launch the generic kernel for a sub-transform of log2 size LS with an arbitrary IO policy.
+template <typename T, class IO>
+int launch_sub(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, int LS, size_t units)
+{
+    switch (LS) {
+    // 16 (c32) / 8 (c64) adjacent columns or rows per workgroup = 128-byte segments while the tile fits the LDS budget
+    // (sub-transforms up to 2^9 points; 2^10: 8; larger ones fewer still -- big_block).
+#define KOFFT_CASE(LL) \
+    case LL: return launch_wg<T, LL, EPI_STORE, IO, big_block<T, IO, LL>()>(ctx, io, tw, units);
+        KOFFT_CASE(7)
+        KOFFT_CASE(8)
+        KOFFT_CASE(9)
+        KOFFT_CASE(10)
+        KOFFT_CASE(11)
+        KOFFT_CASE(12)
+        KOFFT_CASE(13)
+#undef KOFFT_CASE
+    default: return KOFFT_ERR_UNSUPPORTED;
+    }
+}
+
+// Sub-transforms of the middle factor are at most 2^9 points (three factors cover 2^21 .. 2^26 with 7..9 bits each).
+template <typename T>
+int launch_mid(kofft_hip_ctx *ctx, const BigMidIO<T> &io, const cpx<T> *tw, int LS, size_t units)
+{
+    switch (LS) {
+    case 7: return launch_wg<T, 7, EPI_STORE, BigMidIO<T>, big_block<T, BigMidIO<T>, 7>()>(ctx, io, tw, units);
+    case 8: return launch_wg<T, 8, EPI_STORE, BigMidIO<T>, big_block<T, BigMidIO<T>, 8>()>(ctx, io, tw, units);
+    case 9: return launch_wg<T, 9, EPI_STORE, BigMidIO<T>, big_block<T, BigMidIO<T>, 9>()>(ctx, io, tw, units);
+    default: return KOFFT_ERR_UNSUPPORTED;
+    }
+}
+
+template <typename T>
+inline int big_rows_per_wg(int LB) { return LB <= 9 ? KOFFT_BIG_XPB(T) : LB == 10 ? 8 : LB == 11 ? 4 : LB == 12 ? 2 : 1; }
+
+template <typename T, bool INVERSE>
+int fft_big_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t batch)
+{
+    const int L = ilog2(n);
+    // Two factors while both stay <= 2^10 points (tiles of 8 adjacent columns / rows, 64..128-byte segments); from 2^22
+    // on, three factors of 7..9 bits: one more pass over HBM, but every pass keeps full-width tiles (two factors of
+    // 11..13 bits shrink the tiles to 4, 2, 1 columns and fall to 0.05..0.16 of the roofline).
+    const bool three = L >= 22 && !ctx->big_two_only;  // measured crossover (2^21: two factors still ahead)
+    const int L1 = three ? (L + 2) / 3 : L / 2;
+    const int L2 = three ? (L - L1 + 1) / 2 : 0;
+    const int L3 = L - L1 - L2;
+    const cpx<T> *tw = nullptr;
+    int rc = get_table<T>(ctx, Kind<T>::tw, n, &tw);
+    if (rc) return rc;
+    const size_t xf_bytes = n * sizeof(cpx<T>);
+    size_t chunk = ctx->big_chunk_bytes / xf_bytes;
+    if (chunk < 1) chunk = 1;
+    if (chunk > batch) chunk = batch;
+    const size_t need = chunk * xf_bytes * (three ? 2 : 1);
+    if (ctx->big_tmp_bytes < need) {
+        if (ctx->big_tmp) KOFFT_HIP_TRY(ctx, hipFree(ctx->big_tmp));
+        ctx->big_tmp = nullptr;
+        ctx->big_tmp_bytes = 0;
+        KOFFT_HIP_TRY(ctx, hipMalloc(&ctx->big_tmp, need));
+        ctx->big_tmp_bytes = need;
+    }
+    cpx<T> *mid = static_cast<cpx<T> *>(ctx->big_tmp);
+    cpx<T> *mid2 = mid + chunk * n;
+    const T scale = (T)1 / (T)(float)n;
+    for (size_t b0 = 0; b0 < batch; b0 += chunk) {
+        const size_t nb = (batch - b0 < chunk) ? batch - b0 : chunk;
+        const cpx<T> *src = reinterpret_cast<const cpx<T> *>(d_in) + b0 * n;
+        cpx<T> *dst = reinterpret_cast<cpx<T> *>(d_out) + b0 * n;
+        // first factor: stages 0 .. L1-1 down the columns of a 2^L1 x 2^(L-L1) matrix
+        BigColsIO<T, INVERSE> a{src, mid, L - L1, L - L1, n};
+        rc = launch_sub<T>(ctx, a, tw, L1, nb << (L - L1));
+        if (rc) return rc;
+        const cpx<T> *last_in = mid;
+        if (three) {
+            BigMidIO<T> m{mid, mid2, L1, L2, L3, L - L2, L - 1 - L1, n};
+            rc = launch_mid<T>(ctx, m, tw, L2, nb << (L - L2));
+            if (rc) return rc;
+            last_in = mid2;
+        }
+        // last factor: the remaining L3 stages along contiguous rows, prefix K of L - L3 bits, output transposed
+        const int LP = L - L3;
+        BigRowsIO<T, INVERSE> b{last_in, dst, LP, L3, L - L3, L - 1 - LP, n, scale, big_rows_per_wg<T>(L3) * sizeof(cpx<T>) >= 64};
+        rc = launch_sub<T>(ctx, b, tw, L3, nb << LP);
+        if (rc) return rc;
+    }
+    return KOFFT_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// non-power-of-two lengths: Bluestein (fft.rs:1088-1132)
+// ---------------------------------------------------------------------------------
+template <typename T>
+int get_bluestein(kofft_hip_ctx *ctx, size_t n, size_t m, const cpx<T> **chirp, const cpx<T> **bfft)
+{
+    const int kc = sizeof(T) == 4 ? 5 : 6, kb = sizeof(T) == 4 ? 7 : 8;
+    auto ic = ctx->tables.find(std::make_pair(kc, n));
+    auto ib = ctx->tables.find(std::make_pair(kb, n));
+    if (ic != ctx->tables.end() && ib != ctx->tables.end()) {
+        *chirp = static_cast<const cpx<T> *>(ic->second);
+        *bfft = static_cast<const cpx<T> *>(ib->second);
+        return KOFFT_OK;
+    }
+    std::vector<T> hc(2 * n), hb(2 * m);
+    if constexpr (sizeof(T) == 4) kofft_tables::bluestein_f32(n, m, (float *)hc.data(), (float *)hb.data());
+    else kofft_tables::bluestein_f64(n, m, (double *)hc.data(), (double *)hb.data());
+    void *dc = nullptr, *db = nullptr;
+    // every failure path below frees both tables (nothing is cached until the last step has succeeded)
+    auto fail = [&](const char *what, hipError_t e) {
+        if (dc) (void)hipFree(dc);
+        if (db) (void)hipFree(db);
+        if (e != hipSuccess) ctx->last_error = std::string(what) + ": " + hipGetErrorString(e);
+    };
+    hipError_t e = hipMalloc(&dc, hc.size() * sizeof(T));
+    if (e == hipSuccess) e = hipMalloc(&db, hb.size() * sizeof(T));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        fail("bluestein tables: hipMalloc", e);
+        return KOFFT_ERR_HIP;
+    }
+    e = hipMemcpy(dc, hc.data(), hc.size() * sizeof(T), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(db, hb.data(), hb.size() * sizeof(T), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        fail("bluestein tables: upload", e);
+        return KOFFT_ERR_HIP;
+    }
+    // b_fft = fft(b) with the ordinary power-of-two path (fft.rs:425-427)
+    int rc = fft_dev<T>(ctx, static_cast<T *>(db), static_cast<T *>(db), m, 1, 0);
+    if (rc) {
+        fail("", hipSuccess);
+        return rc;
+    }
+    // the table is cached for every later call, on whatever stream that call uses: finish it first
+    e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        fail("bluestein tables: fft(b)", e);
+        return KOFFT_ERR_HIP;
+    }
+    ctx->tables[std::make_pair(kc, n)] = dc;
+    ctx->tables[std::make_pair(kb, n)] = db;
+    *chirp = static_cast<const cpx<T> *>(dc);
+    *bfft = static_cast<const cpx<T> *>(db);
+    return KOFFT_OK;
+}
+
+template <typename T, bool INVERSE>
+int fft_bluestein_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t batch)
+{
+    size_t m = 1;
+    while (m < 2 * n - 1) m <<= 1;  // (2n-1).next_power_of_two()
+    const cpx<T> *chirp = nullptr, *bfft = nullptr;
+    int rc = get_bluestein<T>(ctx, n, m, &chirp, &bfft);
+    if (rc) return rc;
+    const size_t xf_bytes = m * sizeof(cpx<T>);
+    size_t chunk = (size_t(512) << 20) / xf_bytes;
+    if (chunk < 1) chunk = 1;
+    if (chunk > batch) chunk = batch;
+    if (ctx->blue_tmp_bytes < chunk * xf_bytes) {
+        if (ctx->blue_tmp) KOFFT_HIP_TRY(ctx, hipFree(ctx->blue_tmp));
+        ctx->blue_tmp = nullptr;
+        ctx->blue_tmp_bytes = 0;
+        KOFFT_HIP_TRY(ctx, hipMalloc(&ctx->blue_tmp, chunk * xf_bytes));
+        ctx->blue_tmp_bytes = chunk * xf_bytes;
+    }
+    cpx<T> *a = static_cast<cpx<T> *>(ctx->blue_tmp);
+    const T scale_m = (T)1 / (T)(float)m, scale_n = (T)1 / (T)(float)n;
+    for (size_t b0 = 0; b0 < batch; b0 += chunk) {
+        const size_t nb = (batch - b0 < chunk) ? batch - b0 : chunk;
+        const cpx<T> *src = reinterpret_cast<const cpx<T> *>(d_in) + b0 * n;
+        cpx<T> *dst = reinterpret_cast<cpx<T> *>(d_out) + b0 * n;
+        if (ctx->blue_fused && m <= (size_t(1) << max_log2<T>())) {
+            BlueFirstIO<T, INVERSE> io1{{}, src, a, chirp, bfft, (int)n, (int)m};
+            rc = dispatch<T, EPI_STORE>(ctx, io1, m, nb);
+            if (rc) return rc;
+            BlueSecondIO<T, INVERSE> io2{{}, a, dst, chirp, (int)n, (int)m, scale_m, scale_n};
+            rc = dispatch<T, EPI_STORE>(ctx, io2, m, nb);
+            if (rc) return rc;
+            continue;
+        }
+        const size_t tm = nb * m, tn = nb * n;
+        hipLaunchKernelGGL((bluestein_pre_kernel<T, INVERSE>), dim3((unsigned)((tm + 255) / 256)), dim3(256), 0, ctx->stream, src, a,
+                           chirp, n, m, tm);
+        KOFFT_HIP_TRY(ctx, hipGetLastError());
+        rc = fft_dev<T>(ctx, reinterpret_cast<T *>(a), reinterpret_cast<T *>(a), m, nb, 0);
+        if (rc) return rc;
+        hipLaunchKernelGGL((bluestein_mid_kernel<T>), dim3((unsigned)((tm + 255) / 256)), dim3(256), 0, ctx->stream, a, bfft, m, tm);
+        KOFFT_HIP_TRY(ctx, hipGetLastError());
+        rc = fft_dev<T>(ctx, reinterpret_cast<T *>(a), reinterpret_cast<T *>(a), m, nb, 0);
+        if (rc) return rc;
+        hipLaunchKernelGGL((bluestein_post_kernel<T, INVERSE>), dim3((unsigned)((tn + 255) / 256)), dim3(256), 0, ctx->stream, a, dst,
+                           chirp, n, m, tn, scale_m, scale_n);
+        KOFFT_HIP_TRY(ctx, hipGetLastError());
+    }
+    return KOFFT_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// typed entry points behind the C ABI
+// ---------------------------------------------------------------------------------
+template <typename T>
+int fft_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t batch, int inverse)
+{
+    // argument checks come first and need no device, so the reference's error order is testable anywhere
+    if (batch == 0) return KOFFT_OK;
+    if (n == 0) return KOFFT_ERR_EMPTY_INPUT;  // fft.rs:1056 / 1136
+    if (n > (size_t(1) << (is_pow2(n) ? max_log2_big<T>() : max_log2_big<T>() - 1))) return KOFFT_ERR_UNSUPPORTED;
+    if (!ctx || !d_in || !d_out) return KOFFT_ERR_NULL;
+    KOFFT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!is_pow2(n))  // fft.rs:1083-1132
+        return inverse ? fft_bluestein_dev<T, true>(ctx, d_in, d_out, n, batch) : fft_bluestein_dev<T, false>(ctx, d_in, d_out, n, batch);
+    if (n > (size_t(1) << max_log2<T>()))
+        return inverse ? fft_big_dev<T, true>(ctx, d_in, d_out, n, batch) : fft_big_dev<T, false>(ctx, d_in, d_out, n, batch);
+    if (n == 1) {  // fft.rs:1059 / 1139: nothing to do
+        if (d_in != d_out)
+            KOFFT_HIP_TRY(ctx, hipMemcpyAsync(d_out, d_in, batch * 2 * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
+        return KOFFT_OK;
+    }
+    const T scale = (T)1 / (T)(float)n;  // fft.rs:1167
+    if (inverse) {
+        ComplexIO<T, true> io{{}, reinterpret_cast<const cpx<T> *>(d_in), reinterpret_cast<cpx<T> *>(d_out), (int)n, scale};
+        return dispatch<T, EPI_STORE>(ctx, io, n, batch);
+    }
+    ComplexIO<T, false> io{{}, reinterpret_cast<const cpx<T> *>(d_in), reinterpret_cast<cpx<T> *>(d_out), (int)n, scale};
+    return dispatch<T, EPI_STORE>(ctx, io, n, batch);
+}
+
+
+}  // namespace host
+}  // namespace kofft

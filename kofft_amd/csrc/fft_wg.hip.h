@@ -221,7 +221,7 @@ struct StftMagIO : StftIO {
 
 // max over a non-negative f32 array, NaN never selected (spectrogram.rs:69-71: `if mag > max_mag`): non-negative floats
 // order like their bit patterns, so an unsigned atomicMax is exact whatever the order of arrival.
-__global__ __launch_bounds__(256) void max_nonneg_kernel(const float *__restrict__ x, const size_t count, unsigned *__restrict__ out_bits)
+static __global__ __launch_bounds__(256) void max_nonneg_kernel(const float *__restrict__ x, const size_t count, unsigned *__restrict__ out_bits)
 {
     float m = 0.0f;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {

@@ -1,0 +1,428 @@
+// host_common.hip.h -- what every translation unit of libkofft_hip.so shares: the context, the planner-table cache,
+// launch geometry and the size dispatch.  The kernels are instantiated per family in their own translation units
+// (k_complex_*.hip, k_real_*.hip, k_stft.hip, k_nd.hip) so that the library builds in parallel; kofft_hip.hip holds the
+// host-pointer wrappers and the extern "C" ABI of include/kofft_hip.h.  gfx950 only; compiled with -ffp-contract=off.
+#pragma once
+
+#include "../../include/kofft_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "fft_big.hip.h"
+#include "fft_persist.hip.h"
+#include "fft_wg.hip.h"
+#include "tables.h"
+
+// ---------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------
+struct kofft_hip_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t order_event = nullptr;  // kofft_hip_set_stream: orders the new stream after the old one
+    int num_cus = 256;
+    bool use_persist = true;  // KOFFT_HIP_NO_PERSIST=1 forces the generic kernels (A/B measurements, tests)
+    int persist_grid_pct = 0; // KOFFT_HIP_PERSIST_GRID_PCT: scale the persistent grids (measurements only)
+    bool big_two_only = false; // KOFFT_HIP_BIG_TWO_FACTORS=1: never split into three factors (A/B measurements)
+    bool blue_fused = true;    // KOFFT_HIP_BLUESTEIN_FUSED=0: pointwise steps as separate kernels at every size
+    bool nd_transpose = true;  // KOFFT_HIP_ND_TRANSPOSE=0: long strided axes through the strided kernel
+    int nd_transpose_min = 4096;  // KOFFT_HIP_ND_TRANSPOSE_MIN: shortest axis that takes the transpose route (measured: 1024 loses, 2048 ties)
+    bool zero_copy = true;     // KOFFT_HIP_ZERO_COPY=0: small host calls through staged copies like large ones
+    bool host_pipeline = true; // KOFFT_HIP_HOST_PIPELINE=0: host-pointer batches in one upload / kernel / download
+    int host_chunks = 0;       // KOFFT_HIP_HOST_CHUNKS: pieces of a pipelined host batch (default 8)
+    bool persist_small = true; // KOFFT_HIP_PERSIST_SMALL=0: n = 128, 256 on the generic kernels (A/B measurements)
+    std::string last_error;
+    // planner caches: (kind, n) -> device table.  kind 0/1 = FftPlanner twiddles f32/f64,
+    // 2/3 = RfftPlanner post-pass table f32/f64.
+    std::map<std::pair<int, size_t>, void *> tables;
+    // staging for the host-pointer entry points
+    void *stage[3] = {nullptr, nullptr, nullptr};
+    size_t stage_bytes[3] = {0, 0, 0};
+    // intermediate of the two-factor large-n path (fft_big.hip.h): `big_chunk` transforms at a time
+    void *big_tmp = nullptr;
+    size_t big_tmp_bytes = 0;
+    // small host-pointer calls (one frame, one transform): a pinned, device-mapped buffer the kernels read and write
+    // directly over PCIe -- one launch and one synchronisation instead of two staged copies around them
+    void *pinned = nullptr;      // host address
+    void *pinned_dev = nullptr;  // the same memory as the device sees it
+    size_t pinned_bytes = 0;
+    void *blue_tmp = nullptr;  // zero-padded work buffer of the Bluestein arm
+    size_t blue_tmp_bytes = 0;
+    size_t big_chunk_bytes = size_t(2048) << 20;  // KOFFT_HIP_BIG_CHUNK_MB; measured: small chunks do not profit from the Infinity Cache, larger launches overlap better
+};
+
+namespace kofft {
+namespace host {
+
+#define KOFFT_HIP_TRY(ctx, expr)                                                              \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            (ctx)->last_error = std::string(#expr) + ": " + hipGetErrorString(e_);            \
+            return KOFFT_ERR_HIP;                                                             \
+        }                                                                                     \
+    } while (0)
+
+inline bool is_pow2(size_t n) { return n != 0 && (n & (n - 1)) == 0; }
+inline int ilog2(size_t n)
+{
+    int l = 0;
+    while ((size_t(1) << l) < n) ++l;
+    return l;
+}
+
+template <typename T> struct Kind;
+template <> struct Kind<float> { static constexpr int tw = 0, rt = 2; };
+template <> struct Kind<double> { static constexpr int tw = 1, rt = 3; };
+
+template <typename T>
+int get_table(kofft_hip_ctx *ctx, int kind, size_t n, const cpx<T> **out)
+{
+    auto key = std::make_pair(kind, n);
+    auto it = ctx->tables.find(key);
+    if (it != ctx->tables.end()) {
+        *out = static_cast<const cpx<T> *>(it->second);
+        return KOFFT_OK;
+    }
+    const bool is_rfft = kind >= 2;
+    const size_t entries = is_rfft ? n : n / 2;
+    std::vector<T> host(2 * (entries ? entries : 1));
+    if (is_rfft) {
+        if constexpr (sizeof(T) == 4) kofft_tables::rfft_table_f32(n, (float *)host.data());
+        else kofft_tables::rfft_table_f64(n, (double *)host.data());
+    } else {
+        if constexpr (sizeof(T) == 4) kofft_tables::twiddles_f32(n, (float *)host.data());
+        else kofft_tables::twiddles_f64(n, (double *)host.data());
+    }
+    void *d = nullptr;
+    KOFFT_HIP_TRY(ctx, hipMalloc(&d, host.size() * sizeof(T)));
+    // synchronous copy: tables are built once per (context, n), never in a timed region
+    hipError_t e = hipMemcpy(d, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        ctx->last_error = std::string("table upload: ") + hipGetErrorString(e);
+        return KOFFT_ERR_HIP;
+    }
+    ctx->tables[key] = d;
+    *out = static_cast<const cpx<T> *>(d);
+    return KOFFT_OK;
+}
+
+constexpr size_t kZeroCopyMax = size_t(512) << 10;  // bytes per direction up to which a host call goes zero-copy
+// (measured per-call latency, host memory: n = 64 31 -> 17 us, 1024 33 -> 20, 4096 36 -> 22, 65536 95 -> 79; 1 MiB: no gain)
+
+inline int ensure_pinned(kofft_hip_ctx *ctx, size_t bytes)
+{
+    if (ctx->pinned_bytes >= bytes) return KOFFT_OK;
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    ctx->pinned = ctx->pinned_dev = nullptr;
+    ctx->pinned_bytes = 0;
+    const size_t want = bytes < (size_t(1) << 20) ? (size_t(1) << 20) : bytes;
+    if (hipHostMalloc(&ctx->pinned, want, hipHostMallocMapped) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->pinned = nullptr;
+        return KOFFT_ERR_ALLOC;
+    }
+    if (hipHostGetDevicePointer(&ctx->pinned_dev, ctx->pinned, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipHostFree(ctx->pinned);
+        ctx->pinned = nullptr;
+        return KOFFT_ERR_ALLOC;
+    }
+    ctx->pinned_bytes = want;
+    return KOFFT_OK;
+}
+
+inline int ensure_stage(kofft_hip_ctx *ctx, int which, size_t bytes)
+{
+    if (ctx->stage_bytes[which] >= bytes) return KOFFT_OK;
+    if (ctx->stage[which]) KOFFT_HIP_TRY(ctx, hipFree(ctx->stage[which]));
+    ctx->stage[which] = nullptr;
+    ctx->stage_bytes[which] = 0;
+    KOFFT_HIP_TRY(ctx, hipMalloc(&ctx->stage[which], bytes));
+    ctx->stage_bytes[which] = bytes;
+    return KOFFT_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// launch geometry
+// ---------------------------------------------------------------------------------
+#ifndef KOFFT_RL_BIG
+#define KOFFT_RL_BIG 5
+#endif
+// threads per transform >= 8 (c64) / 16 (c32): every load / store instruction covers whole 128-byte lines per transform
+// (A/B on one box: n = 32 c64 0.65 -> 0.79 of the roofline, n = 64 c32 0.64 -> 0.71, n = 128 c32 0.60 -> 0.70.)
+constexpr int rl_for(int L) { return (L == 5 || L == 6) ? 2 : (L == 7 || L == 9) ? 3 : (L >= 13 ? KOFFT_RL_BIG : 4); }
+constexpr int block_for(int L)
+{
+    const int tpt = (1 << L) >> rl_for(L);
+    return tpt > 256 ? tpt : 256;
+}
+template <typename T> constexpr int max_log2();
+template <> constexpr int max_log2<float>() { return 14; }
+template <> constexpr int max_log2<double>() { return 13; }
+
+// hipFuncSetAttribute once per (kernel instance, device): `done` is a function-local static of the caller's template
+// instance, one bit per device ordinal.
+inline int set_dyn_lds_once(kofft_hip_ctx *ctx, std::atomic<unsigned long long> &done, const void *kern, size_t lds)
+{
+    const unsigned long long bit = 1ull << (ctx->device & 63);
+    if (ctx->device < 64 && (done.load(std::memory_order_relaxed) & bit)) return KOFFT_OK;
+    KOFFT_HIP_TRY(ctx, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (ctx->device < 64) done.fetch_or(bit, std::memory_order_relaxed);
+    return KOFFT_OK;
+}
+
+template <typename T, int L, int EPI, class IO, int BLOCK_OVERRIDE = 0>
+int launch_wg(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t batch)
+{
+    constexpr int RL = rl_for(L);
+    constexpr int BLOCK = BLOCK_OVERRIDE ? BLOCK_OVERRIDE : block_for(L);
+    constexpr int TPT = (1 << L) >> RL;
+    constexpr int XPB = BLOCK / TPT;
+    constexpr size_t lds = lds_wg_bytes<T, wg_split_lds<T, L, EPI, IO>(), IO::kSlotMinor, XPB>(1 << L);
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = fft_wg_kernel<T, L, RL, BLOCK, EPI, IO>;
+    if (lds > 64 * 1024) {
+        static std::atomic<unsigned long long> attr_done{0};
+        const int arc = set_dyn_lds_once(ctx, attr_done, reinterpret_cast<const void *>(kern), lds);
+        if (arc) return arc;
+    }
+    const size_t blocks = (batch + XPB - 1) / XPB;
+    if (blocks > 0x7fffffffULL) return KOFFT_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BLOCK), lds, ctx->stream, io, tw, batch);
+    KOFFT_HIP_TRY(ctx, hipGetLastError());
+    return KOFFT_OK;
+}
+
+// Persistent, prefetching kernels (fft_persist.hip.h): the streaming path for large batches.  Every workgroup walks the
+// batch with a stride of the grid size and keeps the next transform's loads in flight while it computes.
+// PersistCfg<L, IO> is the per-(size, policy) configuration, each value chosen by same-box A/B measurement:
+//   BLOCK / RL      threads per workgroup, log2 of the points per thread (threads per transform = n >> RL)
+//   MINW            waves per SIMD the kernel must fit (register budget); WG_PER_CU = workgroups launched per CU
+//   kInvInLds       window samples / irfft table in one LDS copy per workgroup instead of registers
+//   kTwLastInLds    the last pass reads its twiddles from an LDS copy of the table (frees 24..30 VGPRs)
+template <int L, class IO> struct PersistCfg;
+template <class IO> struct PersistCfgBase {
+    static constexpr int NBUF = 1, RL = 4;
+    static constexpr bool kInvInLds = IO::kInvInLds, kTwLastInLds = false;
+};
+template <class IO> struct PersistCfg<13, IO> : PersistCfgBase<IO> { static constexpr int BLOCK = 512, MINW = 2, WG_PER_CU = 1; };
+template <class IO> struct PersistCfg<12, IO> : PersistCfgBase<IO> { static constexpr int BLOCK = 256, MINW = 2, WG_PER_CU = 2; };
+template <class IO> struct PersistCfg<11, IO> : PersistCfgBase<IO> { static constexpr int BLOCK = 256, MINW = 2, WG_PER_CU = 2; };
+template <class IO> struct PersistCfg<10, IO> : PersistCfgBase<IO> {
+    static constexpr int BLOCK = 256, MINW = IO::kLeanRegisters ? 3 : 2, WG_PER_CU = MINW;
+};
+// irfft prefetches two row elements per output: the last pass reads its twiddles from LDS to stay inside 256 VGPRs
+template <> struct PersistCfg<10, IrfftIO<float>> {
+    static constexpr int BLOCK = 256, NBUF = 1, RL = 4, MINW = 2, WG_PER_CU = 2;
+    static constexpr bool kInvInLds = true, kTwLastInLds = true;
+};
+template <> struct PersistCfg<11, IrfftIO<float>> {
+    static constexpr int BLOCK = 256, NBUF = 1, RL = 4, MINW = 2, WG_PER_CU = 2;
+    static constexpr bool kInvInLds = true, kTwLastInLds = true;
+};
+// STFT n = 2048 / 4096 is compute-limited (more stages per point): with the window in LDS the kernel fits 3 waves/SIMD
+// (158 VGPRs), measured +5.5 % / +3.5 % (the memory-limited complex kernel LOSES 4 % with a third workgroup per CU).
+template <class IO> struct PersistCfgStftBig {
+    static constexpr int BLOCK = 256, NBUF = 1, RL = 4, MINW = 3, WG_PER_CU = 3;
+    static constexpr bool kInvInLds = true, kTwLastInLds = false;
+};
+template <> struct PersistCfg<12, StftIO> : PersistCfgStftBig<StftIO> {};
+template <> struct PersistCfg<11, StftIO> : PersistCfgStftBig<StftIO> {};
+template <> struct PersistCfg<12, StftMagIO> : PersistCfgStftBig<StftMagIO> {};
+template <> struct PersistCfg<11, StftMagIO> : PersistCfgStftBig<StftMagIO> {};
+// rfft 8192 (m = 4096): window pairs in registers so that two workgroups (exchange buffer + post-pass table) fit a CU
+template <> struct PersistCfg<12, RfftIO<float>> {
+    static constexpr int BLOCK = 256, NBUF = 1, RL = 4, MINW = 2, WG_PER_CU = 2;
+    static constexpr bool kInvInLds = false, kTwLastInLds = false;
+};
+// n = 64: 4 points per thread, 16 threads per transform, three passes of two stages
+template <class IO> struct PersistCfg<6, IO> {
+    static constexpr int BLOCK = 256, NBUF = 1, RL = 2, MINW = 4, WG_PER_CU = 4;
+    static constexpr bool kInvInLds = IO::kInvInLds, kTwLastInLds = false;
+};
+// n = 256, 128: 8 points per thread, 32 / 16 threads per transform -> 2 / 4 transforms per wavefront
+template <class IO> struct PersistCfg<8, IO> {
+    static constexpr int BLOCK = 256, NBUF = 1, RL = 3, MINW = 4, WG_PER_CU = 4;
+    static constexpr bool kInvInLds = IO::kInvInLds, kTwLastInLds = false;
+};
+template <class IO> struct PersistCfg<7, IO> {
+    static constexpr int BLOCK = 256, NBUF = 1, RL = 3, MINW = 4, WG_PER_CU = 4;
+    static constexpr bool kInvInLds = IO::kInvInLds, kTwLastInLds = false;
+};
+// n = 512: 8 points per thread so that a transform is still one wavefront (three passes of three stages)
+template <class IO> struct PersistCfg<9, IO> {
+    static constexpr int BLOCK = 256, NBUF = 1, RL = 3, MINW = 4, WG_PER_CU = 4;
+    static constexpr bool kInvInLds = IO::kInvInLds, kTwLastInLds = false;
+};
+
+// Workgroups per CU actually launched.  The rfft kernels (misaligned 8200-byte output rows, an extra LDS round trip)
+// stream better with FEWER concurrent rows once the batch no longer fits the 256 MiB Infinity Cache: measured at 4 GiB
+// of input, n = 512 / 1024 / 2048: +6 % / +4 % / +4 % with half the grid (config 3: 3.49 -> 3.37 ms; n = 128 / 256: the
+// persistent kernel only beats the generic one, by 10 %, with half the grid); at 512 MiB the
+// 2048-point kernel loses 10 % with half the grid, the two smaller ones still gain.  STFT and complex want the full grid.
+template <int L, class IO> struct PersistGrid {
+    static int wg_per_cu(int base, size_t) { return base; }
+};
+template <> struct PersistGrid<6, RfftIO<float>> { static int wg_per_cu(int base, size_t) { return base / 2; } };
+template <> struct PersistGrid<7, RfftIO<float>> { static int wg_per_cu(int base, size_t) { return base / 2; } };
+template <> struct PersistGrid<8, RfftIO<float>> { static int wg_per_cu(int base, size_t) { return base / 2; } };
+template <> struct PersistGrid<9, RfftIO<float>> { static int wg_per_cu(int base, size_t) { return base / 2; } };
+template <> struct PersistGrid<10, RfftIO<float>> {
+    static int wg_per_cu(int base, size_t input_bytes) { return input_bytes > (size_t(1) << 30) ? base / 2 : base; }
+};
+
+template <typename T, int L, int EPI, class IO>
+int launch_persist(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t batch)
+{
+    using Cfg = PersistCfg<L, IO>;
+    constexpr int RL = Cfg::RL;
+    constexpr int XPB = Cfg::BLOCK / ((1 << L) >> RL);
+    constexpr size_t lds = (size_t)XPB * Cfg::NBUF * lds_elems(1 << L) * sizeof(cpx<T>) +
+                           (Cfg::kInvInLds ? (size_t)(1 << L) * sizeof(typename IO::Inv) : 0) +
+                           (EPI == EPI_RFFT ? (size_t)(1 << L) * sizeof(cpx<T>) : 0) +
+                           (Cfg::kTwLastInLds ? (size_t)(1 << L) / 2 * sizeof(cpx<T>) : 0);
+    static_assert(lds * Cfg::WG_PER_CU <= 160 * 1024, "LDS budget");
+    auto kern = fft_persist_kernel<T, L, RL, EPI, IO, Cfg>;
+    {
+        static std::atomic<unsigned long long> attr_done{0};
+        const int arc = set_dyn_lds_once(ctx, attr_done, reinterpret_cast<const void *>(kern), lds);
+        if (arc) return arc;
+    }
+    size_t blocks = (size_t)ctx->num_cus * PersistGrid<L, IO>::wg_per_cu(Cfg::WG_PER_CU, batch * sizeof(cpx<T>) << L);
+    if (ctx->persist_grid_pct > 0) blocks = blocks * (size_t)ctx->persist_grid_pct / 100;  // measurement knob
+    if (blocks < 1) blocks = 1;
+    const size_t need = (batch + XPB - 1) / XPB;
+    if (blocks > need) blocks = need;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Cfg::BLOCK), lds, ctx->stream, io, tw, batch);
+    KOFFT_HIP_TRY(ctx, hipGetLastError());
+    return KOFFT_OK;
+}
+
+template <typename T, int N, int EPI, class IO>
+int launch_small(kofft_hip_ctx *ctx, const IO &io, size_t batch, const cpx<T> *tw = nullptr)
+{
+    const size_t blocks = (batch + kSmallBlock - 1) / kSmallBlock;
+    if (blocks > 0x7fffffffULL) return KOFFT_ERR_UNSUPPORTED;
+    constexpr size_t lds = small_lds_bytes<T, N>();
+    auto kern = fft_small_kernel<T, N, EPI, IO>;
+    if (lds > 64 * 1024) {
+        static std::atomic<unsigned long long> attr_done{0};
+        const int arc = set_dyn_lds_once(ctx, attr_done, reinterpret_cast<const void *>(kern), lds);
+        if (arc) return arc;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kSmallBlock), lds, ctx->stream, io, tw, batch);
+    KOFFT_HIP_TRY(ctx, hipGetLastError());
+    return KOFFT_OK;
+}
+
+// adjacent columns / rows per workgroup: 128-byte segments (16 x c32, 8 x c64) when the LDS budget allows
+// (measured, c32: 2^15..2^19 0.19 -> 0.225 of the roofline, 2^22..2^24 0.12 -> 0.15)
+#ifndef KOFFT_BIG_XPB
+#define KOFFT_BIG_XPB(T) (sizeof(T) == 4 ? 16 : 8)
+#endif
+template <typename T, class IO, int LS>
+constexpr int big_block()
+{
+    const int tpt = (1 << LS) >> rl_for(LS);
+    int xpb = KOFFT_BIG_XPB(T);
+    while (xpb > 1 && (xpb * tpt > 1024 || (size_t)xpb * (1 << LS) * 8 > 80 * 1024)) xpb /= 2;
+    int block = xpb * tpt;
+    if (block < 64) block = 64;
+    return block;
+}
+
+// Run the n-point transform described by `io` (n a power of two >= 1) over `batch` units.
+template <typename T, int EPI, class IO>
+int dispatch(kofft_hip_ctx *ctx, const IO &io, size_t n, size_t batch)
+{
+    if (batch == 0) return KOFFT_OK;
+    const int L = ilog2(n);
+    if (L > max_log2<T>()) return KOFFT_ERR_UNSUPPORTED;
+    switch (L) {
+    case 0: return launch_small<T, 1, EPI>(ctx, io, batch);
+    case 1: return launch_small<T, 2, EPI>(ctx, io, batch);
+    case 2: return launch_small<T, 4, EPI>(ctx, io, batch);
+    case 3: return launch_small<T, 8, EPI>(ctx, io, batch);
+    case 4: return launch_small<T, 16, EPI>(ctx, io, batch);
+    default: break;
+    }
+    const cpx<T> *tw = nullptr;
+    int rc = get_table<T>(ctx, Kind<T>::tw, n, &tw);
+    if (rc) return rc;
+    // n = 32 in f32: still one thread per transform (64 data registers), IO staged through LDS like the small sizes
+    if constexpr (sizeof(T) == 4 && !IO::kSlotMinor) if (L == 5) return launch_small<T, 32, EPI>(ctx, io, batch, tw);
+    if constexpr (sizeof(T) == 4 && IO::kPersist) if (ctx->use_persist) {
+        // streaming sizes: enough transforms to give every resident workgroup several iterations
+        if constexpr (EPI == EPI_STORE && IO::kPersistMaxLog2 >= 13) {
+            if (L == 13 && batch >= (size_t)ctx->num_cus * 4) return launch_persist<T, 13, EPI>(ctx, io, tw, batch);
+            if (L == 12 && batch >= (size_t)ctx->num_cus * 4) return launch_persist<T, 12, EPI>(ctx, io, tw, batch);
+        }
+        if constexpr (EPI == EPI_RFFT) {
+            if (L == 12 && batch >= (size_t)ctx->num_cus * 4) return launch_persist<T, 12, EPI>(ctx, io, tw, batch);
+        }
+        if (L == 11 && batch >= (size_t)ctx->num_cus * 16) return launch_persist<T, 11, EPI>(ctx, io, tw, batch);
+        if (L == 10 && batch >= (size_t)ctx->num_cus * 32) return launch_persist<T, 10, EPI>(ctx, io, tw, batch);
+        if (L == 9 && batch >= (size_t)ctx->num_cus * 64) return launch_persist<T, 9, EPI>(ctx, io, tw, batch);
+        if (ctx->persist_small && io.group_rows_ok()) {
+            if constexpr (IO::kPersistMinLog2 <= 8)
+                if (L == 8 && batch >= (size_t)ctx->num_cus * 128) return launch_persist<T, 8, EPI>(ctx, io, tw, batch);
+            if constexpr (IO::kPersistMinLog2 <= 7)
+                if (L == 7 && batch >= (size_t)ctx->num_cus * 256) return launch_persist<T, 7, EPI>(ctx, io, tw, batch);
+            if constexpr (IO::kPersistMinLog2 <= 6)
+                if (L == 6 && batch >= (size_t)ctx->num_cus * 512) return launch_persist<T, 6, EPI>(ctx, io, tw, batch);
+        }
+    }
+    switch (L) {
+    // lane-over-lines policies (strided axes): as many adjacent lines per workgroup as big_block allows (128-byte segments)
+#define KOFFT_CASE(LL) \
+    case LL: return launch_wg<T, LL, EPI, IO, (IO::kSlotMinor ? big_block<T, IO, LL>() : 0)>(ctx, io, tw, batch);
+        KOFFT_CASE(5)
+        KOFFT_CASE(6)
+        KOFFT_CASE(7)
+        KOFFT_CASE(8)
+        KOFFT_CASE(9)
+        KOFFT_CASE(10)
+        KOFFT_CASE(11)
+        KOFFT_CASE(12)
+        KOFFT_CASE(13)
+    case 14:
+        if constexpr (sizeof(T) == 4) return launch_wg<T, 14, EPI>(ctx, io, tw, batch);
+        else return KOFFT_ERR_UNSUPPORTED;
+#undef KOFFT_CASE
+    default: return KOFFT_ERR_UNSUPPORTED;
+    }
+}
+
+template <typename T> constexpr int max_log2_big() { return 26; }
+
+// ---- typed device-pointer entry points, one translation unit per family ---------------------------------------------
+template <typename T>
+int fft_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t batch, int inverse);  // k_complex_f32/f64.hip
+template <typename T>
+int rfft_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, const T *d_window, size_t n, size_t batch);  // k_real_f32/f64.hip
+template <typename T>
+int irfft_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t batch);
+int stft_dev(kofft_hip_ctx *ctx, const float *d_signal, size_t len, const float *d_window, size_t win_len, size_t start0,
+             size_t hop, float *d_out, size_t count);  // k_stft.hip
+int istft_dev(kofft_hip_ctx *ctx, float *d_frames, size_t frames, const float *d_window, size_t win_len, size_t hop,
+              float *d_output, size_t out_len, float *d_scratch, size_t scratch_len, int mode = 1, size_t start0 = 0);
+int stft_mag_dev(kofft_hip_ctx *ctx, const float *d_samples, size_t len, size_t win_len, size_t hop, float *d_mags,
+                 size_t frames, float *d_max);
+template <typename T>
+int fft_nd_dev(kofft_hip_ctx *ctx, T *d_data, size_t depth, size_t rows, size_t cols, int inverse);  // k_nd.hip
+
+}  // namespace host
+}  // namespace kofft

@@ -1,0 +1,8 @@
+// k_complex_f64.hip -- Complex<double> transforms (fft.rs:1054-1174): every kernel instance of the family.
+#include "complex_impl.hip.h"
+
+namespace kofft {
+namespace host {
+template int fft_dev<double>(kofft_hip_ctx *, const double *, double *, size_t, size_t, int);
+}  // namespace host
+}  // namespace kofft

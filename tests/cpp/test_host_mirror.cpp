@@ -310,6 +310,21 @@ int main()
         FftPlan<float>(64, FftStrategy::Radix4, fft).fft(x64).unwrap();  // the correct transform
         CHECK(same_bits(x64, want));
     }
+    {   // multi-GPU STFT through the C++ mirror: one device here, same path as G devices
+        std::vector<float> sig(3000), window = hann(256);
+        for (size_t i = 0; i < sig.size(); ++i) sig[i] = std::sin(0.05f * (float)i);
+        const size_t frames = (sig.size() + 63) / 64;
+        std::vector<std::vector<Complex32>> a(frames), b(frames), c(frames);
+        stft(sig, window, 64, a, fft).unwrap();
+        HipMulti multi(1);
+        CHECK(multi.ngpu() == 1);
+        multi.stft(sig, window, 64, b, false).unwrap();
+        multi.stft(sig, window, 64, c, true).unwrap();  // with the RCCL all-gather
+        for (size_t f = 0; f < frames; ++f) CHECK(same_bits(a[f], b[f]) && same_bits(a[f], c[f]));
+        std::vector<std::vector<Complex32>> few(2);
+        CHECK(multi.stft(sig, window, 64, few) == Result::Err(FftError::MismatchedLengths));
+        CHECK(multi.stft(sig, window, 0, b) == Result::Err(FftError::InvalidHopSize));
+    }
     std::printf("%d checks, %d failed\n", g_checks, g_fail);
     return g_fail == 0 ? 0 : 1;
 }

@@ -90,3 +90,32 @@ def test_argument_validation_needs_no_device(hiplib):
     assert hiplib.kofft_hip_stft_parallel_f32(null, p, sz(10), p, sz(4), sz(0), p, sz(1)) == 5
     assert hiplib.kofft_hip_stft_parallel_f32(null, p, sz(10), p, sz(4), sz(4), p, sz(2)) == -3  # no frames check
     assert hiplib.kofft_hip_stft_f32_dev(null, p, sz(10), p, sz(4), sz(0), p, sz(0), sz(1)) == 5
+
+
+def test_multi_gpu_entry_validates_without_a_device(hiplib):
+    """kofft_hip_stft_f32_multi (SURVEY 8b): stft::stft's checks in its order (stft.rs:83-87) come before any device call."""
+    buf = np.zeros(64, np.float32)
+    p = C.c_void_p(buf.ctypes.data)
+    sz = C.c_size_t
+    f = hiplib.kofft_hip_stft_f32_multi
+    assert f(0, p, sz(10), p, sz(4), sz(2), p, sz(5), 0) == 6     # ngpu <= 0 -> InvalidValue
+    assert f(-3, p, sz(10), p, sz(4), sz(2), p, sz(5), 1) == 6
+    assert f(2, p, sz(10), p, sz(4), sz(0), p, sz(5), 0) == 5     # hop == 0 -> InvalidHopSize
+    assert f(2, p, sz(10), p, sz(4), sz(4), p, sz(2), 0) == 3     # frames < ceil(len/hop) -> MismatchedLengths (tests/stft.rs:6-14)
+    assert f(2, p, sz(0), p, sz(4), sz(2), p, sz(0), 1) == 0      # nothing to do
+    assert f(2, p, sz(10), p, sz(0), sz(4), p, sz(3), 0) == 1     # empty window -> fft(&mut []) -> EmptyInput
+    assert f(2, p, sz(10), None, sz(4), sz(4), p, sz(3), 0) == -3  # null window
+    assert f(2, p, sz(10), p, sz(4), sz(4), None, sz(3), 0) == -3  # null output
+    # handle form: null handle / bad arguments
+    h = C.c_void_p()
+    assert hiplib.kofft_hip_multi_create(0, None, C.byref(h)) == 6 and not h.value
+    assert hiplib.kofft_hip_multi_create(1, None, None) == -3
+    assert hiplib.kofft_hip_multi_destroy(None) == -3
+    assert hiplib.kofft_hip_multi_ngpu(None) == 0
+    assert hiplib.kofft_hip_multi_stft_f32(None, p, sz(10), p, sz(4), sz(0), p, sz(3), 0, None) == 5
+    assert hiplib.kofft_hip_multi_stft_f32(None, p, sz(10), p, sz(4), sz(4), p, sz(2), 0, None) == 3
+    assert hiplib.kofft_hip_multi_stft_f32(None, p, sz(10), p, sz(4), sz(4), p, sz(3), 0, None) == -3
+    assert hiplib.kofft_hip_multi_fft_c32(None, p, sz(0), sz(1), 0) == 1
+    assert hiplib.kofft_hip_multi_fft_c32(None, p, sz(8), sz(0), 0) == 0
+    assert hiplib.kofft_hip_multi_fft_c32(None, p, sz(8), sz(1), 0) == -3
+    assert b"RCCL" in hiplib.kofft_hip_strerror(-5)
