@@ -2,9 +2,15 @@
 //
 // The device never computes trigonometry: kofft's tables are produced by rounding-
 // sensitive recurrences, so they are generated here, with the reference's exact
-// order of operations, and uploaded.  Compiled with g++ -ffp-contract=off; sinf/cosf/
-// fmaf come from glibc, which is what Rust's f32::sin_cos / mul_add lower to on
-// x86_64-unknown-linux-gnu.
+// order of operations, and uploaded.  Compiled with g++ -ffp-contract=off; fmaf / fma and
+// sincosf / sincos come from glibc: Rust's mul_add lowers to the former, and its sin_cos()
+// -- `(self.sin(), self.cos())` in std -- is merged by LLVM into the latter on
+// x86_64-unknown-linux-gnu.  The pair is requested with ONE explicit sincos call so that the
+// tables do not depend on this compiler's own merging heuristics (f64 sincos differs from
+// sin / cos in the last bit for ~0.14 % of arguments in glibc 2.35; sincosf never does).
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE
+#endif
 #include "tables.h"
 
 #include <cmath>
@@ -14,14 +20,12 @@ namespace {
 template <typename T> struct Num;
 template <> struct Num<float> {
     static float pi() { return 3.14159265358979323846f; }  // core::f32::consts::PI
-    static float sin(float x) { return sinf(x); }
-    static float cos(float x) { return cosf(x); }
+    static void sin_cos(float x, float *s, float *c) { ::sincosf(x, s, c); }
     static float fma(float a, float b, float c) { return fmaf(a, b, c); }
 };
 template <> struct Num<double> {
     static double pi() { return 3.14159265358979323846; }  // core::f64::consts::PI
-    static double sin(double x) { return ::sin(x); }
-    static double cos(double x) { return ::cos(x); }
+    static void sin_cos(double x, double *s, double *c) { ::sincos(x, s, c); }
     static double fma(double a, double b, double c) { return ::fma(a, b, c); }
 };
 
@@ -31,7 +35,8 @@ void twiddles(size_t n, T *out)
 {
     const size_t half = n / 2;
     const T angle = (-(T)2.0f * Num<T>::pi()) / (T)(float)n;
-    const T s = Num<T>::sin(angle), c = Num<T>::cos(angle);
+    T s, c;
+    Num<T>::sin_cos(angle, &s, &c);
     T w_re = (T)1, w_im = (T)0;
     for (size_t k = 0; k < half; ++k) {
         out[2 * k] = w_re;
@@ -47,7 +52,8 @@ template <typename T>
 void rfft_table(size_t m, T *out)
 {
     const T angle = -Num<T>::pi() / (T)(float)m;
-    const T s = Num<T>::sin(angle), c = Num<T>::cos(angle);
+    T s, c;
+    Num<T>::sin_cos(angle, &s, &c);
     T re = (T)1, im = (T)0;
     for (size_t k = 0; k < m; ++k) {
         out[2 * k] = re;
@@ -67,10 +73,9 @@ void bluestein(size_t n, size_t m, T *chirp, T *b)
     for (size_t i = 0; i < 2 * m; ++i) b[i] = (T)0;
     for (size_t i = 0; i < n; ++i) {
         const T angle = Num<T>::pi() * (T)(float)(i * i) / (T)(float)n;
-        chirp[2 * i] = Num<T>::cos(-angle);
-        chirp[2 * i + 1] = Num<T>::sin(-angle);
-        b[2 * i] = Num<T>::cos(angle);
-        b[2 * i + 1] = Num<T>::sin(angle);
+        // Complex::expi (num.rs:123-126): re = cos, im = sin of one sin_cos() call
+        Num<T>::sin_cos(-angle, &chirp[2 * i + 1], &chirp[2 * i]);
+        Num<T>::sin_cos(angle, &b[2 * i + 1], &b[2 * i]);
     }
     for (size_t i = 1; i < n; ++i) {
         b[2 * (m - i)] = b[2 * i];

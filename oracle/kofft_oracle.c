@@ -7,6 +7,9 @@
  */
 #include "kofft_oracle.h"
 
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE /* sincosf / sincos */
+#endif
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -14,7 +17,7 @@
 /* ---- f32 instantiation ---- */
 #define REAL float
 #define SFX(name) name##_f32
-#define RSIN sinf
+#define RSINCOS sincosf
 #define RCOS cosf
 #define RFMA fmaf
 /* core::f32::consts::PI (num.rs:2, 57-59) */
@@ -22,7 +25,7 @@
 #include "kofft_oracle_impl.inc"
 #undef REAL
 #undef SFX
-#undef RSIN
+#undef RSINCOS
 #undef RCOS
 #undef RFMA
 #undef R_PI
@@ -30,7 +33,7 @@
 /* ---- f64 instantiation ---- */
 #define REAL double
 #define SFX(name) name##_f64
-#define RSIN sin
+#define RSINCOS sincos
 #define RCOS cos
 #define RFMA fma
 /* core::f64::consts::PI (num.rs:91-93) */
@@ -38,7 +41,7 @@
 #include "kofft_oracle_impl.inc"
 #undef REAL
 #undef SFX
-#undef RSIN
+#undef RSINCOS
 #undef RCOS
 #undef RFMA
 #undef R_PI
@@ -118,6 +121,45 @@ int ko_istft_f32(float *frames_data, size_t frames, const float *window, size_t 
     for (size_t i = 0; i < out_len; ++i)
         if (scratch[i] > 1e-8f) output[i] /= scratch[i];
     return KO_OK;
+}
+
+/* visual::spectrogram::stft_magnitudes (visual/spectrogram.rs:52-76): window = hann(win_len) (window.rs:24-28), frames =
+ * ceil(len / hop) STFT frames (compute_stft = stft.rs:76-105), then for the first win_len/2 bins of every frame
+ *   mag = (c.re * c.re + c.im * c.im).sqrt()        -- f32, un-fused, correctly rounded sqrt (spectrogram.rs:66)
+ *   if mag > max_mag { max_mag = mag }              -- a NaN is never selected (spectrogram.rs:68-70)
+ * mags: frames * (win_len/2) floats, row-major.  hop == 0: the reference divides by it (div_ceil) and panics. */
+int ko_stft_magnitudes_f32(const float *samples, size_t len, size_t win_len, size_t hop, float *mags, float *max_mag)
+{
+    if (hop == 0) return KO_ERR_INVALID_HOP_SIZE;
+    const size_t frames = (len + hop - 1) / hop;
+    const size_t height = win_len / 2;
+    *max_mag = 0.0f;
+    if (frames == 0) return KO_OK;
+    float *window = (float *)malloc((win_len ? win_len : 1) * sizeof(float));
+    float *spec = (float *)malloc((frames * win_len * 2 + 1) * sizeof(float));
+    if (!window || !spec) {
+        free(window);
+        free(spec);
+        return KO_ERR_ALLOC;
+    }
+    ko_hann_f32(win_len, window);
+    int rc = ko_stft_f32(samples, len, window, win_len, hop, spec, frames);
+    if (rc == KO_OK) {
+        float mx = 0.0f;
+        for (size_t x = 0; x < frames; ++x) {
+            for (size_t y = 0; y < height; ++y) {
+                const float re = spec[2 * (x * win_len + y)], im = spec[2 * (x * win_len + y) + 1];
+                const float rr = re * re, ii = im * im;
+                const float mag = sqrtf(rr + ii);
+                mags[x * height + y] = mag;
+                if (mag > mx) mx = mag;
+            }
+        }
+        *max_mag = mx;
+    }
+    free(window);
+    free(spec);
+    return rc;
 }
 
 const char *ko_strerror(int code)

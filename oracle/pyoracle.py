@@ -168,3 +168,13 @@ def istft(frames: np.ndarray, window: np.ndarray, hop: int, out_len: int) -> np.
     _chk(lib().ko_istft_f32(_p(fr), _SZ(fr.shape[0]), _p(win), _SZ(win.size), _SZ(hop), _p(out), _SZ(out_len),
                             _p(scratch), _SZ(out_len)))
     return out
+
+
+def stft_magnitudes(samples: np.ndarray, win_len: int, hop: int):
+    """visual::spectrogram::stft_magnitudes (visual/spectrogram.rs:52-76): (mags[frames, win_len/2], max_mag)."""
+    sig = np.ascontiguousarray(samples, np.float32)
+    frames = -(-sig.size // int(hop)) if hop else 0
+    mags = np.zeros((frames, int(win_len) // 2), np.float32)
+    mx = C.c_float(0.0)
+    _chk(lib().ko_stft_magnitudes_f32(_p(sig), _SZ(sig.size), _SZ(int(win_len)), _SZ(int(hop)), _p(mags), C.byref(mx)))
+    return mags, float(mx.value)

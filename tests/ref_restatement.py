@@ -12,8 +12,8 @@ Independent of oracle/ in:
   * FMA -- `mul_add` is evaluated in exact rational arithmetic and rounded ONCE to the target type (ties to even),
     instead of calling fmaf()/fma();
   * trigonometry -- glibc libm through ctypes (Rust's f32::sin / cos / sin_cos lower to sinf / cosf / sincosf on
-    x86_64-unknown-linux-gnu); `sincosf_equals_sinf_cosf` lets a test check the one assumption that cannot be read off
-    the source: whether LLVM merges the two calls into sincosf and whether that changes a bit.
+    x86_64-unknown-linux-gnu); `sin_cos_separate` lets a test measure the one assumption that cannot be read off the
+    source: whether LLVM merges the two calls into sincos[f], and where that changes a bit.
 
 Each function cites the reference lines it follows (okian/kofft v0.1.5).
 """
@@ -43,15 +43,16 @@ def _cplx(dtype):
     return np.complex64 if _real(dtype) is np.float32 else np.complex128
 
 
-def sin_cos(x, dtype):
-    """Float::sin_cos (num.rs:56-58 / 93-95): (sin, cos) from the platform libm, one call each."""
+def sin_cos_separate(x, dtype):
+    """(sin, cos) from two libm calls: what Rust's std source says literally (`(self.sin(), self.cos())`)."""
     if _real(dtype) is np.float32:
         return np.float32(_libm.sinf(float(x))), np.float32(_libm.cosf(float(x)))
     return np.float64(_libm.sin(float(x))), np.float64(_libm.cos(float(x)))
 
 
-def sincos_merged(x, dtype):
-    """The same pair from the merged libm entry point (what LLVM emits when it combines sin and cos of one operand)."""
+def sin_cos(x, dtype):
+    """Float::sin_cos (num.rs:56-58 / 93-95) as a linux-gnu build executes it: LLVM merges the sin and the cos of one
+    operand into ONE sincosf / sincos libcall.  (f32: bit-identical to two calls; f64: not always -- see the tests.)"""
     if _real(dtype) is np.float32:
         s, c = C.c_float(), C.c_float()
         _libm.sincosf(float(x), C.byref(s), C.byref(c))

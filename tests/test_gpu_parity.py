@@ -483,13 +483,11 @@ def test_stft_magnitudes_match_oracle(fft32, oracle, win_len, hop, length):
     sqrt(re*re + im*im) in f32, and the maximum.  The last size takes the streaming kernel with the fused store."""
     rng = seeded(1400 + win_len)
     samples = rng.uniform(-1, 1, length).astype(np.float32)
-    frames = -(-length // hop)
-    spec = oracle.stft(samples, oracle.hann(win_len), hop, frames)[:, : win_len // 2]
-    re, im = spec.real.astype(np.float32), spec.imag.astype(np.float32)
-    want = np.sqrt((re * re + im * im).astype(np.float32)).astype(np.float32)  # f32 products, f32 sum, correctly rounded sqrt
+    want, want_max = oracle.stft_magnitudes(samples, win_len, hop)  # oracle/kofft_oracle.c: spectrogram.rs:52-76 restated
     mags, mx = fft32.stft_magnitudes(samples, win_len, hop)
     assert_parity(mags, want, f"stft_magnitudes win={win_len}", REL_TOL_F32)
-    assert mx == float(want.max())
+    assert bits_equal(mags, want)
+    assert mx == want_max
 
 
 # ---- 2-D / 3-D FFT (SURVEY 8f row 3) ---------------------------------------------------------------------------------------

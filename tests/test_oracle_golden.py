@@ -85,3 +85,54 @@ def test_tables_bitwise_and_drift(oracle, gold):
     # the first entry is exactly (1, 0); the quarter-turn entry is NOT exactly (0, -1): no symmetry shortcuts
     t = gold["twiddles32_4096"]["table"]
     assert t[0] == 1 + 0j and t[1024] != 0 - 1j
+
+
+def test_bin_export_matches_the_oracle(oracle):
+    """tests/golden/bin (consumed by integration/rust/kofft-hip/tests/golden_pin.rs) is the oracle's output on the stored
+    inputs: every case of the manifest is recomputed here, so the fixtures cannot go stale unnoticed."""
+    bindir = GOLDEN / "bin"
+    lines = [ln.split("\t") for ln in (bindir / "manifest.tsv").read_text().splitlines() if ln.strip()]
+    assert len(lines) >= 45
+
+    def rd(case, field, dtype):
+        return np.frombuffer((bindir / f"{case}.{field}.bin").read_bytes(), dtype=dtype)
+
+    kinds = set()
+    for cols in lines:
+        kind, case = cols[0], cols[1]
+        p = dict(c.split("=") for c in cols[2:])
+        kinds.add(kind)
+        if kind == "fft":
+            cdt = np.complex64 if p["dtype"] == "c32" else np.complex128
+            x = rd(case, "x", cdt)
+            assert x.size == int(p["n"])
+            assert bits_equal(oracle.fft(x), rd(case, "y", cdt)), case
+            assert bits_equal(oracle.ifft(x), rd(case, "y_inv", cdt)), case
+        elif kind == "rfft":
+            rdt, cdt = (np.float32, np.complex64) if p["dtype"] == "f32" else (np.float64, np.complex128)
+            x = rd(case, "x", rdt)
+            win = rd(case, "window", rdt) if p["window"] == "1" else None
+            y = rd(case, "y", cdt)
+            assert bits_equal(oracle.rfft(x, win), y), case
+            assert bits_equal(oracle.irfft(y, x.size), rd(case, "x_back", rdt)), case
+        elif kind == "stft":
+            got = oracle.stft(rd(case, "signal", np.float32), rd(case, "window", np.float32), int(p["hop"]), int(p["frames"]))
+            assert bits_equal(got.ravel(), rd(case, "frames", np.complex64)), case
+        elif kind == "istft":
+            fr = rd(case, "frames", np.complex64).reshape(int(p["frames"]), int(p["win"]))
+            got = oracle.istft(fr, rd(case, "window", np.float32), int(p["hop"]), int(p["out_len"]))
+            assert bits_equal(got, rd(case, "output", np.float32)), case
+        elif kind == "mags":
+            mags, mx = oracle.stft_magnitudes(rd(case, "samples", np.float32), int(p["win"]), int(p["hop"]))
+            assert bits_equal(mags.ravel(), rd(case, "mags", np.float32)) and np.float32(mx) == rd(case, "max", np.float32)[0], case
+        elif kind == "twiddles":
+            dt = np.float32 if p["dtype"] == "f32" else np.float64
+            assert bits_equal(oracle.get_twiddles(int(p["n"]), dt), rd(case, "table", np.complex64 if dt == np.float32 else np.complex128)), case
+        elif kind == "rffttab":
+            dt = np.float32 if p["dtype"] == "f32" else np.float64
+            assert bits_equal(oracle.rfft_table(int(p["m"]), dt), rd(case, "table", np.complex64 if dt == np.float32 else np.complex128)), case
+        elif kind == "hann":
+            assert bits_equal(oracle.hann(int(p["len"])), rd(case, "table", np.float32)), case
+        else:
+            raise AssertionError(kind)
+    assert kinds == {"fft", "rfft", "stft", "istft", "mags", "twiddles", "rffttab", "hann"}
