@@ -11,10 +11,52 @@ namespace host {
 // large n: two factors (fft_big.hip.h)
 // ---------------------------------------------------------------------------------
 
+// The persistent, prefetching form of a factor (fft_tile_persist_kernel): 512 threads per CU (one or several workgroups),
+// so that every thread may use 256 registers -- two register sets and a pass's twiddles, no scratch.
+template <typename T, int LS, class IO>
+int launch_tile_persist(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t units)
+{
+    constexpr int RL = rl_for(LS);
+    constexpr int BLOCK = big_block<T, IO, LS>();
+    constexpr int TPT = (1 << LS) >> RL;
+    constexpr int XPB = BLOCK / TPT;
+    constexpr size_t lds = lds_wg_bytes<T, IO::kSplitLds, true, XPB>(1 << LS) +
+                           (IO::kTileInvariantTw ? (size_t(1) << LS) / 2 * sizeof(cpx<T>) : 0);  // + the first factor's table copy
+    constexpr int WG_PER_CU = BLOCK >= 512 ? 1 : 512 / BLOCK;
+    static_assert(lds * WG_PER_CU <= 160 * 1024, "LDS budget");
+    if (units % XPB != 0) return KOFFT_ERR_UNSUPPORTED;  // (never: units = transforms << bits, bits >= 7)
+    auto kern = fft_tile_persist_kernel<T, LS, RL, BLOCK, IO>;
+    if (lds > 64 * 1024) {
+        static std::atomic<unsigned long long> attr_done{0};
+        const int arc = set_dyn_lds_once(ctx, attr_done, reinterpret_cast<const void *>(kern), lds);
+        if (arc) return arc;
+    }
+    const size_t ntiles = units / XPB;
+    size_t blocks = (size_t)ctx->num_cus * WG_PER_CU;
+    if (ctx->persist_grid_pct > 0) blocks = blocks * (size_t)ctx->persist_grid_pct / 100;
+    if (blocks < 1) blocks = 1;
+    if (blocks > ntiles) blocks = ntiles;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BLOCK), lds, ctx->stream, io, tw, ntiles);
+    KOFFT_HIP_TRY(ctx, hipGetLastError());
+    return KOFFT_OK;
+}
+
 // Launch the generic kernel for a sub-transform of log2 size LS with an arbitrary IO policy.
 template <typename T, class IO>
 int launch_sub(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, int LS, size_t units)
 {
+    if (ctx->big_persist && units >= (size_t)ctx->num_cus * 64) {  // every resident workgroup gets several tiles
+        switch (LS) {
+#define KOFFT_CASE(LL) \
+    case LL: return launch_tile_persist<T, LL, IO>(ctx, io, tw, units);
+            KOFFT_CASE(7)
+            KOFFT_CASE(8)
+            KOFFT_CASE(9)
+            KOFFT_CASE(10)
+#undef KOFFT_CASE
+        default: break;  // 2^11 .. 2^13-point factors: tiles of 4, 2, 1 units -- the one-tile-per-workgroup kernel
+        }
+    }
     switch (LS) {
     // 16 (c32) / 8 (c64) adjacent columns or rows per workgroup = 128-byte segments while the tile fits the LDS budget
     // (sub-transforms up to 2^9 points; 2^10: 8; larger ones fewer still -- big_block).
@@ -36,6 +78,14 @@ int launch_sub(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, int LS, size_
 template <typename T>
 int launch_mid(kofft_hip_ctx *ctx, const BigMidIO<T> &io, const cpx<T> *tw, int LS, size_t units)
 {
+    if (ctx->big_persist && units >= (size_t)ctx->num_cus * 64) {
+        switch (LS) {
+        case 7: return launch_tile_persist<T, 7, BigMidIO<T>>(ctx, io, tw, units);
+        case 8: return launch_tile_persist<T, 8, BigMidIO<T>>(ctx, io, tw, units);
+        case 9: return launch_tile_persist<T, 9, BigMidIO<T>>(ctx, io, tw, units);
+        default: break;
+        }
+    }
     switch (LS) {
     case 7: return launch_wg<T, 7, EPI_STORE, BigMidIO<T>, big_block<T, BigMidIO<T>, 7>()>(ctx, io, tw, units);
     case 8: return launch_wg<T, 8, EPI_STORE, BigMidIO<T>, big_block<T, BigMidIO<T>, 8>()>(ctx, io, tw, units);
@@ -94,6 +144,9 @@ int fft_big_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t ba
         // last factor: the remaining L3 stages along contiguous rows, prefix K of L - L3 bits, output transposed
         const int LP = L - L3;
         BigRowsIO<T, INVERSE> b{last_in, dst, LP, L3, L - L3, L - 1 - LP, n, scale, big_rows_per_wg<T>(L3) * sizeof(cpx<T>) >= 64};
+        // an intermediate small enough to stay in the 256 MiB Infinity Cache is read with plain loads (measured on a
+        // copy model, tools/ubench_mall: streaming hints on the caller's buffers only, 3.1 -> 2.5 ms per 2 x 4 GiB)
+        b.nt_load = ctx->big_mid_nt >= 0 ? ctx->big_mid_nt != 0 : nb * xf_bytes > (size_t(192) << 20);
         rc = launch_sub<T>(ctx, b, tw, L3, nb << LP);
         if (rc) return rc;
     }

@@ -23,6 +23,8 @@
 // lives in a scratch buffer of `chunk` transforms so that factor B reads it back from the Infinity Cache.
 #pragma once
 
+#include <type_traits>
+
 #include "fft_wg.hip.h"
 
 namespace kofft {
@@ -42,7 +44,18 @@ struct BigColsIO {
     int LB;     // log2 of the column count
     int shift;  // L - LA
     size_t n;   // full transform length
+    static constexpr bool nt = false;  // the intermediate is read back by the next factor: plain stores
     __device__ __forceinline__ TwSubFirst tw_map(size_t) const { return TwSubFirst{shift}; }
+    // tile forms (fft_tile_persist_kernel): local index i of unit xf lives at  transform(xf) * n + off(xf) + (i << sl)
+    static constexpr bool kConjIn = INVERSE, kConjScaleOut = false, kNtOut = false;
+    static constexpr bool kTileInvariantTw = true;  // no frequency prefix yet: every tile uses the same 2^(L_sub-1) table entries
+    __device__ __forceinline__ bool nt_in() const { return true; }
+    __device__ __forceinline__ T out_scale() const { return T(1); }
+    __device__ __forceinline__ size_t xf_transform(size_t xf) const { return xf >> LB; }
+    __device__ __forceinline__ unsigned in_off(size_t xf) const { return (unsigned)(xf & ((size_t(1) << LB) - 1)); }
+    __device__ __forceinline__ int in_sl() const { return LB; }
+    __device__ __forceinline__ unsigned out_off(size_t xf) const { return in_off(xf); }
+    __device__ __forceinline__ int out_sl() const { return LB; }
     __device__ __forceinline__ cpx<T> load(size_t xf, int c) const
     {
         const size_t b = xf >> LB, j = xf & ((size_t(1) << LB) - 1);
@@ -74,11 +87,22 @@ struct BigRowsIO {
     size_t n;
     T scale;    // 1 / (n as f32 as T), fft.rs:1167
     bool nt;    // non-temporal stores: only when a workgroup's adjacent rows fill at least 64-byte segments
+    bool nt_load = true;  // the intermediate is read once: streaming hint, unless it is meant to be served by the Infinity Cache
     __device__ __forceinline__ TwSub tw_map(size_t xf) const { return TwSub{shift, (int)(xf & ((size_t(1) << LA) - 1)), kbase}; }
+    static constexpr bool kConjIn = false, kConjScaleOut = INVERSE, kNtOut = true;
+    static constexpr bool kTileInvariantTw = false;  // the table index carries the row's prefix K
+    __device__ __forceinline__ bool nt_in() const { return nt_load; }
+    __device__ __forceinline__ T out_scale() const { return scale; }
+    __device__ __forceinline__ size_t xf_transform(size_t xf) const { return xf >> LA; }
+    __device__ __forceinline__ unsigned in_off(size_t xf) const { return (unsigned)((xf & ((size_t(1) << LA) - 1)) << LB); }
+    __device__ __forceinline__ int in_sl() const { return 0; }
+    __device__ __forceinline__ unsigned out_off(size_t xf) const { return (unsigned)(xf & ((size_t(1) << LA) - 1)); }
+    __device__ __forceinline__ int out_sl() const { return LA; }
     __device__ __forceinline__ cpx<T> load(size_t xf, int c) const
     {
         const size_t b = xf >> LA, K = xf & ((size_t(1) << LA) - 1);
-        return ld_stream(in + b * n + (K << LB) + (size_t)c);  // the intermediate is read exactly once
+        const cpx<T> *p = in + b * n + (K << LB) + (size_t)c;
+        return nt_load ? ld_stream(p) : *p;  // the intermediate is read exactly once
     }
     __device__ __forceinline__ void store(size_t xf, int q, cpx<T> v) const
     {
@@ -109,10 +133,28 @@ struct BigMidIO {
     int shift;  // L - LS
     int kbase;  // L - 1 - S
     size_t n;
+    static constexpr bool nt = false;
     __device__ __forceinline__ TwSub tw_map(size_t xf) const
     {
         return TwSub{shift, (int)((xf >> JB) & ((size_t(1) << S) - 1)), kbase};
     }
+    static constexpr bool kConjIn = false, kConjScaleOut = false, kNtOut = false;
+    static constexpr bool kTileInvariantTw = false;
+    __device__ __forceinline__ bool nt_in() const { return true; }
+    __device__ __forceinline__ T out_scale() const { return T(1); }
+    __device__ __forceinline__ size_t xf_transform(size_t xf) const { return xf >> (S + JB); }
+    __device__ __forceinline__ unsigned in_off(size_t xf) const
+    {
+        const size_t K = (xf >> JB) & ((size_t(1) << S) - 1), j = xf & ((size_t(1) << JB) - 1);
+        return (unsigned)((K << (LS + JB)) + j);
+    }
+    __device__ __forceinline__ int in_sl() const { return JB; }
+    __device__ __forceinline__ unsigned out_off(size_t xf) const
+    {
+        const size_t K = (xf >> JB) & ((size_t(1) << S) - 1), j = xf & ((size_t(1) << JB) - 1);
+        return (unsigned)((K << JB) + j);
+    }
+    __device__ __forceinline__ int out_sl() const { return S + JB; }
     __device__ __forceinline__ cpx<T> load(size_t xf, int c) const
     {
         const size_t b = xf >> (S + JB), K = (xf >> JB) & ((size_t(1) << S) - 1), j = xf & ((size_t(1) << JB) - 1);
@@ -124,6 +166,156 @@ struct BigMidIO {
         out[b * n + ((size_t)q << (S + JB)) + (K << JB) + j] = v;
     }
 };
+
+// ---- persistent, prefetching form of the factor kernels --------------------------------------------------------------
+// One workgroup per CU walks the tiles (a tile = XPB adjacent units = XPB adjacent columns / rows of ONE transform) with a
+// stride of the grid.  The next tile's loads are issued into a second register set before the current tile is computed,
+// so the CU always has a tile of HBM reads in flight while it runs butterflies, LDS exchanges and the previous tile's
+// stores; with one 512-thread workgroup per CU the register budget is 256 per thread: both sets and the twiddles of a
+// pass fit, nothing spills (the one-tile-per-workgroup form ran at 128 registers with 36..116 bytes of scratch per lane
+// and waited on memory for 45 % of its wave cycles).  Addressing is "one buffer descriptor per transform + one per-lane
+// byte offset + a wave-uniform offset per register" (local index i of a unit sits at  off(unit) + (i << sl)  inside its
+// transform), so the 16 loads / stores of a set cost no 64-bit address arithmetic.
+// Same butterflies, same table entries as fft_wg_kernel with the same policy: bit-identical results.
+template <typename T, int L, int RL, int BLOCK, class IO>
+__global__ __launch_bounds__(BLOCK, (BLOCK >= 1024 ? 4 : 2)) void fft_tile_persist_kernel(const IO io, const cpx<T> *__restrict__ tw,
+                                                                              const size_t ntiles)
+{
+    constexpr int N = 1 << L;
+    constexpr int R = 1 << RL;
+    constexpr int TPT = N / R;
+    static_assert(TPT >= 1 && BLOCK % TPT == 0, "bad geometry");
+    constexpr int XPB = BLOCK / TPT;
+    constexpr int NP = (L + RL - 1) / RL;
+    static_assert(NP >= 2 && NP <= 5, "pass count");
+    constexpr bool SPLIT = IO::kSplitLds;
+    static_assert(IO::kSlotMinor, "tile kernel: lanes run over adjacent units");
+    static_assert((SPLIT ? sizeof(T) : sizeof(cpx<T>)) == 8, "slot-minor layout is built for 8-byte exchange elements");
+    using G0 = WgGeom<L, RL, 0>;
+    using GL = WgGeom<L, RL, NP - 1>;
+    constexpr int ES = (int)sizeof(cpx<T>);
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x;
+    const int tau = tid / XPB;
+    const int slot = tid % XPB;
+
+    size_t tile = blockIdx.x;
+    if (tile >= ntiles) return;  // the whole workgroup leaves together
+    // First factor: the sub-transform's table entries T_n[idx << shift], idx < N/2, do not depend on the tile.  One LDS copy
+    // per workgroup (8 KiB for 2^10 c64 points) replaces 27 global loads per thread and tile; the 8 lanes of a unit group
+    // read one address (broadcast).  Behind the exchange region.
+    const cpx<T> *tw_lds = nullptr;
+    if constexpr (IO::kTileInvariantTw) {
+        cpx<T> *tl = reinterpret_cast<cpx<T> *>(smem_raw + lds_wg_bytes<T, SPLIT, true, XPB>(N));
+        for (int i = tid; i < N / 2; i += BLOCK) tl[i] = tw[io.tw_map(0)(i, 0)];
+        tw_lds = tl;
+        __syncthreads();
+    }
+    auto compute = [&](auto pass, cpx<T> *v, const size_t xf) {
+        constexpr int P = decltype(pass)::value;
+        if constexpr (IO::kTileInvariantTw) {
+            using Gm = WgGeom<L, RL, P>;
+#pragma unroll
+            for (int g = 0; g < Gm::G; ++g)
+                reg_pass<T, L, Gm::S0, Gm::Q, false>(&v[g * (1 << Gm::Q)], (tau + g * Gm::TPT) >> Gm::JB, tw_lds, TwPlain{});
+        } else {
+            wg_compute<T, L, RL, P>(v, io, tw, xf, tau);
+        }
+    };
+    const int in_sl = io.in_sl(), out_sl = io.out_sl();
+    const unsigned xf_bytes = (unsigned)(io.n * sizeof(cpx<T>));  // n <= 2^26 points: below 4 GiB
+
+    auto issue_loads = [&](cpx<T> *dst, const size_t t, const bool valid) {
+        // an EMPTY descriptor when there is no next tile: the loads return zeros without touching memory, and no branch
+        // sits between them (see fft_persist.hip.h)
+        const size_t xf0 = (valid ? t : 0) * XPB;
+        const rsrc_t d = make_rsrc(io.in + io.xf_transform(xf0) * io.n, valid ? xf_bytes : 0u);
+        const int lane = (int)((io.in_off(xf0 + slot) + ((unsigned)tau << in_sl)) * (unsigned)ES);
+#ifdef KOFFT_TILE_PTR_LOAD
+        if (valid) {
+#pragma unroll
+            for (int u = 0; u < R; ++u) dst[u] = io.load(xf0 + slot, G0::in_index(tau, u));
+        }
+        return;
+#endif
+        if (io.nt_in()) {
+#pragma unroll
+            for (int u = 0; u < R; ++u) dst[u] = buf_load_cpx<T, AUX_NT>(d, lane, (G0::in_index(0, u) << in_sl) * ES);
+        } else {
+#pragma unroll
+            for (int u = 0; u < R; ++u) dst[u] = buf_load_cpx<T, AUX_DEFAULT>(d, lane, (G0::in_index(0, u) << in_sl) * ES);
+        }
+    };
+
+    // Two register sets, A and B, swap roles every tile (2x unrolled, no copies): while the tile held in one set is
+    // computed and stored, the other set receives the next tile's loads.  (A copy `cur = nxt` after the stores would
+    // put VALU writes to the store-data registers right behind 16-byte buffer stores that use an SGPR offset -- a
+    // sequence the compiler does not pad, and one that stored the NEXT tile's values from a few lanes about once in
+    // ten launches on gfx950.)
+    auto run_tile = [&](cpx<T> *cur, const size_t t) {
+        const size_t xf = t * XPB + slot;
+        if (IO::kConjIn) {
+#pragma unroll
+            for (int u = 0; u < R; ++u) cur[u].im = -cur[u].im;  // ifft: conj on the way in (fft.rs:1163-1165)
+        }
+        compute(std::integral_constant<int, 0>{}, cur, xf);
+        if constexpr (NP > 1) { wg_exchange<T, L, RL, 0, SPLIT, true, XPB>(cur, smem_raw, tau, slot); compute(std::integral_constant<int, 1>{}, cur, xf); }
+        if constexpr (NP > 2) { wg_exchange<T, L, RL, 1, SPLIT, true, XPB>(cur, smem_raw, tau, slot); compute(std::integral_constant<int, 2>{}, cur, xf); }
+        if constexpr (NP > 3) { wg_exchange<T, L, RL, 2, SPLIT, true, XPB>(cur, smem_raw, tau, slot); compute(std::integral_constant<int, 3>{}, cur, xf); }
+        if constexpr (NP > 4) { wg_exchange<T, L, RL, 3, SPLIT, true, XPB>(cur, smem_raw, tau, slot); compute(std::integral_constant<int, 4>{}, cur, xf); }
+        const size_t xf0 = t * XPB;
+        const rsrc_t d = make_rsrc(io.out + io.xf_transform(xf0) * io.n, xf_bytes);
+        const int lane = (int)((io.out_off(xf) + ((unsigned)tau << out_sl)) * (unsigned)ES);
+        const T scale = io.out_scale();
+#ifdef KOFFT_TILE_PTR_STORE
+#pragma unroll
+        for (int u = 0; u < R; ++u) io.store(xf, GL::out_index(tau, u), cur[u]);
+        return;
+#endif
+        // 16-byte stores: the register offset goes into the VGPR offset, NOT into the SGPR offset field.  hipcc pads the
+        // "store of more than 8 bytes, then a VALU write to its data registers" hazard only when the instruction has no
+        // SGPR offset (it assumes the hazard away otherwise); on gfx950 the SGPR-offset form did store, about once in
+        // ten launches, the NEXT value of the data registers' first half from the last lanes of each 16-lane row.
+        constexpr bool nt_out = IO::kNtOut;  // tiles of this kernel are at least 64 bytes wide: streaming stores for the last factor
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            cpx<T> v = cur[u];
+            if (IO::kConjScaleOut) {  // conj, then scale (fft.rs:1168-1172)
+                const T im = -v.im;
+                v = mk<T>(v.re * scale, im * scale);
+            }
+            const int off = lane + (GL::out_index(0, u) << out_sl) * ES;
+            if (nt_out) buf_store_cpx_aux<T, AUX_NT>(v, d, off, 0);
+            else buf_store_cpx_aux<T, AUX_DEFAULT>(v, d, off, 0);
+        }
+    };
+
+    cpx<T> ra[R], rb[R];
+#ifdef KOFFT_TILE_NO_PREFETCH
+#define KOFFT_TILE_PREFETCH(CUR, NXT) issue_loads(CUR, tile, true);
+#else
+#define KOFFT_TILE_PREFETCH(CUR, NXT) issue_loads(NXT, ntile, more);
+    issue_loads(ra, tile, true);
+#endif
+#define KOFFT_TILE_STEP(CUR, NXT)                                                                        \
+    {                                                                                                    \
+        const size_t ntile = tile + gridDim.x;                                                           \
+        const bool more = ntile < ntiles; /* workgroup-uniform */                                        \
+        KOFFT_TILE_PREFETCH(CUR, NXT)                                                                    \
+        __builtin_amdgcn_sched_barrier(0); /* keep the prefetch ahead of the first use of CUR */         \
+        run_tile(CUR, tile);                                                                             \
+        if (!more) break;                                                                                \
+        tile = ntile;                                                                                    \
+        __syncthreads(); /* the last gathers of this tile are done before the next tile's first scatter */ \
+    }
+    for (;;) {
+        KOFFT_TILE_STEP(ra, rb)
+        KOFFT_TILE_STEP(rb, ra)
+    }
+#undef KOFFT_TILE_STEP
+#undef KOFFT_TILE_PREFETCH
+}
 
 // ndfft (ndfft.rs:74-155): FftImpl::fft_strided over every line of one axis.  Unit xf is one line:
 // element i lives at  (xf / inner) * outer_stride + (xf % inner) + i * stride.  Adjacent lines are adjacent in memory,

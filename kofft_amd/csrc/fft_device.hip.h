@@ -122,6 +122,22 @@ __device__ __forceinline__ void buf_store_cpx(cpx<T> c, rsrc_t r, int voff, int 
     }
 }
 
+template <typename T, int AUX>
+__device__ __forceinline__ void buf_store_cpx_aux(cpx<T> c, rsrc_t r, int voff, int coff)
+{
+    typedef T vec2 __attribute__((ext_vector_type(2)));
+    vec2 f;
+    f.x = c.re;
+    f.y = c.im;
+    if constexpr (sizeof(T) == 4) {
+        typedef unsigned v2u __attribute__((ext_vector_type(2)));
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, f), r, voff, coff, AUX);
+    } else {
+        typedef unsigned v4u __attribute__((ext_vector_type(4)));
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, f), r, voff, coff, AUX);
+    }
+}
+
 __device__ __forceinline__ void buf_store_f32(float v, rsrc_t r, int voff, int coff)
 {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, coff, KOFFT_STORE_AUX);
