@@ -41,11 +41,43 @@ int launch_tile_persist(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size
     return KOFFT_OK;
 }
 
+// The last factor with its table entries resident per row tile (fft_rows_persist_kernel).
+template <typename T, int LS, class IO>
+int launch_rows_persist(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t nb)
+{
+    constexpr int RL = rl_for(LS);
+    constexpr int BLOCK = big_block<T, IO, LS>();
+    constexpr int TPT = (1 << LS) >> RL;
+    constexpr int XPB = BLOCK / TPT;
+    constexpr size_t lds = lds_wg_bytes<T, IO::kSplitLds, true, XPB>(1 << LS) + (size_t)rows_tw_entries<LS, RL>() * XPB * sizeof(cpx<T>);
+    constexpr int WG_PER_CU = BLOCK >= 512 ? 1 : 512 / BLOCK;
+    static_assert(lds * WG_PER_CU <= 160 * 1024, "LDS budget");
+    if (nb > 0xffffffffULL || ((size_t(1) << io.LA) % XPB) != 0) return KOFFT_ERR_UNSUPPORTED;
+    auto kern = fft_rows_persist_kernel<T, LS, RL, BLOCK, IO>;
+    if (lds > 64 * 1024) {
+        static std::atomic<unsigned long long> attr_done{0};
+        const int arc = set_dyn_lds_once(ctx, attr_done, reinterpret_cast<const void *>(kern), lds);
+        if (arc) return arc;
+    }
+    const size_t KT = (size_t(1) << io.LA) / XPB;
+    size_t blocks = (size_t)ctx->num_cus * WG_PER_CU;
+    if (ctx->persist_grid_pct > 0) blocks = blocks * (size_t)ctx->persist_grid_pct / 100;
+    if (blocks < 1) blocks = 1;
+    if (blocks >= KT) {  // whole groups of workgroups per row tile, no more groups than transforms
+        size_t groups = blocks / KT;
+        if (groups > nb) groups = nb;
+        blocks = KT * groups;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BLOCK), lds, ctx->stream, io, tw, (unsigned)nb);
+    KOFFT_HIP_TRY(ctx, hipGetLastError());
+    return KOFFT_OK;
+}
+
 // Launch the generic kernel for a sub-transform of log2 size LS with an arbitrary IO policy.
 template <typename T, class IO>
 int launch_sub(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, int LS, size_t units)
 {
-    if (ctx->big_persist && units >= (size_t)ctx->num_cus * 64) {  // every resident workgroup gets several tiles
+    if (ctx->big_persist && units >= (size_t)ctx->num_cus * ctx->big_persist_min_units) {  // every resident workgroup gets several tiles
         switch (LS) {
 #define KOFFT_CASE(LL) \
     case LL: return launch_tile_persist<T, LL, IO>(ctx, io, tw, units);
@@ -78,7 +110,7 @@ int launch_sub(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, int LS, size_
 template <typename T>
 int launch_mid(kofft_hip_ctx *ctx, const BigMidIO<T> &io, const cpx<T> *tw, int LS, size_t units)
 {
-    if (ctx->big_persist && units >= (size_t)ctx->num_cus * 64) {
+    if (ctx->big_persist && units >= (size_t)ctx->num_cus * ctx->big_persist_min_units) {
         switch (LS) {
         case 7: return launch_tile_persist<T, 7, BigMidIO<T>>(ctx, io, tw, units);
         case 8: return launch_tile_persist<T, 8, BigMidIO<T>>(ctx, io, tw, units);
@@ -147,7 +179,17 @@ int fft_big_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t ba
         // an intermediate small enough to stay in the 256 MiB Infinity Cache is read with plain loads (measured on a
         // copy model, tools/ubench_mall: streaming hints on the caller's buffers only, 3.1 -> 2.5 ms per 2 x 4 GiB)
         b.nt_load = ctx->big_mid_nt >= 0 ? ctx->big_mid_nt != 0 : nb * xf_bytes > (size_t(192) << 20);
-        rc = launch_sub<T>(ctx, b, tw, L3, nb << LP);
+        rc = KOFFT_ERR_UNSUPPORTED;
+        if (ctx->big_persist && ctx->big_rows_resident && (nb << LP) >= (size_t)ctx->num_cus * ctx->big_persist_min_units) {
+            switch (L3) {
+            case 7: rc = launch_rows_persist<T, 7>(ctx, b, tw, nb); break;
+            case 8: rc = launch_rows_persist<T, 8>(ctx, b, tw, nb); break;
+            case 9: rc = launch_rows_persist<T, 9>(ctx, b, tw, nb); break;
+            case 10: rc = launch_rows_persist<T, 10>(ctx, b, tw, nb); break;
+            default: break;
+            }
+        }
+        if (rc == KOFFT_ERR_UNSUPPORTED) rc = launch_sub<T>(ctx, b, tw, L3, nb << LP);
         if (rc) return rc;
     }
     return KOFFT_OK;

@@ -25,6 +25,7 @@
 
 #include <type_traits>
 
+#include "fft_persist.hip.h"
 #include "fft_wg.hip.h"
 
 namespace kofft {
@@ -315,6 +316,203 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 1024 ? 4 : 2)) void fft_tile_persi
     }
 #undef KOFFT_TILE_STEP
 #undef KOFFT_TILE_PREFETCH
+}
+
+// ---- last factor, persistent, twiddles RESIDENT per row tile ---------------------------------------------------------
+// The last factor's table index carries the row's frequency prefix K (TwSub), so every tile of XPB rows needs its own
+// 2^L - 1 entries per row: 46 global loads per thread and tile in the generic tile kernel, issued behind the next tile's
+// prefetch -- and "vmcnt" counts in order, so waiting for a twiddle also waits for the whole prefetch.  But the entries
+// depend on K only, not on the transform: a workgroup that stays on ONE row tile (K0 .. K0+XPB-1) and walks the
+// transforms of the launch needs them once.  Passes before the last read them from an LDS copy ([entry][row] so the
+// lanes of a row group read consecutive cells), the last pass -- every thread its own 2^Q - 1 per group -- keeps them in
+// registers.  No global load but the data prefetch is left inside the loop.
+// Work split: `groups` workgroups per row tile when the grid has at least one per tile (each takes every groups-th
+// transform), otherwise every workgroup walks several row tiles and reloads the tables when it moves on.
+template <typename T, int Q, int STRIDE>
+__device__ __forceinline__ void reg_pass_lds(cpx<T> *v, const cpx<T> *tl)
+{
+#pragma unroll
+    for (int t = 0; t < Q; ++t) {
+        const int pos = Q - 1 - t;
+#pragma unroll
+        for (int h = 0; h < (1 << t); ++h) {
+            const cpx<T> w = tl[((1 << t) - 1 + h) * STRIDE];
+#pragma unroll
+            for (int lo = 0; lo < (1 << pos); ++lo) {
+                const int c = (h << (pos + 1)) | lo;
+                bfly(v[c], v[c | (1 << pos)], w);
+            }
+        }
+    }
+}
+
+template <typename T, int L, int S0, int Q, class TwMap>
+__device__ __forceinline__ void load_pass_twiddles_map(cpx<T> *twr, const int k, const cpx<T> *__restrict__ tw, const TwMap map)
+{
+#pragma unroll
+    for (int t = 0; t < Q; ++t) {
+#pragma unroll
+        for (int h = 0; h < (1 << t); ++h) {
+            const int idx = (k << (L - 1 - S0 - t)) + (bitrev(h, t) << (L - 1 - t));
+            twr[(1 << t) - 1 + h] = tw[map(idx, S0 + t)];
+        }
+    }
+}
+
+// LDS cells of the row-resident tables: passes 0 .. NP-2, pass P holding 2^(P*RL) groups of 2^RL - 1 entries
+template <int L, int RL>
+__host__ __device__ constexpr int rows_tw_entries()
+{
+    constexpr int NP = (L + RL - 1) / RL;
+    int e = 0;
+    for (int P = 0; P + 1 < NP; ++P) e += (1 << (P * RL)) * ((1 << RL) - 1);
+    return e;
+}
+
+template <typename T, int L, int RL, int BLOCK, class IO>
+__global__ __launch_bounds__(BLOCK, (BLOCK >= 1024 ? 4 : 2)) void fft_rows_persist_kernel(const IO io, const cpx<T> *__restrict__ tw,
+                                                                                         const unsigned nb)
+{
+    constexpr int N = 1 << L;
+    constexpr int R = 1 << RL;
+    constexpr int TPT = N / R;
+    static_assert(TPT >= 1 && BLOCK % TPT == 0, "bad geometry");
+    constexpr int XPB = BLOCK / TPT;
+    constexpr int NP = (L + RL - 1) / RL;
+    static_assert(NP >= 2 && NP <= 4, "pass count");
+    constexpr bool SPLIT = IO::kSplitLds;
+    static_assert((SPLIT ? sizeof(T) : sizeof(cpx<T>)) == 8, "slot-minor layout is built for 8-byte exchange elements");
+    using G0 = WgGeom<L, RL, 0>;
+    using GL = WgGeom<L, RL, NP - 1>;
+    constexpr int QL = GL::Q, GRP = GL::G;  // last pass: GRP groups of 2^QL registers per thread
+    constexpr int ES = (int)sizeof(cpx<T>);
+    constexpr int FULL = R - 1;  // entries per group of a full pass
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cpx<T> *tw_lds = reinterpret_cast<cpx<T> *>(smem_raw + lds_wg_bytes<T, SPLIT, true, XPB>(N));
+    const int tid = threadIdx.x;
+    const int tau = tid / XPB;
+    const int slot = tid % XPB;
+
+    // ---- which row tiles and which transforms this workgroup owns
+    const unsigned KT = (1u << io.LA) / XPB;  // row tiles per transform
+    const unsigned G = gridDim.x, w = blockIdx.x;
+    const bool wide = G >= KT;
+    const unsigned groups = wide ? G / KT : 1u;
+    if (wide && w >= KT * groups) return;
+    unsigned kt = wide ? w % KT : w;
+    const unsigned kt_step = wide ? KT : G;       // wide: one row tile only (kt + KT is past the end)
+    const unsigned b_first = wide ? w / KT : 0u;
+    if (kt >= KT || b_first >= nb) return;
+    unsigned b = b_first;
+
+    const unsigned xf_bytes = (unsigned)(io.n * sizeof(cpx<T>));
+    const int out_sl = io.LA;
+    auto issue_loads = [&](cpx<T> *dst, const unsigned tkt, const unsigned tb, const bool valid) {
+        // (walking the transforms last to first, so that the most recently written part of the intermediate is read first,
+        // measured no gain from the Infinity Cache: 12.4 vs 12.1 ms on config 5)
+        const rsrc_t d = make_rsrc(io.in + (size_t)(valid ? tb : 0) * io.n, valid ? xf_bytes : 0u);
+        const int lane = (int)(((((valid ? tkt : 0) * XPB + slot) << io.LB) + (unsigned)tau) * (unsigned)ES);
+        if (io.nt_in()) {
+#pragma unroll
+            for (int u = 0; u < R; ++u) dst[u] = buf_load_cpx<T, AUX_NT>(d, lane, G0::in_index(0, u) * ES);
+        } else {
+#pragma unroll
+            for (int u = 0; u < R; ++u) dst[u] = buf_load_cpx<T, AUX_DEFAULT>(d, lane, G0::in_index(0, u) * ES);
+        }
+    };
+
+    // one group's 2^RL - 1 entries of a staged pass, straight from the table into the LDS cells [entry][row]
+    auto stage_group = [&](auto s0, cpx<T> *cells, const int k, const TwSub map) {
+        constexpr int S0 = decltype(s0)::value;
+#pragma unroll
+        for (int t = 0; t < RL; ++t) {
+#pragma unroll
+            for (int h = 0; h < (1 << t); ++h) {
+                const int idx = (k << (L - 1 - S0 - t)) + (bitrev(h, t) << (L - 1 - t));
+                cells[((1 << t) - 1 + h) * XPB] = tw[map(idx, S0 + t)];
+            }
+        }
+    };
+    cpx<T> twl[GRP * ((1 << QL) - 1)];  // the last pass's twiddles of this thread, for the current row tile
+    int lds_base[NP > 1 ? NP - 1 : 1];  // this thread's group of entries in each staged pass (cells)
+    auto load_tables = [&](const unsigned tkt) {
+        const TwSub map = io.tw_map((size_t)tkt * XPB + slot);  // K = tkt * XPB + slot
+        int off = 0;
+        // staged passes: one representative thread per (group k, row) fetches the group's entries
+#define KOFFT_ROWS_STAGE(P)                                                                                           \
+        if constexpr (P + 1 < NP) {                                                                                   \
+            using Gm = WgGeom<L, RL, P>;                                                                              \
+            static_assert(Gm::G == 1 && Gm::Q == RL, "staged passes are full passes");                                \
+            const int k = tau >> Gm::JB;                                                                              \
+            lds_base[P] = (off + k * FULL) * XPB + slot;                                                              \
+            if ((tau & ((1 << Gm::JB) - 1)) == 0) stage_group(std::integral_constant<int, Gm::S0>{}, tw_lds + lds_base[P], k, map);                  \
+            off += (1 << Gm::S0) * FULL;                                                                              \
+        }
+        KOFFT_ROWS_STAGE(0)
+        KOFFT_ROWS_STAGE(1)
+        KOFFT_ROWS_STAGE(2)
+#undef KOFFT_ROWS_STAGE
+#pragma unroll
+        for (int g = 0; g < GRP; ++g)
+            load_pass_twiddles_map<T, L, GL::S0, QL>(twl + g * ((1 << QL) - 1), (tau + g * TPT) >> GL::JB, tw, map);
+        __syncthreads();
+    };
+
+    auto run_tile = [&](cpx<T> *cur, const unsigned tkt, const unsigned tb) {
+        // passes 0 .. NP-2 from the LDS tables, last pass from registers
+        reg_pass_lds<T, RL, XPB>(cur, tw_lds + lds_base[0]);
+        if constexpr (NP > 2) {
+            wg_exchange<T, L, RL, 0, SPLIT, true, XPB>(cur, smem_raw, tau, slot);
+            reg_pass_lds<T, RL, XPB>(cur, tw_lds + lds_base[NP > 2 ? 1 : 0]);
+        }
+        if constexpr (NP > 3) {
+            wg_exchange<T, L, RL, 1, SPLIT, true, XPB>(cur, smem_raw, tau, slot);
+            reg_pass_lds<T, RL, XPB>(cur, tw_lds + lds_base[NP > 3 ? 2 : 0]);
+        }
+        wg_exchange<T, L, RL, NP - 2, SPLIT, true, XPB>(cur, smem_raw, tau, slot);
+#pragma unroll
+        for (int g = 0; g < GRP; ++g) reg_pass_r<T, QL>(cur + g * (1 << QL), twl + g * ((1 << QL) - 1));
+        const rsrc_t d = make_rsrc(io.out + (size_t)tb * io.n, xf_bytes);
+        const int lane = (int)((tkt * XPB + slot + ((unsigned)tau << out_sl)) * (unsigned)ES);
+        const T scale = io.out_scale();
+        // (offsets in the VGPR field: see fft_tile_persist_kernel)
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            cpx<T> v = cur[u];
+            if (IO::kConjScaleOut) {  // conj, then scale (fft.rs:1168-1172)
+                const T im = -v.im;
+                v = mk<T>(v.re * scale, im * scale);
+            }
+            buf_store_cpx_aux<T, AUX_NT>(v, d, lane + (GL::out_index(0, u) << out_sl) * ES, 0);
+        }
+    };
+
+    cpx<T> ra[R], rb[R];
+    load_tables(kt);
+    issue_loads(ra, kt, b, true);
+#define KOFFT_ROWS_STEP(CUR, NXT)                                                                          \
+    {                                                                                                      \
+        unsigned nkt = kt, nbb = b + groups;                                                               \
+        if (nbb >= nb) {                                                                                   \
+            nbb = b_first;                                                                                 \
+            nkt = kt + kt_step;                                                                            \
+        }                                                                                                  \
+        const bool more = nkt < KT; /* workgroup-uniform */                                                \
+        issue_loads(NXT, nkt, nbb, more);                                                                  \
+        __builtin_amdgcn_sched_barrier(0); /* keep the prefetch ahead of the first use of CUR */           \
+        run_tile(CUR, kt, b);                                                                              \
+        if (!more) break;                                                                                  \
+        __syncthreads(); /* this tile's last gathers and table reads are done */                          \
+        if (nkt != kt) load_tables(nkt); /* the next row tile: its own table entries */                    \
+        kt = nkt;                                                                                          \
+        b = nbb;                                                                                           \
+    }
+    for (;;) {
+        KOFFT_ROWS_STEP(ra, rb)
+        KOFFT_ROWS_STEP(rb, ra)
+    }
+#undef KOFFT_ROWS_STEP
 }
 
 // ndfft (ndfft.rs:74-155): FftImpl::fft_strided over every line of one axis.  Unit xf is one line:

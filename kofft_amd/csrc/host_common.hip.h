@@ -36,6 +36,8 @@ struct kofft_hip_ctx {
     int persist_grid_pct = 0; // KOFFT_HIP_PERSIST_GRID_PCT: scale the persistent grids (measurements only)
     bool big_two_only = false; // KOFFT_HIP_BIG_TWO_FACTORS=1: never split into three factors (A/B measurements)
     bool big_persist = true;   // KOFFT_HIP_BIG_PERSIST=0: factors on the one-tile-per-workgroup kernel (A/B measurements)
+    size_t big_persist_min_units = 32;  // KOFFT_HIP_BIG_PERSIST_MIN_UNITS: units (columns / rows) per CU from which the persistent factor kernels run
+    bool big_rows_resident = true;  // KOFFT_HIP_BIG_ROWS_RESIDENT=0: last factor on the generic tile kernel (A/B measurements)
     int big_mid_nt = -1;       // KOFFT_HIP_BIG_MID_NT=0/1: force plain / streaming loads of the intermediate (default: by chunk size)
     bool blue_fused = true;    // KOFFT_HIP_BLUESTEIN_FUSED=0: pointwise steps as separate kernels at every size
     bool nd_transpose = true;  // KOFFT_HIP_ND_TRANSPOSE=0: long strided axes through the strided kernel
@@ -61,7 +63,7 @@ struct kofft_hip_ctx {
     size_t pinned_bytes = 0;
     void *blue_tmp = nullptr;  // zero-padded work buffer of the Bluestein arm
     size_t blue_tmp_bytes = 0;
-    size_t big_chunk_bytes = size_t(2048) << 20;  // KOFFT_HIP_BIG_CHUNK_MB; measured: small chunks do not profit from the Infinity Cache, larger launches overlap better
+    size_t big_chunk_bytes = size_t(512) << 20;  // KOFFT_HIP_BIG_CHUNK_MB; measured on config 5 with the persistent factor kernels: 128 MiB 14.7 ms, 256 13.0, 512 12.1, 1024 12.5, 2048 13.1
 };
 
 namespace kofft {
