@@ -127,6 +127,12 @@ __device__ __forceinline__ void exchange_sync()
     }
 }
 
+// Prefetch distance of a configuration: CFG::DEPTH transforms ahead (1 unless the configuration says otherwise).
+template <class CFG, class = void>
+struct persist_depth { static constexpr int value = 1; };
+template <class CFG>
+struct persist_depth<CFG, decltype((void)CFG::DEPTH)> { static constexpr int value = CFG::DEPTH; };
+
 // Everything a thread keeps across transforms.
 // CFG (kofft_hip.hip: PersistCfg<L, IO>) carries the per-size, per-policy choices: BLOCK, NBUF, MINW and where the
 // thread-invariant operands live -- kInvInLds (window samples in one LDS copy per workgroup instead of R registers)
@@ -210,7 +216,16 @@ __device__ __forceinline__ void persist_transform(const typename IO::Raw *raw, c
         static_assert(L <= 12, "rfft epilogue: the staged tables do not fit next to an 8192-point exchange buffer");
         cpx<T> *ybuf = (NP == 3) ? buf0 : buf1;  // not the buffer the last gather read from (when NBUF == 2)
         if (NBUF == 1) exchange_sync<WAVE>();
-        persist_lds_scatter<T, L, RL, NP - 1>(cur, ybuf, st.sc);
+        // Y goes into the buffer in PLAIN natural order, not the padded exchange layout: every access of this epilogue is a
+        // run of consecutive elements (the scatter: lanes tau -> Y[c*TPT + tau]; the reads: ascending k and descending
+        // m - k), and 32 consecutive 8-byte cells cover the 64 banks exactly once.  Under the i + (i >> 4) padding such a
+        // run crosses one or two pad cells and wraps onto its own first banks: 16 % of this kernel's LDS cycles were
+        // bank conflicts (profiles/r01_sq_rfft2048.txt).
+        {
+            cpx<T> *p = ybuf + tau;
+#pragma unroll
+            for (int u = 0; u < R; ++u) p[LastG::out_index(0, u)] = cur[u];
+        }
         exchange_sync<WAVE>();
         if (active) {
             // Output rows are (N+1) complex values back to back, so a row starts `a` elements past a 128-byte line.
@@ -218,27 +233,26 @@ __device__ __forceinline__ void persist_transform(const typename IO::Raw *raw, c
             // row-contiguous form touches 5 lines per 512-byte store, 2 of them partially; measured +8 % on config 3),
             // at the price of one extra, mostly empty, store (g = R) that also carries X[N].
             constexpr int LINE = 128 / (int)sizeof(cpx<T>);
-            constexpr int PSTEP = TPT + TPT / 16;  // lds_pad(k + TPT) - lds_pad(k)
             const int a = io.row_misalign(xf) & (LINE - 1);
             const int k0 = tau - a;  // -15 .. TPT-1
             // descriptor based LINE elements before the row, so that every byte offset below is non-negative
             const rsrc_t od = io.out_desc_back_n(xf0, cnt, LINE);
             const int row_off = sub * (int)io.out_row_bytes();
-            const cpx<T> y0 = ybuf[lds_pad(0)];
-            const cpx<T> *yk = ybuf + (k0 + (k0 >> 4));              // lds_pad(k0 + g*TPT) = lds_pad(k0) + g*PSTEP (also for k0 < 0)
-            const cpx<T> *ynk = ybuf + ((N - k0) + ((N - k0) >> 4));  // lds_pad(N - k0 - g*TPT) = lds_pad(N - k0) - g*PSTEP
+            const cpx<T> y0 = ybuf[0];
+            const cpx<T> *yk = ybuf + k0;         // Y[k0 + g*TPT]
+            const cpx<T> *ynk = ybuf + (N - k0);  // Y[N - k0 - g*TPT]
             const cpx<T> *wk = st.rt_lds + k0;
             const int lane_bytes = (k0 + LINE) * (int)sizeof(cpx<T>);
             if (k0 >= 0) {  // g = 0: k = k0 (lanes that fall before the row start sit this one out)
-                const cpx<T> p = io.post_w(wk[0], yk[0], ynk[0]);  // k0 == 0 reads cell lds_pad(N): in range, value replaced
+                const cpx<T> p = io.post_w(wk[0], yk[0], ynk[0]);  // k0 == 0 reads cell N: in range, value replaced
                 io.store_d(od, lane_bytes, 0, k0 == 0 ? mk<T>(y0.re + y0.im, T(0)) : p, row_off);
             }
 #pragma unroll
             for (int g = 1; g < R; ++g)
-                io.store_d(od, lane_bytes, g * TPT, io.post_w(wk[g * TPT], yk[g * PSTEP], ynk[-g * PSTEP]), row_off);
+                io.store_d(od, lane_bytes, g * TPT, io.post_w(wk[g * TPT], yk[g * TPT], ynk[-g * TPT]), row_off);
             if (k0 <= 0) {  // g = R: k = N + k0 <= N; k == N is X[N]
                 const int kr = (k0 < 0) ? N + k0 : N - 1;  // clamped for the LDS reads of the lane that holds X[N]
-                const cpx<T> p = io.post_w(st.rt_lds[kr], ybuf[lds_pad(kr)], ybuf[lds_pad(N - kr)]);
+                const cpx<T> p = io.post_w(st.rt_lds[kr], ybuf[kr], ybuf[N - kr]);
                 io.store_d(od, lane_bytes, R * TPT, k0 == 0 ? mk<T>(y0.re - y0.im, T(0)) : p, row_off);
             }
         }
@@ -327,8 +341,10 @@ __global__ __launch_bounds__(CFG::BLOCK, CFG::MINW) void fft_persist_kernel(cons
     size_t base = (size_t)blockIdx.x * XPB;
     if (base >= batch) return;  // the whole workgroup leaves together
 
-    // Two raw register sets, A and B, swap roles every transform (no register copies): while the transform
-    // held in one set is computed, the other set receives the next transform's loads.
+    // Raw register sets swap roles every transform (no register copies): while the transform held in one set is
+    // computed, the others receive the loads of the transforms that follow.
+    constexpr int DEPTH = persist_depth<CFG>::value;
+    static_assert(DEPTH == 1 || DEPTH == 2, "prefetch distance");
     Raw ra[R], rb[R];
     const int in_lane_bytes = tau * IO::kRawBytes;
     const int in_row_off = (G == 1) ? 0 : sub * (int)io.in_slot_bytes();
@@ -337,40 +353,64 @@ __global__ __launch_bounds__(CFG::BLOCK, CFG::MINW) void fft_persist_kernel(cons
         const size_t first = b + wslot;
         return first >= batch ? 0 : (batch - first < (size_t)G ? (int)(batch - first) : G);
     };
-    {
-        const rsrc_t d = io.in_desc_n(base + wslot, group_cnt(base));
+    // Issue the loads of the group at `b` (unconditionally, through a descriptor that is EMPTY when there is no such
+    // transform -- the bounds check then returns zeros without touching memory; no branch, so the loads carry no
+    // register shuffles behind them).
+    auto issue = [&](Raw *dst, const size_t b) {
+        const rsrc_t d = io.in_desc_n(b + wslot, group_cnt(b));
 #pragma unroll
-        for (int u = 0; u < R; ++u) ra[u] = io.fetch_d(d, in_lane_bytes, FirstG::in_index(0, u), in_row_off);
-    }
+        for (int u = 0; u < R; ++u) dst[u] = io.fetch_d(d, in_lane_bytes, FirstG::in_index(0, u), in_row_off);
+    };
+    issue(ra, base);
 
-    // One step: issue the NEXT transform's loads into NXT (unconditionally, through a descriptor that is EMPTY when
-    // there is no next transform -- the bounds check then returns zeros without touching memory; no branch, so the
-    // loads carry no register shuffles behind them), then run the transform held in CUR.
+    if constexpr (DEPTH == 1) {
+        // One step: issue the NEXT transform's loads into NXT, then run the transform held in CUR.
 #define KOFFT_PERSIST_STEP(CUR, NXT, LEAVE)                                                                          \
     {                                                                                                                \
         const size_t nbase = base + step;                                                                            \
         const bool more = nbase < batch; /* workgroup-uniform */                                                     \
-        {                                                                                                            \
-            const rsrc_t d = io.in_desc_n(nbase + wslot, group_cnt(nbase));                                          \
-            _Pragma("unroll") for (int u = 0; u < R; ++u)                                                            \
-                NXT[u] = io.fetch_d(d, in_lane_bytes, FirstG::in_index(0, u), in_row_off);                           \
-        }                                                                                                            \
+        issue(NXT, nbase);                                                                                           \
         __builtin_amdgcn_sched_barrier(0); /* keep the prefetch ahead of CUR's first use */                          \
         persist_transform<T, L, RL, EPI, CFG>(CUR, st, io, tw, buf0, buf1, base + wslot, group_cnt(base), sub, tau);  \
         if (!more) LEAVE;                                                                                            \
         base = nbase;                                                                                                \
     }
-    // The first step is peeled off the loop.  s_waitcnt vmcnt counts loads AND stores in issue order, so "CUR has
-    // landed" is vmcnt(32 - i): 16 stores of the previous transform and 16 loads of the next one may stay in flight.
-    // With the first step inside the loop the compiler must merge the entry state (no stores yet) with the back-edge
-    // state and emits vmcnt(15 - i) for both -- which, on the back edge, waits for the previous transform's STORES to
-    // complete, once per two transforms.  After the peel both predecessors of the loop header look the same.
-    KOFFT_PERSIST_STEP(ra, rb, return)
-    for (;;) {
-        KOFFT_PERSIST_STEP(rb, ra, break)
-        KOFFT_PERSIST_STEP(ra, rb, break)
-    }
+        // The first step is peeled off the loop.  s_waitcnt vmcnt counts loads AND stores in issue order, so "CUR has
+        // landed" is vmcnt(32 - i): 16 stores of the previous transform and 16 loads of the next one may stay in flight.
+        // With the first step inside the loop the compiler must merge the entry state (no stores yet) with the back-edge
+        // state and emits vmcnt(15 - i) for both -- which, on the back edge, waits for the previous transform's STORES to
+        // complete, once per two transforms.  After the peel both predecessors of the loop header look the same.
+        KOFFT_PERSIST_STEP(ra, rb, return)
+        for (;;) {
+            KOFFT_PERSIST_STEP(rb, ra, break)
+            KOFFT_PERSIST_STEP(ra, rb, break)
+        }
 #undef KOFFT_PERSIST_STEP
+    } else {
+        // Two transforms ahead (three sets): for configurations that run ONE wavefront per SIMD, where a transform's
+        // own work (~3 us) is not enough time for its successor's loads to land under load.  While transform t is
+        // computed, t+1 has been in flight for a whole transform and t+2 is issued.
+        Raw rc[R];
+        issue(rb, base + step);
+#define KOFFT_PERSIST_STEP2(CUR, FAR, LEAVE)                                                                         \
+    {                                                                                                                \
+        const size_t nbase = base + step;                                                                            \
+        const bool more = nbase < batch; /* workgroup-uniform */                                                     \
+        issue(FAR, nbase + step);                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        persist_transform<T, L, RL, EPI, CFG>(CUR, st, io, tw, buf0, buf1, base + wslot, group_cnt(base), sub, tau);  \
+        if (!more) LEAVE;                                                                                            \
+        base = nbase;                                                                                                \
+    }
+        KOFFT_PERSIST_STEP2(ra, rc, return)
+        for (;;) {
+            KOFFT_PERSIST_STEP2(rb, ra, break)
+            KOFFT_PERSIST_STEP2(rc, rb, break)
+            KOFFT_PERSIST_STEP2(ra, rc, break)
+        }
+#undef KOFFT_PERSIST_STEP2
+    }
 }
+
 
 }  // namespace kofft

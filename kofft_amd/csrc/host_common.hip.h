@@ -228,6 +228,14 @@ template <class IO> struct PersistCfg<11, IO> : PersistCfgBase<IO> { static cons
 template <class IO> struct PersistCfg<10, IO> : PersistCfgBase<IO> {
     static constexpr int BLOCK = 256, MINW = IO::kLeanRegisters ? 3 : 2, WG_PER_CU = MINW;
 };
+// rfft 2048 (m = 1024, one wavefront per transform): with half the grid (PersistGrid below: fewer concurrent rows) a CU
+// runs ONE wavefront per SIMD, and one transform of work is too short for the next one's loads to land: two ahead.
+#ifndef KOFFT_RFFT10_DEPTH
+#define KOFFT_RFFT10_DEPTH 2
+#endif
+template <> struct PersistCfg<10, RfftIO<float>> : PersistCfgBase<RfftIO<float>> {
+    static constexpr int BLOCK = 256, MINW = 2, WG_PER_CU = 2, DEPTH = KOFFT_RFFT10_DEPTH;
+};
 // irfft prefetches two row elements per output: the last pass reads its twiddles from LDS to stay inside 256 VGPRs
 template <> struct PersistCfg<10, IrfftIO<float>> {
     static constexpr int BLOCK = 256, NBUF = 1, RL = 4, MINW = 2, WG_PER_CU = 2;
