@@ -153,10 +153,17 @@ struct PersistState {
 };
 
 // One transform: raw[] holds its (already landed or still in flight) inputs.
+struct NoAcc {};
+template <class IO, bool HAS = io_has_acc<IO>::value>
+struct persist_acc { using type = NoAcc; };
+template <class IO>
+struct persist_acc<IO, true> { using type = typename IO::Acc; };
+
 template <typename T, int L, int RL, int EPI, class CFG, class IO>
 __device__ __forceinline__ void persist_transform(const typename IO::Raw *raw, const PersistState<T, L, RL, EPI, IO, CFG> &st,
                                                   const IO &io, const cpx<T> *__restrict__ tw, cpx<T> *buf0, cpx<T> *buf1,
-                                                  const size_t xf0, const int cnt, const int sub, const int tau)
+                                                  const size_t xf0, const int cnt, const int sub, const int tau,
+                                                  typename persist_acc<IO>::type &acc)
 {
     // The wavefront's group: cnt (0 .. G) valid transforms starting at xf0; this lane belongs to number `sub`.
     constexpr int NBUF = CFG::NBUF;
@@ -263,7 +270,10 @@ __device__ __forceinline__ void persist_transform(const typename IO::Raw *raw, c
             const int lane_bytes = tau * (int)sizeof(cpx<T>);
             const int row_off = sub * (int)io.out_row_bytes();
 #pragma unroll
-            for (int u = 0; u < R; ++u) io.store_d(od, lane_bytes, LastG::out_index(0, u), cur[u], row_off);
+            for (int u = 0; u < R; ++u) {
+                if constexpr (io_has_acc<IO>::value) io.store_d_acc(od, lane_bytes, LastG::out_index(0, u), cur[u], row_off, acc);
+                else io.store_d(od, lane_bytes, LastG::out_index(0, u), cur[u], row_off);
+            }
         }
     }
 }
@@ -362,6 +372,11 @@ __global__ __launch_bounds__(CFG::BLOCK, CFG::MINW) void fft_persist_kernel(cons
         for (int u = 0; u < R; ++u) dst[u] = io.fetch_d(d, in_lane_bytes, FirstG::in_index(0, u), in_row_off);
     };
     issue(ra, base);
+    typename persist_acc<IO>::type acc{};
+    if constexpr (io_has_acc<IO>::value) acc = io.acc_init();
+    auto finish = [&]() {
+        if constexpr (io_has_acc<IO>::value) io.acc_finish(acc);
+    };
 
     if constexpr (DEPTH == 1) {
         // One step: issue the NEXT transform's loads into NXT, then run the transform held in CUR.
@@ -371,7 +386,7 @@ __global__ __launch_bounds__(CFG::BLOCK, CFG::MINW) void fft_persist_kernel(cons
         const bool more = nbase < batch; /* workgroup-uniform */                                                     \
         issue(NXT, nbase);                                                                                           \
         __builtin_amdgcn_sched_barrier(0); /* keep the prefetch ahead of CUR's first use */                          \
-        persist_transform<T, L, RL, EPI, CFG>(CUR, st, io, tw, buf0, buf1, base + wslot, group_cnt(base), sub, tau);  \
+        persist_transform<T, L, RL, EPI, CFG>(CUR, st, io, tw, buf0, buf1, base + wslot, group_cnt(base), sub, tau, acc); \
         if (!more) LEAVE;                                                                                            \
         base = nbase;                                                                                                \
     }
@@ -380,11 +395,12 @@ __global__ __launch_bounds__(CFG::BLOCK, CFG::MINW) void fft_persist_kernel(cons
         // With the first step inside the loop the compiler must merge the entry state (no stores yet) with the back-edge
         // state and emits vmcnt(15 - i) for both -- which, on the back edge, waits for the previous transform's STORES to
         // complete, once per two transforms.  After the peel both predecessors of the loop header look the same.
-        KOFFT_PERSIST_STEP(ra, rb, return)
+        KOFFT_PERSIST_STEP(ra, rb, { finish(); return; })
         for (;;) {
             KOFFT_PERSIST_STEP(rb, ra, break)
             KOFFT_PERSIST_STEP(ra, rb, break)
         }
+        finish();
 #undef KOFFT_PERSIST_STEP
     } else {
         // Two transforms ahead (three sets): for configurations that run ONE wavefront per SIMD, where a transform's
@@ -398,16 +414,17 @@ __global__ __launch_bounds__(CFG::BLOCK, CFG::MINW) void fft_persist_kernel(cons
         const bool more = nbase < batch; /* workgroup-uniform */                                                     \
         issue(FAR, nbase + step);                                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
-        persist_transform<T, L, RL, EPI, CFG>(CUR, st, io, tw, buf0, buf1, base + wslot, group_cnt(base), sub, tau);  \
+        persist_transform<T, L, RL, EPI, CFG>(CUR, st, io, tw, buf0, buf1, base + wslot, group_cnt(base), sub, tau, acc); \
         if (!more) LEAVE;                                                                                            \
         base = nbase;                                                                                                \
     }
-        KOFFT_PERSIST_STEP2(ra, rc, return)
+        KOFFT_PERSIST_STEP2(ra, rc, { finish(); return; })
         for (;;) {
             KOFFT_PERSIST_STEP2(rb, ra, break)
             KOFFT_PERSIST_STEP2(rc, rb, break)
             KOFFT_PERSIST_STEP2(ra, rc, break)
         }
+        finish();
 #undef KOFFT_PERSIST_STEP2
     }
 }

@@ -25,6 +25,13 @@ __host__ __device__ constexpr int lds_elems(int n) { return n + (n >> 4) + 1; }
 
 struct NoInv {};
 
+// Optional per-thread accumulator a policy may carry across its stores (StftMagIO: the running maximum).  Policies
+// without one cost nothing: the kernels test io_has_acc<IO> at compile time.
+template <class IO, class = void>
+struct io_has_acc { static constexpr bool value = false; };
+template <class IO>
+struct io_has_acc<IO, decltype((void)IO::kHasAcc)> { static constexpr bool value = IO::kHasAcc; };
+
 // Default for every IO policy of a stand-alone transform: plain table indexing, threads of a transform contiguous.
 struct PlainTw {
     static constexpr bool kSlotMinor = false;
@@ -200,17 +207,42 @@ struct StftIO : PlainTw {
 // magnitude into the store cuts the output from 8 B x n to 4 B x n/2 per frame.  The maximum is a separate reduction.
 struct StftMagIO : StftIO {
     float *__restrict__ mags;  // frames x n/2
+    unsigned *__restrict__ max_bits;  // the maximum magnitude, as the bit pattern of a non-negative f32 (zeroed by the caller)
+    // The maximum rides on the stores: every thread keeps the largest magnitude it has stored (`if mag > max_mag`,
+    // spectrogram.rs:68-70: a NaN is never selected), and when the kernel is done each wavefront reduces its lanes and
+    // issues ONE atomicMax.  Non-negative floats order like their bit patterns, so the unsigned maximum is exact whatever
+    // the order of arrival; no second pass over the magnitudes.
+    static constexpr bool kHasAcc = true;
+    using Acc = float;
+    __device__ __forceinline__ Acc acc_init() const { return 0.0f; }
+    __device__ __forceinline__ void acc_finish(Acc m) const
+    {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float o = __shfl_xor(m, off);
+            if (o > m) m = o;
+        }
+        if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(max_bits, __builtin_bit_cast(unsigned, m));
+    }
     // sqrtf is correctly rounded here (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt); __fsqrt_rn is not
     __device__ __forceinline__ static float mag(cpx<float> c) { return sqrtf(c.re * c.re + c.im * c.im); }
-    __device__ __forceinline__ void store(size_t xf, int o, cpx<float> v) const
+    __device__ __forceinline__ void store_acc(size_t xf, int o, cpx<float> v, Acc &acc) const
     {
-        if (o < n / 2) st_stream(mags + xf * (size_t)(n / 2) + o, mag(v));
+        if (o < n / 2) {
+            const float m = mag(v);
+            st_stream(mags + xf * (size_t)(n / 2) + o, m);
+            if (m > acc) acc = m;
+        }
     }
     __device__ __forceinline__ rsrc_t out_desc(size_t xf) const { return make_rsrc(mags + xf * (size_t)(n / 2), (unsigned)(n / 2) * 4u); }
-    __device__ __forceinline__ void store_d(rsrc_t d, int lane_bytes, int ou, cpx<float> v, int row_off = 0) const
+    __device__ __forceinline__ void store_d_acc(rsrc_t d, int lane_bytes, int ou, cpx<float> v, int row_off, Acc &acc) const
     {
         // lane_bytes = 8 * tau (complex offset); the magnitude row has 4-byte elements
-        if (ou + (lane_bytes >> 3) < n / 2) buf_store_f32(mag(v), d, row_off + (lane_bytes >> 1), ou * 4);
+        if (ou + (lane_bytes >> 3) < n / 2) {
+            const float m = mag(v);
+            buf_store_f32(m, d, row_off + (lane_bytes >> 1), ou * 4);
+            if (m > acc) acc = m;
+        }
     }
     __device__ __forceinline__ rsrc_t out_desc_n(size_t xf0, int cnt) const
     {
@@ -218,23 +250,6 @@ struct StftMagIO : StftIO {
     }
     __device__ __forceinline__ unsigned out_row_bytes() const { return (unsigned)(n / 2) * 4u; }
 };
-
-// max over a non-negative f32 array, NaN never selected (spectrogram.rs:69-71: `if mag > max_mag`): non-negative floats
-// order like their bit patterns, so an unsigned atomicMax is exact whatever the order of arrival.
-static __global__ __launch_bounds__(256) void max_nonneg_kernel(const float *__restrict__ x, const size_t count, unsigned *__restrict__ out_bits)
-{
-    float m = 0.0f;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
-        const float v = x[i];
-        if (v > m) m = v;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const float o = __shfl_xor(m, off);
-        if (o > m) m = o;
-    }
-    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __builtin_bit_cast(unsigned, m));
-}
 
 // rfft.rs:444-446 pack z[i] = (x[2i], x[2i+1]) (with the optional row window of the
 // batched entry point); the post-pass of rfft.rs:450-463 runs in the kernel epilogue,
@@ -632,9 +647,18 @@ __global__ __launch_bounds__(BLOCK, (IO::kMinWaves > 1 && BLOCK == 512 && L >= 9
             if (k0 <= 0) st_stream(orow + k0 + N, xo[R]);
         }
     } else {
-        if (active) {
+        if constexpr (io_has_acc<IO>::value) {
+            typename IO::Acc acc = io.acc_init();
+            if (active) {
 #pragma unroll
-            for (int u = 0; u < R; ++u) io.store(xf, GL::out_index(tau, u), v[u]);
+                for (int u = 0; u < R; ++u) io.store_acc(xf, GL::out_index(tau, u), v[u], acc);
+            }
+            io.acc_finish(acc);  // every wavefront of the workgroup, active or not (the reduction uses all lanes)
+        } else {
+            if (active) {
+#pragma unroll
+                for (int u = 0; u < R; ++u) io.store(xf, GL::out_index(tau, u), v[u]);
+            }
         }
     }
 }
@@ -782,15 +806,25 @@ __global__ __launch_bounds__(kSmallBlock) void fft_small_kernel(const IO io, con
         }
     } else {
         if constexpr (N == 1) {
-            io.store(xf, 0, x[0]);
+            if constexpr (!io_has_acc<IO>::value) io.store(xf, 0, x[0]);  // (a 1-point frame has no magnitude bins: n/2 == 0)
         } else {
 #pragma unroll
             for (int i = 0; i < N; ++i) buf[t * S + i] = Y(i);
             __syncthreads();
+            if constexpr (io_has_acc<IO>::value) {
+                typename IO::Acc acc = io.acc_init();
 #pragma unroll
-            for (int j = 0; j < N; ++j) {
-                const int e = j * B + t, r = e / N, o = e % N;
-                if (xf0 + r < batch) io.store(xf0 + r, o, buf[r * S + o]);
+                for (int j = 0; j < N; ++j) {
+                    const int e = j * B + t, r = e / N, o = e % N;
+                    if (xf0 + r < batch) io.store_acc(xf0 + r, o, buf[r * S + o], acc);
+                }
+                io.acc_finish(acc);
+            } else {
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const int e = j * B + t, r = e / N, o = e % N;
+                    if (xf0 + r < batch) io.store(xf0 + r, o, buf[r * S + o]);
+                }
             }
         }
     }

@@ -236,6 +236,15 @@ template <class IO> struct PersistCfg<10, IO> : PersistCfgBase<IO> {
 template <> struct PersistCfg<10, RfftIO<float>> : PersistCfgBase<RfftIO<float>> {
     static constexpr int BLOCK = 256, MINW = 2, WG_PER_CU = 2, DEPTH = KOFFT_RFFT10_DEPTH;
 };
+#ifndef KOFFT_STFT10_DEPTH
+#define KOFFT_STFT10_DEPTH 1
+#endif
+template <> struct PersistCfg<10, StftIO> : PersistCfgBase<StftIO> {
+    static constexpr int BLOCK = 256, MINW = 2, WG_PER_CU = 2, DEPTH = KOFFT_STFT10_DEPTH;
+};
+template <> struct PersistCfg<10, StftMagIO> : PersistCfgBase<StftMagIO> {
+    static constexpr int BLOCK = 256, MINW = 2, WG_PER_CU = 2, DEPTH = KOFFT_STFT10_DEPTH;
+};
 // irfft prefetches two row elements per output: the last pass reads its twiddles from LDS to stay inside 256 VGPRs
 template <> struct PersistCfg<10, IrfftIO<float>> {
     static constexpr int BLOCK = 256, NBUF = 1, RL = 4, MINW = 2, WG_PER_CU = 2;

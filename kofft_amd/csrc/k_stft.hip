@@ -81,17 +81,10 @@ int stft_mag_dev(kofft_hip_ctx *ctx, const float *d_samples, size_t len, size_t 
             d_win = static_cast<const float *>(it->second);
         }
     }
-    StftMagIO io{{{}, d_samples, d_win, nullptr, len, hop, 0, (int)win_len}, d_mags};
+    // one launch: the magnitudes are stored and their maximum reduced by the same kernel (StftMagIO::acc_finish)
+    StftMagIO io{{{}, d_samples, d_win, nullptr, len, hop, 0, (int)win_len}, d_mags, reinterpret_cast<unsigned *>(d_max)};
     int rc = dispatch<float, EPI_STORE>(ctx, io, win_len, frames);
     if (rc) return rc;
-    const size_t count = frames * (win_len / 2);
-    if (count > 0) {
-        size_t blocks = (count + 255) / 256;
-        if (blocks > (size_t)ctx->num_cus * 8) blocks = (size_t)ctx->num_cus * 8;
-        hipLaunchKernelGGL(max_nonneg_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_mags, count,
-                           reinterpret_cast<unsigned *>(d_max));
-        KOFFT_HIP_TRY(ctx, hipGetLastError());
-    }
     return KOFFT_OK;
 }
 
