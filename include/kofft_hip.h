@@ -27,8 +27,11 @@
  *     the reference's recipe and uploaded; no device-side trigonometry).
  *   - Lengths: complex transforms take any n up to 2^26 (powers of two) / 2^25 (others:
  *     the reference's Bluestein arm, fft.rs:1088-1132, built from the same kernels).
- *     rfft / irfft / stft need a power-of-two inner transform; anything else returns
- *     KOFFT_ERR_UNSUPPORTED (never a wrong answer).
+ *     rfft / irfft (half length), stft / istft / stft_magnitudes (window length) and every
+ *     axis of the 2-D / 3-D transforms take the same range: powers of two up to 2^14 (f32) /
+ *     2^13 (f64) run fused in one kernel, anything else is composed from the complex
+ *     transform plus pack / post-pass kernels (the reference calls fft.fft on any length too:
+ *     rfft.rs:447, stft.rs:102).  Beyond that range: KOFFT_ERR_UNSUPPORTED, never a wrong answer.
  */
 #ifndef KOFFT_HIP_H
 #define KOFFT_HIP_H

@@ -63,6 +63,8 @@ struct kofft_hip_ctx {
     size_t pinned_bytes = 0;
     void *blue_tmp = nullptr;  // zero-padded work buffer of the Bluestein arm
     size_t blue_tmp_bytes = 0;
+    void *real_tmp = nullptr;  // the inner complex transform of real / STFT lengths the fused kernels do not cover
+    size_t real_tmp_bytes = 0;
     size_t big_chunk_bytes = size_t(512) << 20;  // KOFFT_HIP_BIG_CHUNK_MB; measured on config 5 with the persistent factor kernels: 128 MiB 14.7 ms, 256 13.0, 512 12.1, 1024 12.5, 2048 13.1
 };
 
@@ -428,6 +430,21 @@ int dispatch(kofft_hip_ctx *ctx, const IO &io, size_t n, size_t batch)
 }
 
 template <typename T> constexpr int max_log2_big() { return 26; }
+// complex lengths fft_dev takes: powers of two up to 2^26, anything else (Bluestein, m = next_pow2(2n-1)) up to 2^25
+inline bool complex_len_ok(size_t n) { return n <= (size_t(1) << (is_pow2(n) ? 26 : 25)); }
+// inner lengths the fused real / STFT kernels cover (one workgroup per transform); the rest is composed (real_impl.hip.h)
+template <typename T> inline bool fused_len_ok(size_t m) { return is_pow2(m) && m <= (size_t(1) << max_log2<T>()); }
+
+inline int ensure_real_tmp(kofft_hip_ctx *ctx, size_t bytes)
+{
+    if (ctx->real_tmp_bytes >= bytes) return KOFFT_OK;
+    if (ctx->real_tmp) KOFFT_HIP_TRY(ctx, hipFree(ctx->real_tmp));
+    ctx->real_tmp = nullptr;
+    ctx->real_tmp_bytes = 0;
+    KOFFT_HIP_TRY(ctx, hipMalloc(&ctx->real_tmp, bytes));
+    ctx->real_tmp_bytes = bytes;
+    return KOFFT_OK;
+}
 
 // ---- typed device-pointer entry points, one translation unit per family ---------------------------------------------
 template <typename T>

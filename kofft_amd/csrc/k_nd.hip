@@ -14,7 +14,8 @@ int fft_axis_dev(kofft_hip_ctx *ctx, T *d_data, size_t len, size_t lines, size_t
     // segments (8 lines at 2^10 still beat this route, 4 lines at 2^11 tie with it).  Instead: transpose a panel of lines into contiguous rows, run the batched (persistent) kernels
     // on it, transpose back -- four coalesced passes instead of two scattered ones (4096 x 4096 c32: 0.45 -> 0.2x ms).
     // Every line still goes through the same 1-D transform, so the results are unchanged.
-    if (ctx->nd_transpose && len >= (size_t)ctx->nd_transpose_min && stride == inner && lines * len * sizeof(cpx<T>) >= (size_t(16) << 20)) {
+    // ... and the only route for axis lengths the strided kernel does not cover (non-powers of two: Bluestein; beyond 2^14)
+    if (stride == inner && (!fused_len_ok<T>(len) || (ctx->nd_transpose && len >= (size_t)ctx->nd_transpose_min && lines * len * sizeof(cpx<T>) >= (size_t(16) << 20)))) {
         const size_t outer = lines / inner;  // dense [len][inner] blocks, outer_stride apart
         const size_t cap = size_t(1) << 30, col_bytes = len * sizeof(cpx<T>);
         size_t P = cap / col_bytes;
@@ -26,15 +27,13 @@ int fft_axis_dev(kofft_hip_ctx *ctx, T *d_data, size_t len, size_t lines, size_t
         if (OG > outer) OG = outer;
         if (OG > 65535) OG = 65535;
         const size_t need = OG * P * col_bytes;
-        if (ctx->big_tmp_bytes < need) {
-            if (ctx->big_tmp) KOFFT_HIP_TRY(ctx, hipFree(ctx->big_tmp));
-            ctx->big_tmp = nullptr;
-            ctx->big_tmp_bytes = 0;
-            KOFFT_HIP_TRY(ctx, hipMalloc(&ctx->big_tmp, need));
-            ctx->big_tmp_bytes = need;
+        // the panel lives in its own scratch: fft_dev below may use the factor path's intermediate (n > 2^14) or the
+        // Bluestein work buffer (other lengths)
+        {
+            const int prc = ensure_real_tmp(ctx, need);
+            if (prc) return prc;
         }
-        // NOTE: fft_dev on n <= 16384 never touches big_tmp (only the two-factor path does), so the panel is safe there
-        cpx<T> *panel = static_cast<cpx<T> *>(ctx->big_tmp);
+        cpx<T> *panel = static_cast<cpx<T> *>(ctx->real_tmp);
         cpx<T> *data = reinterpret_cast<cpx<T> *>(d_data);
         for (size_t o0 = 0; o0 < outer; o0 += OG) {
             const size_t og = (outer - o0 < OG) ? outer - o0 : OG;
@@ -69,7 +68,7 @@ int fft_nd_dev(kofft_hip_ctx *ctx, T *d_data, size_t depth, size_t rows, size_t 
 {
     if (depth == 0 || rows == 0 || cols == 0) return KOFFT_OK;  // ndfft.rs:84-86, 124-126
     for (size_t n : {depth, rows, cols})
-        if (!is_pow2(n) || n > (size_t(1) << max_log2<T>())) return KOFFT_ERR_UNSUPPORTED;
+        if (!complex_len_ok(n)) return KOFFT_ERR_UNSUPPORTED;
     if (!ctx || !d_data) return KOFFT_ERR_NULL;
     KOFFT_HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc;

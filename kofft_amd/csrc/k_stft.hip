@@ -5,14 +5,67 @@
 namespace kofft {
 namespace host {
 
+// ---- composed form for window lengths the fused kernels do not cover (stft.rs:91-103 calls fft.fft(frame) for ANY
+// win_len): the framing product into the output buffer, then fft_dev in place over the frames.
+__global__ __launch_bounds__(256) void stft_frame_kernel(const float *__restrict__ signal, const float *__restrict__ window,
+                                                         cpx<float> *__restrict__ out, const size_t len, const size_t win_len,
+                                                         const size_t hop, const size_t start0, const size_t total /* frames * win_len */)
+{
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const size_t f = idx / win_len, i = idx % win_len;
+    const size_t pos = start0 + f * hop + i;
+    out[idx] = mk<float>(pos < len ? signal[pos] * window[i] : 0.0f, 0.0f);  // stft.rs:95-100
+}
+
+// magnitudes of bins 0 .. n/2-1 of composed frames, and their maximum (spectrogram.rs:63-71)
+__global__ __launch_bounds__(256) void mag_kernel(const cpx<float> *__restrict__ spec, float *__restrict__ mags, unsigned *__restrict__ max_bits,
+                                                  const size_t win_len, const size_t total /* frames * (win_len/2) */)
+{
+    const size_t half = win_len / 2;
+    float m = 0.0f;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const cpx<float> c = spec[(idx / half) * win_len + idx % half];
+        const float v = sqrtf(c.re * c.re + c.im * c.im);
+        mags[idx] = v;
+        if (v > m) m = v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float o = __shfl_xor(m, off);
+        if (o > m) m = o;
+    }
+    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(max_bits, __builtin_bit_cast(unsigned, m));
+}
+
+static int stft_composed_dev(kofft_hip_ctx *ctx, const float *d_signal, size_t len, const float *d_window, size_t win_len,
+                             size_t start0, size_t hop, float *d_out, size_t count)
+{
+    size_t chunk = (size_t(512) << 20) / (win_len * 8);
+    if (chunk < 1) chunk = 1;
+    if (chunk > count) chunk = count;
+    if ((chunk * win_len + 255) / 256 > 0x7fffffffULL) return KOFFT_ERR_UNSUPPORTED;
+    for (size_t f0 = 0; f0 < count; f0 += chunk) {
+        const size_t nf = (count - f0 < chunk) ? count - f0 : chunk;
+        cpx<float> *dst = reinterpret_cast<cpx<float> *>(d_out) + f0 * win_len;
+        hipLaunchKernelGGL(stft_frame_kernel, dim3((unsigned)((nf * win_len + 255) / 256)), dim3(256), 0, ctx->stream, d_signal, d_window,
+                           dst, len, win_len, hop, start0 + f0 * hop, nf * win_len);
+        KOFFT_HIP_TRY(ctx, hipGetLastError());
+        const int rc = fft_dev<float>(ctx, reinterpret_cast<const float *>(dst), reinterpret_cast<float *>(dst), win_len, nf, 0);
+        if (rc) return rc;
+    }
+    return KOFFT_OK;
+}
+
 int stft_dev(kofft_hip_ctx *ctx, const float *d_signal, size_t len, const float *d_window, size_t win_len,
              size_t start0, size_t hop, float *d_out, size_t count)
 {
     if (count == 0) return KOFFT_OK;
     if (win_len == 0) return KOFFT_ERR_EMPTY_INPUT;  // fft.fft(&mut []) -> fft.rs:1056
-    if (!is_pow2(win_len) || win_len > (size_t(1) << max_log2<float>())) return KOFFT_ERR_UNSUPPORTED;
+    if (!complex_len_ok(win_len)) return KOFFT_ERR_UNSUPPORTED;
     if (!ctx || (!d_signal && len) || !d_window || !d_out) return KOFFT_ERR_NULL;
     KOFFT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!fused_len_ok<float>(win_len)) return stft_composed_dev(ctx, d_signal, len, d_window, win_len, start0, hop, d_out, count);
     StftIO io{{}, d_signal, d_window, reinterpret_cast<cpx<float> *>(d_out), len, hop, start0, (int)win_len};
     return dispatch<float, EPI_STORE>(ctx, io, win_len, count);
 }
@@ -25,7 +78,7 @@ int istft_dev(kofft_hip_ctx *ctx, float *d_frames, size_t frames, const float *d
     if (hop == 0) return KOFFT_ERR_INVALID_HOP_SIZE;                               // stft.rs:125 / 299
     if (mode == 1 && scratch_len != out_len) return KOFFT_ERR_MISMATCHED_LENGTHS;  // stft.rs:128
     if (frames > 0 && win_len == 0) return KOFFT_ERR_EMPTY_INPUT;                  // fft.ifft(&mut []) -> fft.rs:1136
-    if (frames > 0 && (!is_pow2(win_len) || win_len > (size_t(1) << max_log2<float>()))) return KOFFT_ERR_UNSUPPORTED;
+    if (frames > 0 && !complex_len_ok(win_len)) return KOFFT_ERR_UNSUPPORTED;
     if (!ctx || (frames && (!d_frames || !d_window)) || (out_len && (!d_output || (mode != 0 && !d_scratch)))) return KOFFT_ERR_NULL;
     KOFFT_HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (frames > 0) {
@@ -59,7 +112,7 @@ int stft_mag_dev(kofft_hip_ctx *ctx, const float *d_samples, size_t len, size_t 
     const size_t required = (len + hop - 1) / hop;
     if (frames < required) return KOFFT_ERR_MISMATCHED_LENGTHS;
     if (frames > 0 && win_len == 0) return KOFFT_ERR_EMPTY_INPUT;
-    if (frames > 0 && (!is_pow2(win_len) || win_len > (size_t(1) << max_log2<float>()))) return KOFFT_ERR_UNSUPPORTED;
+    if (frames > 0 && !complex_len_ok(win_len)) return KOFFT_ERR_UNSUPPORTED;
     if (!ctx || !d_max || (frames && (!d_mags || (!d_samples && len)))) return KOFFT_ERR_NULL;
     KOFFT_HIP_TRY(ctx, hipSetDevice(ctx->device));
     KOFFT_HIP_TRY(ctx, hipMemsetAsync(d_max, 0, sizeof(float), ctx->stream));  // max_mag starts at 0.0
@@ -80,6 +133,29 @@ int stft_mag_dev(kofft_hip_ctx *ctx, const float *d_samples, size_t len, size_t 
         } else {
             d_win = static_cast<const float *>(it->second);
         }
+    }
+    if (!fused_len_ok<float>(win_len)) {
+        // any other window length: the composed STFT into scratch, then magnitudes + maximum in one pass (in frame chunks)
+        size_t chunk = (size_t(512) << 20) / (win_len * 8);
+        if (chunk < 1) chunk = 1;
+        if (chunk > frames) chunk = frames;
+        int rc = ensure_real_tmp(ctx, chunk * win_len * 8);
+        if (rc) return rc;
+        float *spec = static_cast<float *>(ctx->real_tmp);
+        for (size_t f0 = 0; f0 < frames; f0 += chunk) {
+            const size_t nf = (frames - f0 < chunk) ? frames - f0 : chunk;
+            rc = stft_composed_dev(ctx, d_samples, len, d_win, win_len, f0 * hop, hop, spec, nf);
+            if (rc) return rc;
+            const size_t total = nf * (win_len / 2);
+            if (total) {
+                size_t blocks = (total + 255) / 256;
+                if (blocks > (size_t)ctx->num_cus * 16) blocks = (size_t)ctx->num_cus * 16;
+                hipLaunchKernelGGL(mag_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, reinterpret_cast<const cpx<float> *>(spec),
+                                   d_mags + f0 * (win_len / 2), reinterpret_cast<unsigned *>(d_max), win_len, total);
+                KOFFT_HIP_TRY(ctx, hipGetLastError());
+            }
+        }
+        return KOFFT_OK;
     }
     // one launch: the magnitudes are stored and their maximum reduced by the same kernel (StftMagIO::acc_finish)
     StftMagIO io{{{}, d_samples, d_win, nullptr, len, hop, 0, (int)win_len}, d_mags, reinterpret_cast<unsigned *>(d_max)};

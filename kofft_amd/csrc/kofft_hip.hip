@@ -196,7 +196,7 @@ int rfft_host(kofft_hip_ctx *ctx, const T *in, T *out, const T *window, size_t n
     if (n == 0) return KOFFT_ERR_EMPTY_INPUT;
     if (n % 2 != 0) return KOFFT_ERR_INVALID_VALUE;
     const size_t m = n / 2;
-    if (!is_pow2(m) || m > (size_t(1) << max_log2<T>())) return KOFFT_ERR_UNSUPPORTED;
+    if (!complex_len_ok(m)) return KOFFT_ERR_UNSUPPORTED;
     if (!ctx || !in || !out) return KOFFT_ERR_NULL;
     KOFFT_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t in_bytes = batch * n * sizeof(T), out_bytes = batch * (m + 1) * 2 * sizeof(T);
@@ -251,7 +251,7 @@ int irfft_host(kofft_hip_ctx *ctx, const T *in, T *out, size_t n, size_t batch)
     if (n == 0) return KOFFT_ERR_EMPTY_INPUT;
     if (n % 2 != 0) return KOFFT_ERR_INVALID_VALUE;
     const size_t m = n / 2;
-    if (!is_pow2(m) || m > (size_t(1) << max_log2<T>())) return KOFFT_ERR_UNSUPPORTED;
+    if (!complex_len_ok(m)) return KOFFT_ERR_UNSUPPORTED;
     if (!ctx || !in || !out) return KOFFT_ERR_NULL;
     KOFFT_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t in_bytes = batch * (m + 1) * 2 * sizeof(T), out_bytes = batch * n * sizeof(T);
@@ -295,7 +295,7 @@ int stft_host(kofft_hip_ctx *ctx, const float *signal, size_t len, const float *
 {
     if (count == 0) return KOFFT_OK;
     if (win_len == 0) return KOFFT_ERR_EMPTY_INPUT;
-    if (!is_pow2(win_len) || win_len > (size_t(1) << max_log2<float>())) return KOFFT_ERR_UNSUPPORTED;
+    if (!complex_len_ok(win_len)) return KOFFT_ERR_UNSUPPORTED;
     if (!ctx || (!signal && len) || !window || !out) return KOFFT_ERR_NULL;
     KOFFT_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t lo = start0 < len ? start0 : len;
@@ -343,7 +343,7 @@ int istft_host(kofft_hip_ctx *ctx, float *frames_data, size_t frames, const floa
     if (hop == 0) return KOFFT_ERR_INVALID_HOP_SIZE;
     if (mode == 1 && scratch_len != out_len) return KOFFT_ERR_MISMATCHED_LENGTHS;
     if (frames > 0 && win_len == 0) return KOFFT_ERR_EMPTY_INPUT;
-    if (frames > 0 && (!is_pow2(win_len) || win_len > (size_t(1) << max_log2<float>()))) return KOFFT_ERR_UNSUPPORTED;
+    if (frames > 0 && !complex_len_ok(win_len)) return KOFFT_ERR_UNSUPPORTED;
     if (!ctx || (frames && (!frames_data || !window)) || (out_len && (!output || (mode == 1 && !scratch)))) return KOFFT_ERR_NULL;
     KOFFT_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t fr_bytes = frames * win_len * 2 * sizeof(float);
@@ -394,7 +394,7 @@ int fft_nd_host(kofft_hip_ctx *ctx, T *data, size_t depth, size_t rows, size_t c
 {
     if (depth == 0 || rows == 0 || cols == 0) return KOFFT_OK;
     for (size_t n : {depth, rows, cols})
-        if (!is_pow2(n) || n > (size_t(1) << max_log2<T>())) return KOFFT_ERR_UNSUPPORTED;
+        if (!complex_len_ok(n)) return KOFFT_ERR_UNSUPPORTED;
     if (!ctx || !data) return KOFFT_ERR_NULL;
     KOFFT_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t bytes = depth * rows * cols * 2 * sizeof(T);
@@ -498,6 +498,7 @@ int kofft_hip_destroy(kofft_hip_ctx *ctx)
         if (ctx->stage[i]) (void)hipFree(ctx->stage[i]);
     if (ctx->big_tmp) (void)hipFree(ctx->big_tmp);
     if (ctx->blue_tmp) (void)hipFree(ctx->blue_tmp);
+    if (ctx->real_tmp) (void)hipFree(ctx->real_tmp);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->order_event) (void)hipEventDestroy(ctx->order_event);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -700,7 +701,7 @@ int kofft_hip_stft_magnitudes_f32(kofft_hip_ctx *ctx, const float *samples, size
     if (hop == 0) return KOFFT_ERR_INVALID_HOP_SIZE;
     if (frames < (len + hop - 1) / hop) return KOFFT_ERR_MISMATCHED_LENGTHS;
     if (frames > 0 && win_len == 0) return KOFFT_ERR_EMPTY_INPUT;
-    if (frames > 0 && (!is_pow2(win_len) || win_len > (size_t(1) << max_log2<float>()))) return KOFFT_ERR_UNSUPPORTED;
+    if (frames > 0 && !complex_len_ok(win_len)) return KOFFT_ERR_UNSUPPORTED;
     if (!ctx || !max_mag || (frames && (!mags || (!samples && len)))) return KOFFT_ERR_NULL;
     KOFFT_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t m_bytes = frames * (win_len / 2) * sizeof(float);

@@ -249,7 +249,7 @@ def test_stft_api_variants(fft32, oracle):
 
 
 # ---- error behaviour through the mirrored API -------------------------------------------------------------
-def test_error_variants_match_reference(fft32):
+def test_error_variants_match_reference(fft32, oracle):
     import kofft_amd as K
     from kofft_amd import FftError
 
@@ -282,9 +282,11 @@ def test_error_variants_match_reference(fft32):
     fft32.fft_with_strategy(d, K.FftStrategy.SplitRadix)
     fft32.fft(e)
     assert bits_equal(d, e)
-    # non-power-of-two real FFT lengths (n/2 not a power of two) are outside the device path: reported, not mis-computed
-    with pytest.raises(K.DeviceError):
-        fft32.rfft(np.zeros(12, np.float32), np.zeros(7, np.complex64))
+    # real FFT lengths whose half is not a power of two take the composed path (rfft.rs:447 calls fft.fft for any m)
+    x12 = np.arange(12, dtype=np.float32)
+    out12 = np.zeros(7, np.complex64)
+    fft32.rfft(x12.copy(), out12)
+    assert bits_equal(out12, oracle.rfft(x12[None, :])[0])
 
 
 def test_strided_split_and_batch_helpers(fft32, fft64, oracle):
@@ -407,6 +409,73 @@ def test_fft_c64_large_n(fft64, oracle, log2n, batch):
     if log2n == 20:  # tests/split64.rs-style truth check at cfg5's size: f64 drift budget 2.3e-11
         ref = np.fft.fft(x[0])
         assert rel_err(want[0], ref) < 1e-9
+
+
+# ---- real / STFT lengths beyond the fused kernels: composed from fft_dev ------------------------------
+@pytest.mark.parametrize("n,batch", [(2, 5), (6, 4), (12, 7), (30, 3), (1000, 9), (65536, 3), (1 << 20, 2), (40000, 2)])
+def test_rfft_irfft_any_length_f32(fft32, oracle, n, batch):
+    """rfft_direct / irfft_direct call fft.fft / fft.ifft on the half length whatever it is (rfft.rs:447, 504): Bluestein for
+    non-powers of two (fft.rs:1083-1132), the factor path beyond 2^14.  Window product, transform and post-pass are separate
+    kernels here; every element still sees the reference's operations in the reference's order."""
+    rng = seeded(3000 + n % 977)
+    x = rng.uniform(-1, 1, (batch, n)).astype(np.float32)
+    win = rng.uniform(0, 1, n).astype(np.float32)
+    for w in (None, win):
+        got = fft32.rfft_batch(x, w)
+        want = oracle.rfft(x, w)
+        assert_parity(got, want, f"composed rfft n={n} window={w is not None}", REL_TOL_F32)
+    spec = oracle.rfft(x)
+    assert_parity(fft32.irfft_batch(spec, n), oracle.irfft(spec, n), f"composed irfft n={n}", REL_TOL_F32)
+
+
+@pytest.mark.parametrize("n,batch", [(12, 5), (1000, 4), (65536, 2), (34, 3)])
+def test_rfft_irfft_any_length_f64(fft64, oracle, n, batch):
+    rng = seeded(3100 + n % 977)
+    x = rng.uniform(-1, 1, (batch, n))
+    got = fft64.rfft_batch(x)
+    want = oracle.rfft(x)
+    assert_parity(got, want, f"composed rfft f64 n={n}", REL_TOL_F64)
+    assert_parity(fft64.irfft_batch(want, n), oracle.irfft(want, n), f"composed irfft f64 n={n}", REL_TOL_F64)
+
+
+@pytest.mark.parametrize("win_len,hop,length", [(12, 5, 200), (1000, 250, 9000), (32768, 8192, 100_000), (3, 1, 20)])
+def test_stft_istft_any_window_length(fft32, oracle, win_len, hop, length):
+    """stft calls fft.fft(frame) for any win_len (stft.rs:91-103); istft, inverse_parallel and stft_magnitudes follow."""
+    import kofft_amd as K
+
+    rng = seeded(3200 + win_len % 977)
+    signal = rng.uniform(-1, 1, length).astype(np.float32)
+    window = oracle.hann(win_len)
+    frames = -(-length // hop) + 1
+    spec = oracle.stft(signal, window, hop, frames)
+    got = fft32.stft_into(signal, window, hop, frames)
+    assert_parity(got, spec, f"composed stft win={win_len}", REL_TOL_F32)
+    want = oracle.istft(spec, window, hop, length)
+    out = np.zeros(length, np.float32)
+    K.istft(spec.copy(), window, hop, out, np.zeros(length, np.float32), fft32)
+    assert_parity(out, want, f"istft win={win_len}", REL_TOL_F32)
+    mags, mx = fft32.stft_magnitudes(signal, win_len, hop)
+    wm, wmx = oracle.stft_magnitudes(signal, win_len, hop)
+    assert bits_equal(mags, wm) and mx == wmx
+
+
+@pytest.mark.parametrize("depth,rows,cols", [(1, 12, 10), (1, 100, 6), (6, 5, 7), (1, 3, 32768), (2, 1000, 16)])
+def test_ndfft_any_axis_length(fft32, oracle, depth, rows, cols):
+    """ndfft runs FftImpl::fft on rows and fft_strided down the other axes for any length (ndfft.rs:89-98, 131-151): axes the
+    strided kernel does not cover go through transpose -> batched fft_dev (Bluestein / factor path) -> transpose."""
+    rng = seeded(3300 + rows * 7 + cols)
+    x = rand_c(rng, (depth, rows, cols))
+    want = x.copy()
+    if depth > 1:
+        want = _oracle_axis(oracle, want, 0)
+        want = _oracle_axis(oracle, want, 1)
+        want = _oracle_axis(oracle, want, 2)
+    else:
+        want = _oracle_axis(oracle, want, 2)
+        want = _oracle_axis(oracle, want, 1)
+    y = x.copy().reshape(-1)
+    fft32.fftnd(y, depth, rows, cols)
+    assert_parity(y.reshape(depth, rows, cols), want, f"ndfft {depth}x{rows}x{cols}", REL_TOL_F32)
 
 
 # ---- ISTFT (SURVEY 8f row 1) -----------------------------------------------------------------------------------------
