@@ -17,7 +17,7 @@ template <typename T, int LS, class IO>
 int launch_tile_persist(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t units)
 {
     constexpr int RL = rl_for(LS);
-    constexpr int BLOCK = big_block<T, IO, LS>();
+    constexpr int BLOCK = big_block<T, IO, LS, 128 * 1024>();
     constexpr int TPT = (1 << LS) >> RL;
     constexpr int XPB = BLOCK / TPT;
     constexpr size_t lds = lds_wg_bytes<T, IO::kSplitLds, true, XPB>(1 << LS) +
@@ -46,7 +46,9 @@ template <typename T, int LS, class IO>
 int launch_rows_persist(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t nb)
 {
     constexpr int RL = rl_for(LS);
-    constexpr int BLOCK = big_block<T, IO, LS>();
+    // (c32 rows of 2^10 points: 16-row tiles need 1024 threads at 128 registers and spill 30 of them -- measured slower
+    // than 8-row tiles at 512 threads, 2^19: 0.244 vs 0.282 of the roofline)
+    constexpr int BLOCK = big_block<T, IO, LS, (sizeof(T) == 4 ? 80 : 128) * 1024>();
     constexpr int TPT = (1 << LS) >> RL;
     constexpr int XPB = BLOCK / TPT;
     constexpr size_t lds = lds_wg_bytes<T, IO::kSplitLds, true, XPB>(1 << LS) + (size_t)rows_tw_entries<LS, RL>() * XPB * sizeof(cpx<T>);

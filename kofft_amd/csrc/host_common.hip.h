@@ -356,12 +356,15 @@ int launch_small(kofft_hip_ctx *ctx, const IO &io, size_t batch, const cpx<T> *t
 #ifndef KOFFT_BIG_XPB
 #define KOFFT_BIG_XPB(T) (sizeof(T) == 4 ? 16 : 8)
 #endif
-template <typename T, class IO, int LS>
+// LDS_CAP: bytes of exchange buffer a workgroup may use -- 80 KiB where two workgroups share a CU (the one-tile-per-
+// workgroup kernels), 128 KiB for the persistent kernels (one workgroup per CU): c32 tiles of 2^10-point sub-transforms
+// are then 16 columns = 128-byte segments instead of 8 = 64.
+template <typename T, class IO, int LS, size_t LDS_CAP = 80 * 1024>
 constexpr int big_block()
 {
     const int tpt = (1 << LS) >> rl_for(LS);
     int xpb = KOFFT_BIG_XPB(T);
-    while (xpb > 1 && (xpb * tpt > 1024 || (size_t)xpb * (1 << LS) * 8 > 80 * 1024)) xpb /= 2;
+    while (xpb > 1 && (xpb * tpt > 1024 || (size_t)xpb * (1 << LS) * 8 > LDS_CAP)) xpb /= 2;
     int block = xpb * tpt;
     if (block < 64) block = 64;
     return block;
