@@ -69,6 +69,9 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inplace", action="store_true", help="fft4096 only: transform the buffer in place (values overflow after ~10 steps; timing study only)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work for the cpu_baseline sample")
+    ap.add_argument("--rehearse-one-card", action="store_true",
+                    help="rehearsal only (invalidates the metric): every rank uses cuda:0 and the process group is gloo, so the "
+                         "N-rank protocol (launcher, barriers, reductions, sharding, gather) can run on a one-GPU box")
     ap.add_argument("--dry-launch", action="store_true",
                     help="launcher self-test: every rank prints its rendezvous environment and exits without touching a GPU")
     return ap.parse_args(argv)
@@ -422,12 +425,17 @@ def run_rank(args) -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP library is the only implementation of this path")
+    if args.rehearse_one_card:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     n_seen = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.rehearse_one_card:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         ones = torch.ones(1, dtype=torch.float64, device=dev)
         dist.all_reduce(ones)  # a real collective: n_gpus below is the number of ranks RCCL actually connected
         n_seen = int(round(float(ones.item())))
@@ -447,7 +455,10 @@ def run_rank(args) -> None:
 
     def barrier():
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            if args.rehearse_one_card:
+                dist.barrier()
+            else:
+                dist.barrier(device_ids=[local_rank])
 
     def reduce_max(x: float) -> float:
         t = torch.tensor([x], dtype=torch.float64, device=dev)
@@ -508,6 +519,7 @@ def run_rank(args) -> None:
             "blocks_ms_per_step": head["blocks_ms_per_step"],
             "launches_total": launches[0],
             "launcher": "self" if os.environ.get("KOFFT_BENCH_LAUNCHED") else ("torchrun" if world > 1 else "single"),
+            **({"rehearsal": "every rank on cuda:0, gloo process group: NOT a measurement"} if args.rehearse_one_card else {}),
         }
         if allgather is not None:
             out["allgather"] = allgather
@@ -520,7 +532,7 @@ def run_rank(args) -> None:
         print(json.dumps(out), flush=True)
 
     if world > 1:
-        dist.barrier(device_ids=[local_rank])
+        barrier()
         dist.destroy_process_group()
 
 

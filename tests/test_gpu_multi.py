@@ -90,3 +90,31 @@ def test_multi_fft_batch(oracle):
     m.fft_batch(y, inverse=True)
     assert bits_equal(y, oracle.ifft(want))
     m.close()
+
+
+@pytest.mark.parametrize("g", [2, 3, 8])
+def test_multi_partition_on_one_card(oracle, g):
+    """G logical devices mapped onto the one physical card (devices = [0] * G): G contexts, G streams, G slices with their
+    halos, G shards written to their places -- everything of the G > 1 path except the RCCL exchange (RCCL refuses duplicate
+    devices), on hardware."""
+    import kofft_amd
+
+    sig = _signal(37_003, seed=7 + g)
+    win = kofft_amd.hann(1024)
+    hop = 256
+    frames = -(-sig.size // hop) + 2  # two frames wholly past the end: zero spectra (stft.rs:95-99)
+    want = oracle.stft(sig, win, hop, frames)
+    m = kofft_amd.HipMulti(g, devices=[0] * g)
+    got, ptrs = m.stft(sig, win, hop, frames, allgather=False, want_device_ptrs=True)
+    assert bits_equal(got, want)
+    assert len(set(ptrs)) == g  # one buffer per logical device
+    per = -(-frames // g)
+    for r in range(g):
+        assert m.shard(frames, r) == (min(r * per, frames), min((r + 1) * per, frames) - min(r * per, frames))
+    # batched complex transforms shard the same way, no exchange at all
+    from conftest import rand_c
+    x = rand_c(seeded(31 + g), (2 * g + 1, 256))
+    y = x.copy()
+    m.fft_batch(y)
+    assert bits_equal(y, oracle.fft(x))
+    m.close()
