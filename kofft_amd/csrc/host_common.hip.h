@@ -35,6 +35,7 @@ struct kofft_hip_ctx {
     bool use_persist = true;  // KOFFT_HIP_NO_PERSIST=1 forces the generic kernels (A/B measurements, tests)
     int persist_grid_pct = 0; // KOFFT_HIP_PERSIST_GRID_PCT: scale the persistent grids (measurements only)
     bool big_two_only = false; // KOFFT_HIP_BIG_TWO_FACTORS=1: never split into three factors (A/B measurements)
+    bool small32 = true;       // KOFFT_HIP_SMALL32=0: f32 n = 32 on the thread-group kernel instead of one thread per transform (A/B)
     bool big_persist = true;   // KOFFT_HIP_BIG_PERSIST=0: factors on the one-tile-per-workgroup kernel (A/B measurements)
     size_t big_persist_min_units = 32;  // KOFFT_HIP_BIG_PERSIST_MIN_UNITS: units (columns / rows) per CU from which the persistent factor kernels run
     bool big_rows_resident = true;  // KOFFT_HIP_BIG_ROWS_RESIDENT=0: last factor on the generic tile kernel (A/B measurements)
@@ -389,7 +390,7 @@ int dispatch(kofft_hip_ctx *ctx, const IO &io, size_t n, size_t batch)
     int rc = get_table<T>(ctx, Kind<T>::tw, n, &tw);
     if (rc) return rc;
     // n = 32 in f32: still one thread per transform (64 data registers), IO staged through LDS like the small sizes
-    if constexpr (sizeof(T) == 4 && !IO::kSlotMinor) if (L == 5) return launch_small<T, 32, EPI>(ctx, io, batch, tw);
+    if constexpr (sizeof(T) == 4 && !IO::kSlotMinor) if (L == 5 && ctx->small32) return launch_small<T, 32, EPI>(ctx, io, batch, tw);
     if constexpr (sizeof(T) == 4 && IO::kPersist) if (ctx->use_persist) {
         // streaming sizes: enough transforms to give every resident workgroup several iterations
         if constexpr (EPI == EPI_STORE && IO::kPersistMaxLog2 >= 13) {
