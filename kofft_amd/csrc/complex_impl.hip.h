@@ -61,17 +61,21 @@ int launch_rows_persist(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size
         const int arc = set_dyn_lds_once(ctx, attr_done, reinterpret_cast<const void *>(kern), lds);
         if (arc) return arc;
     }
-    const size_t KT = (size_t(1) << io.LA) / XPB;
+    const size_t KT = (size_t(1) << io.LA) / XPB;  // row tiles per transform
     size_t blocks = (size_t)ctx->num_cus * WG_PER_CU;
     if (ctx->persist_grid_pct > 0) blocks = blocks * (size_t)ctx->persist_grid_pct / 100;
     if (blocks < 1) blocks = 1;
-    if (blocks >= KT) {  // whole groups of workgroups per row tile, no more groups than transforms
-        size_t groups = blocks / KT;
+    // one row tile per workgroup: whole groups of workgroups per row tile (no more groups than transforms) when the chip
+    // has a CU for every row tile, otherwise one launch per slice of `blocks` row tiles
+    for (size_t kt0 = 0; kt0 < KT; kt0 += blocks) {
+        const size_t cnt = KT - kt0 < blocks ? KT - kt0 : blocks;
+        size_t groups = blocks / cnt;
         if (groups > nb) groups = nb;
-        blocks = KT * groups;
+        if (groups < 1) groups = 1;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(cnt * groups)), dim3(BLOCK), lds, ctx->stream, io, tw, (unsigned)nb, (unsigned)kt0,
+                           (unsigned)cnt);
+        KOFFT_HIP_TRY(ctx, hipGetLastError());
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BLOCK), lds, ctx->stream, io, tw, (unsigned)nb);
-    KOFFT_HIP_TRY(ctx, hipGetLastError());
     return KOFFT_OK;
 }
 

@@ -233,13 +233,6 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 1024 ? 4 : 2)) void fft_tile_persi
         const size_t xf0 = (valid ? t : 0) * XPB;
         const rsrc_t d = make_rsrc(io.in + io.xf_transform(xf0) * io.n, valid ? xf_bytes : 0u);
         const int lane = (int)((io.in_off(xf0 + slot) + ((unsigned)tau << in_sl)) * (unsigned)ES);
-#ifdef KOFFT_TILE_PTR_LOAD
-        if (valid) {
-#pragma unroll
-            for (int u = 0; u < R; ++u) dst[u] = io.load(xf0 + slot, G0::in_index(tau, u));
-        }
-        return;
-#endif
         if (io.nt_in()) {
 #pragma unroll
             for (int u = 0; u < R; ++u) dst[u] = buf_load_cpx<T, AUX_NT>(d, lane, (G0::in_index(0, u) << in_sl) * ES);
@@ -257,7 +250,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 1024 ? 4 : 2)) void fft_tile_persi
     // put VALU writes to the store-data registers right behind 16-byte buffer stores that use an SGPR offset -- a
     // sequence the compiler does not pad, and one that stored the NEXT tile's values from a few lanes about once in
     // ten launches on gfx950.)
-    auto run_tile = [&](cpx<T> *cur, const size_t t) {
+    auto run_tile = [&](cpx<T> *cur, const size_t t, const bool do_store) {
         const size_t xf = t * XPB + slot;
         if (IO::kConjIn) {
 #pragma unroll
@@ -272,16 +265,12 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 1024 ? 4 : 2)) void fft_tile_persi
         const rsrc_t d = make_rsrc(io.out + io.xf_transform(xf0) * io.n, xf_bytes);
         const int lane = (int)((io.out_off(xf) + ((unsigned)tau << out_sl)) * (unsigned)ES);
         const T scale = io.out_scale();
-#ifdef KOFFT_TILE_PTR_STORE
-#pragma unroll
-        for (int u = 0; u < R; ++u) io.store(xf, GL::out_index(tau, u), cur[u]);
-        return;
-#endif
         // 16-byte stores: the register offset goes into the VGPR offset, NOT into the SGPR offset field.  hipcc pads the
         // "store of more than 8 bytes, then a VALU write to its data registers" hazard only when the instruction has no
         // SGPR offset (it assumes the hazard away otherwise); on gfx950 the SGPR-offset form did store, about once in
         // ten launches, the NEXT value of the data registers' first half from the last lanes of each 16-lane row.
         constexpr bool nt_out = IO::kNtOut;  // tiles of this kernel are at least 64 bytes wide: streaming stores for the last factor
+        if (!do_store) return;
 #pragma unroll
         for (int u = 0; u < R; ++u) {
             cpx<T> v = cur[u];
@@ -296,11 +285,13 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 1024 ? 4 : 2)) void fft_tile_persi
     };
 
     cpx<T> ra[R], rb[R];
-#ifdef KOFFT_TILE_NO_PREFETCH
-#define KOFFT_TILE_PREFETCH(CUR, NXT) issue_loads(CUR, tile, true);
+    issue_loads(ra, tile, true);
+#ifdef KOFFT_TILE_NO_MEM /* measurement only: the arithmetic and the exchanges without global traffic inside the loop */
+#define KOFFT_TILE_PREFETCH(CUR, NXT)
+#define KOFFT_TILE_RUN(CUR) run_tile(ra, tile, !more)
 #else
 #define KOFFT_TILE_PREFETCH(CUR, NXT) issue_loads(NXT, ntile, more);
-    issue_loads(ra, tile, true);
+#define KOFFT_TILE_RUN(CUR) run_tile(CUR, tile, true)
 #endif
 #define KOFFT_TILE_STEP(CUR, NXT)                                                                        \
     {                                                                                                    \
@@ -308,15 +299,19 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 1024 ? 4 : 2)) void fft_tile_persi
         const bool more = ntile < ntiles; /* workgroup-uniform */                                        \
         KOFFT_TILE_PREFETCH(CUR, NXT)                                                                    \
         __builtin_amdgcn_sched_barrier(0); /* keep the prefetch ahead of the first use of CUR */         \
-        run_tile(CUR, tile);                                                                             \
+        KOFFT_TILE_RUN(CUR);                                                                             \
         if (!more) break;                                                                                \
         tile = ntile;                                                                                    \
         __syncthreads(); /* the last gathers of this tile are done before the next tile's first scatter */ \
     }
-    for (;;) {
+    do {  // first step peeled: see fft_rows_persist_kernel
         KOFFT_TILE_STEP(ra, rb)
-        KOFFT_TILE_STEP(rb, ra)
-    }
+        for (;;) {
+            KOFFT_TILE_STEP(rb, ra)
+            KOFFT_TILE_STEP(ra, rb)
+        }
+    } while (false);
+#undef KOFFT_TILE_RUN
 #undef KOFFT_TILE_STEP
 #undef KOFFT_TILE_PREFETCH
 }
@@ -374,7 +369,8 @@ __host__ __device__ constexpr int rows_tw_entries()
 
 template <typename T, int L, int RL, int BLOCK, class IO>
 __global__ __launch_bounds__(BLOCK, (BLOCK >= 1024 ? 4 : 2)) void fft_rows_persist_kernel(const IO io, const cpx<T> *__restrict__ tw,
-                                                                                         const unsigned nb)
+                                                                                         const unsigned nb, const unsigned kt_base,
+                                                                                         const unsigned kt_count)
 {
     constexpr int N = 1 << L;
     constexpr int R = 1 << RL;
@@ -397,16 +393,16 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 1024 ? 4 : 2)) void fft_rows_persi
     const int tau = tid / XPB;
     const int slot = tid % XPB;
 
-    // ---- which row tiles and which transforms this workgroup owns
-    const unsigned KT = (1u << io.LA) / XPB;  // row tiles per transform
+    // ---- which row tile and which transforms this workgroup owns: the launch covers row tiles kt_base .. kt_base +
+    // kt_count - 1 with `groups` = gridDim.x / kt_count workgroups each, a workgroup taking every groups-th transform.
+    // (When a transform has more row tiles than the chip has CUs the host launches once per slice of row tiles: ONE row
+    // tile per workgroup keeps table loads out of the pipelined loop -- see load_tables.)
     const unsigned G = gridDim.x, w = blockIdx.x;
-    const bool wide = G >= KT;
-    const unsigned groups = wide ? G / KT : 1u;
-    if (wide && w >= KT * groups) return;
-    unsigned kt = wide ? w % KT : w;
-    const unsigned kt_step = wide ? KT : G;       // wide: one row tile only (kt + KT is past the end)
-    const unsigned b_first = wide ? w / KT : 0u;
-    if (kt >= KT || b_first >= nb) return;
+    const unsigned groups = G / kt_count;
+    if (groups == 0 || w >= kt_count * groups) return;
+    const unsigned kt = kt_base + w % kt_count;
+    const unsigned b_first = w / kt_count;
+    if (b_first >= nb) return;
     unsigned b = b_first;
 
     const unsigned xf_bytes = (unsigned)(io.n * sizeof(cpx<T>));
@@ -459,10 +455,15 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 1024 ? 4 : 2)) void fft_rows_persi
 #pragma unroll
         for (int g = 0; g < GRP; ++g)
             load_pass_twiddles_map<T, L, GL::S0, QL>(twl + g * ((1 << QL) - 1), (tau + g * TPT) >> GL::JB, tw, map);
+        // The table loads must have LANDED before the tile loop is (re-)entered.  Left pending, they are "maybe in flight"
+        // at the loop header on one incoming path, and the compiler then guards every use of twl[] inside the loop with
+        // s_waitcnt vmcnt(4) .. vmcnt(0) -- which, vmcnt counting in order, also waits for the just-issued prefetch of
+        // the next tile before the current tile may finish and store (found in the ISA; it cost the overlap).
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
         __syncthreads();
     };
 
-    auto run_tile = [&](cpx<T> *cur, const unsigned tkt, const unsigned tb) {
+    auto run_tile = [&](cpx<T> *cur, const unsigned tkt, const unsigned tb, const bool do_store) {
         // passes 0 .. NP-2 from the LDS tables, last pass from registers
         reg_pass_lds<T, RL, XPB>(cur, tw_lds + lds_base[0]);
         if constexpr (NP > 2) {
@@ -479,6 +480,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 1024 ? 4 : 2)) void fft_rows_persi
         const rsrc_t d = make_rsrc(io.out + (size_t)tb * io.n, xf_bytes);
         const int lane = (int)((tkt * XPB + slot + ((unsigned)tau << out_sl)) * (unsigned)ES);
         const T scale = io.out_scale();
+        if (!do_store) return;
         // (offsets in the VGPR field: see fft_tile_persist_kernel)
 #pragma unroll
         for (int u = 0; u < R; ++u) {
@@ -496,25 +498,25 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 1024 ? 4 : 2)) void fft_rows_persi
     issue_loads(ra, kt, b, true);
 #define KOFFT_ROWS_STEP(CUR, NXT)                                                                          \
     {                                                                                                      \
-        unsigned nkt = kt, nbb = b + groups;                                                               \
-        if (nbb >= nb) {                                                                                   \
-            nbb = b_first;                                                                                 \
-            nkt = kt + kt_step;                                                                            \
-        }                                                                                                  \
-        const bool more = nkt < KT; /* workgroup-uniform */                                                \
-        issue_loads(NXT, nkt, nbb, more);                                                                  \
+        const unsigned nbb = b + groups;                                                                   \
+        const bool more = nbb < nb; /* workgroup-uniform */                                                \
+        issue_loads(NXT, kt, nbb, more);                                                                   \
         __builtin_amdgcn_sched_barrier(0); /* keep the prefetch ahead of the first use of CUR */           \
-        run_tile(CUR, kt, b);                                                                              \
+        run_tile(CUR, kt, b, true);                                                                        \
         if (!more) break;                                                                                  \
-        __syncthreads(); /* this tile's last gathers and table reads are done */                          \
-        if (nkt != kt) load_tables(nkt); /* the next row tile: its own table entries */                    \
-        kt = nkt;                                                                                          \
         b = nbb;                                                                                           \
+        __syncthreads(); /* this tile's last gathers and table reads are done */                          \
     }
-    for (;;) {
+    // The first step is peeled off the loop so that both predecessors of the loop header carry the same pending
+    // operations (loads of one set, stores of the other): with the first step inside, the header merges "no stores yet"
+    // with the back edge and the compiler's conservative vmcnt makes every tile wait for the previous tile's stores.
+    do {
         KOFFT_ROWS_STEP(ra, rb)
-        KOFFT_ROWS_STEP(rb, ra)
-    }
+        for (;;) {
+            KOFFT_ROWS_STEP(rb, ra)
+            KOFFT_ROWS_STEP(ra, rb)
+        }
+    } while (false);
 #undef KOFFT_ROWS_STEP
 }
 
