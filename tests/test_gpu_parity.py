@@ -411,6 +411,30 @@ def test_fft_c64_large_n(fft64, oracle, log2n, batch):
         assert rel_err(want[0], ref) < 1e-9
 
 
+@pytest.mark.parametrize("dtype,log2n,batch", [("c64", 20, 18), ("c64", 16, 300), ("c64", 22, 3), ("c32", 17, 200), ("c32", 20, 40),
+                                               ("c32", 22, 6), ("c64", 19, 40)])
+def test_large_n_persistent_factor_kernels(fft32, fft64, oracle, dtype, log2n, batch):
+    """Batches large enough for the persistent factor kernels (fft_tile_persist_kernel / fft_rows_persist_kernel: every
+    resident workgroup walks several tiles, prefetching the next; the last factor keeps its table entries resident per row
+    tile): forward and inverse, the first / middle / last transforms bit for bit against the oracle, Parseval on all."""
+    n = 1 << log2n
+    cdt = np.complex128 if dtype == "c64" else np.complex64
+    fft = fft64 if dtype == "c64" else fft32
+    rng = seeded(3400 + log2n)
+    x = rand_c(rng, (batch, n), cdt)
+    y = x.copy()
+    fft.fft_batch(y)
+    pick = sorted({0, 1, batch // 2, batch - 1})
+    want = oracle.fft(x[pick])
+    tol = REL_TOL_F64 if dtype == "c64" else REL_TOL_F32
+    assert_parity(y[pick], want, f"persistent factors {dtype} 2^{log2n}", tol)
+    ex = (np.abs(x) ** 2).sum(axis=1, dtype=np.float64)
+    ey = (np.abs(y) ** 2).sum(axis=1, dtype=np.float64) / n
+    assert np.max(np.abs(ey - ex) / ex) < (1e-8 if dtype == "c64" else 3e-3)  # the recurrence tables drift (2^22 f64: 1.1e-9)
+    fft.fft_batch(y, inverse=True)
+    assert_parity(y[pick], oracle.ifft(want), f"persistent factors inverse {dtype} 2^{log2n}", tol)
+
+
 # ---- real / STFT lengths beyond the fused kernels: composed from fft_dev (VERDICT r1 item 6) ------------------------------
 @pytest.mark.parametrize("n,batch", [(2, 5), (6, 4), (12, 7), (30, 3), (1000, 9), (65536, 3), (1 << 20, 2), (40000, 2)])
 def test_rfft_irfft_any_length_f32(fft32, oracle, n, batch):
