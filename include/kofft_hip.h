@@ -76,6 +76,9 @@ int kofft_hip_destroy(kofft_hip_ctx *ctx);
  * the context's own stream. */
 int kofft_hip_set_stream(kofft_hip_ctx *ctx, void *hip_stream);
 int kofft_hip_synchronize(kofft_hip_ctx *ctx);
+/* The context's scratch (host-pointer staging, the large-n intermediate, the Bluestein and composed-length work buffers)
+ * only grows with the largest call seen; this synchronises the stream and frees it all (tables stay cached). */
+int kofft_hip_release_scratch(kofft_hip_ctx *ctx);
 
 /* ---- tables: the planner recipes, on the host --------------------------------
  * kofft_hip_twiddles_*: FftPlanner::get_twiddles(n) (fft.rs:370-408), n/2 complex.

@@ -529,6 +529,29 @@ int kofft_hip_synchronize(kofft_hip_ctx *ctx)
     return KOFFT_OK;
 }
 
+int kofft_hip_release_scratch(kofft_hip_ctx *ctx)
+{
+    if (!ctx) return KOFFT_ERR_NULL;
+    KOFFT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    KOFFT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 3; ++i) {
+        if (ctx->stage[i]) (void)hipFree(ctx->stage[i]);
+        ctx->stage[i] = nullptr;
+        ctx->stage_bytes[i] = 0;
+    }
+    void **bufs[] = {&ctx->big_tmp, &ctx->blue_tmp, &ctx->real_tmp};
+    size_t *sizes[] = {&ctx->big_tmp_bytes, &ctx->blue_tmp_bytes, &ctx->real_tmp_bytes};
+    for (int i = 0; i < 3; ++i) {
+        if (*bufs[i]) (void)hipFree(*bufs[i]);
+        *bufs[i] = nullptr;
+        *sizes[i] = 0;
+    }
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    ctx->pinned = ctx->pinned_dev = nullptr;
+    ctx->pinned_bytes = 0;
+    return KOFFT_OK;
+}
+
 int kofft_hip_twiddles_f32(size_t n, float *out)
 {
     if (!out && n >= 2) return KOFFT_ERR_NULL;
