@@ -20,7 +20,7 @@ int launch_tile_persist(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size
     constexpr int BLOCK = big_block<T, IO, LS, 128 * 1024>();
     constexpr int TPT = (1 << LS) >> RL;
     constexpr int XPB = BLOCK / TPT;
-    constexpr size_t lds = lds_wg_bytes<T, IO::kSplitLds, true, XPB>(1 << LS) +
+    constexpr size_t lds = TileExchange<T, LS, RL, XPB, IO::kSplitLds>::bytes +
                            (IO::kTileInvariantTw ? (size_t(1) << LS) / 2 * sizeof(cpx<T>) : 0);  // + the first factor's table copy
     constexpr int WG_PER_CU = BLOCK >= 512 ? 1 : 512 / BLOCK;
     static_assert(lds * WG_PER_CU <= 160 * 1024, "LDS budget");
@@ -51,7 +51,7 @@ int launch_rows_persist(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size
     constexpr int BLOCK = big_block<T, IO, LS, (sizeof(T) == 4 ? 80 : 128) * 1024>();
     constexpr int TPT = (1 << LS) >> RL;
     constexpr int XPB = BLOCK / TPT;
-    constexpr size_t lds = lds_wg_bytes<T, IO::kSplitLds, true, XPB>(1 << LS) + (size_t)rows_tw_entries<LS, RL>() * XPB * sizeof(cpx<T>);
+    constexpr size_t lds = TileExchange<T, LS, RL, XPB, IO::kSplitLds>::bytes + (size_t)rows_tw_entries<LS, RL>() * XPB * sizeof(cpx<T>);
     constexpr int WG_PER_CU = BLOCK >= 512 ? 1 : 512 / BLOCK;
     static_assert(lds * WG_PER_CU <= 160 * 1024, "LDS budget");
     if (nb > 0xffffffffULL || ((size_t(1) << io.LA) % XPB) != 0) return KOFFT_ERR_UNSUPPORTED;

@@ -178,6 +178,51 @@ struct BigMidIO {
 // byte offset + a wave-uniform offset per register" (local index i of a unit sits at  off(unit) + (i << sl)  inside its
 // transform), so the 16 loads / stores of a set cost no 64-bit address arithmetic.
 // Same butterflies, same table entries as fft_wg_kernel with the same policy: bit-identical results.
+// ---- whole-value (16-byte) exchange for the persistent c64 kernels of 2^10-point factors ---------------------------------
+// With the CU's LDS to itself (one workgroup per CU) a c64 tile fits as whole values: 8 x 1024 x 16 B = 128 KiB.  One
+// scatter, one barrier, one gather per exchange (the split form: two of each plus two more barriers), no temporaries.
+// Cells of 16 bytes, slot-minor:  cell(idx, slot) = (idx ^ bit2(idx)) * 8 + slot.
+//   ds_write_b128 serves lanes in groups of 8 = the 8 slots of one thread index: 8 consecutive cells, all 32 banks once.
+//   ds_read_b128 serves lanes in four groups of 16 -- {0-3, 12-15, 20-27}, ... = slots 0-3 of thread 4g and 4g+3 with
+//   slots 4-7 of 4g+1 and 4g+2, or the complement: conflict-free iff the cells' low index bit differs between threads
+//   4g / 4g+3 and between 4g+1 / 4g+2.  The middle pass gathers idx = [tau >> 2][c][tau & 3]: bit 0 is the thread's
+//   bit 0 (bit 2 is constant per instruction); the last pass gathers idx = [tau][c]: bit 0 is constant, bit 2 is the
+//   thread's bit 0 -- the XOR makes both shapes differ where they must.  (Derived for L = 10, RL = 4 only.)
+__host__ __device__ constexpr int lds_cell_b128(int idx, int slot) { return ((idx ^ ((idx >> 2) & 1)) << 3) + slot; }
+
+template <typename T, int L, int RL, int P, int XPB>
+__device__ __forceinline__ void wg_exchange_b128(cpx<T> *v, char *base, const int tau, const int slot)
+{
+    static_assert(L == 10 && RL == 4 && XPB == 8 && sizeof(cpx<T>) == 16, "layout derived for 2^10-point c64 tiles of 8 units");
+    using Gs = WgGeom<L, RL, P>;
+    using Gg = WgGeom<L, RL, P + 1>;
+    constexpr int R = 1 << RL;
+    cpx<T> *buf = reinterpret_cast<cpx<T> *>(base);
+    if (P > 0) __syncthreads();  // every gather of the previous exchange is done
+#pragma unroll
+    for (int u = 0; u < R; ++u) buf[lds_cell_b128(Gs::out_index(tau, u), slot)] = v[u];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < R; ++u) v[u] = buf[lds_cell_b128(Gg::in_index(tau, u), slot)];
+}
+
+// which exchange a persistent factor kernel uses, and how many bytes it needs
+template <typename T, int L, int RL, int XPB, bool SPLIT>
+struct TileExchange {
+#ifdef KOFFT_TILE_SPLIT_ONLY
+    static constexpr bool kWhole = false;
+#else
+    static constexpr bool kWhole = SPLIT && L == 10 && RL == 4 && XPB == 8 && sizeof(cpx<T>) == 16;
+#endif
+    static constexpr size_t bytes = kWhole ? (size_t)XPB * (1 << L) * sizeof(cpx<T>) : lds_wg_bytes<T, SPLIT, true, XPB>(1 << L);
+    template <int P>
+    __device__ static __forceinline__ void run(cpx<T> *v, char *base, const int tau, const int slot)
+    {
+        if constexpr (kWhole) wg_exchange_b128<T, L, RL, P, XPB>(v, base, tau, slot);
+        else wg_exchange<T, L, RL, P, SPLIT, true, XPB>(v, base, tau, slot);
+    }
+};
+
 template <typename T, int L, int RL, int BLOCK, class IO>
 __global__ __launch_bounds__(BLOCK, (BLOCK >= 1024 ? 4 : 2)) void fft_tile_persist_kernel(const IO io, const cpx<T> *__restrict__ tw,
                                                                               const size_t ntiles)
@@ -208,7 +253,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 1024 ? 4 : 2)) void fft_tile_persi
     // read one address (broadcast).  Behind the exchange region.
     const cpx<T> *tw_lds = nullptr;
     if constexpr (IO::kTileInvariantTw) {
-        cpx<T> *tl = reinterpret_cast<cpx<T> *>(smem_raw + lds_wg_bytes<T, SPLIT, true, XPB>(N));
+        cpx<T> *tl = reinterpret_cast<cpx<T> *>(smem_raw + TileExchange<T, L, RL, XPB, SPLIT>::bytes);
         for (int i = tid; i < N / 2; i += BLOCK) tl[i] = tw[io.tw_map(0)(i, 0)];
         tw_lds = tl;
         __syncthreads();
@@ -257,10 +302,10 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 1024 ? 4 : 2)) void fft_tile_persi
             for (int u = 0; u < R; ++u) cur[u].im = -cur[u].im;  // ifft: conj on the way in (fft.rs:1163-1165)
         }
         compute(std::integral_constant<int, 0>{}, cur, xf);
-        if constexpr (NP > 1) { wg_exchange<T, L, RL, 0, SPLIT, true, XPB>(cur, smem_raw, tau, slot); compute(std::integral_constant<int, 1>{}, cur, xf); }
-        if constexpr (NP > 2) { wg_exchange<T, L, RL, 1, SPLIT, true, XPB>(cur, smem_raw, tau, slot); compute(std::integral_constant<int, 2>{}, cur, xf); }
-        if constexpr (NP > 3) { wg_exchange<T, L, RL, 2, SPLIT, true, XPB>(cur, smem_raw, tau, slot); compute(std::integral_constant<int, 3>{}, cur, xf); }
-        if constexpr (NP > 4) { wg_exchange<T, L, RL, 3, SPLIT, true, XPB>(cur, smem_raw, tau, slot); compute(std::integral_constant<int, 4>{}, cur, xf); }
+        if constexpr (NP > 1) { TileExchange<T, L, RL, XPB, SPLIT>::template run<0>(cur, smem_raw, tau, slot); compute(std::integral_constant<int, 1>{}, cur, xf); }
+        if constexpr (NP > 2) { TileExchange<T, L, RL, XPB, SPLIT>::template run<1>(cur, smem_raw, tau, slot); compute(std::integral_constant<int, 2>{}, cur, xf); }
+        if constexpr (NP > 3) { TileExchange<T, L, RL, XPB, SPLIT>::template run<2>(cur, smem_raw, tau, slot); compute(std::integral_constant<int, 3>{}, cur, xf); }
+        if constexpr (NP > 4) { TileExchange<T, L, RL, XPB, SPLIT>::template run<3>(cur, smem_raw, tau, slot); compute(std::integral_constant<int, 4>{}, cur, xf); }
         const size_t xf0 = t * XPB;
         const rsrc_t d = make_rsrc(io.out + io.xf_transform(xf0) * io.n, xf_bytes);
         const int lane = (int)((io.out_off(xf) + ((unsigned)tau << out_sl)) * (unsigned)ES);
@@ -388,7 +433,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 1024 ? 4 : 2)) void fft_rows_persi
     constexpr int FULL = R - 1;  // entries per group of a full pass
 
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    cpx<T> *tw_lds = reinterpret_cast<cpx<T> *>(smem_raw + lds_wg_bytes<T, SPLIT, true, XPB>(N));
+    cpx<T> *tw_lds = reinterpret_cast<cpx<T> *>(smem_raw + TileExchange<T, L, RL, XPB, SPLIT>::bytes);
     const int tid = threadIdx.x;
     const int tau = tid / XPB;
     const int slot = tid % XPB;
@@ -467,14 +512,14 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 1024 ? 4 : 2)) void fft_rows_persi
         // passes 0 .. NP-2 from the LDS tables, last pass from registers
         reg_pass_lds<T, RL, XPB>(cur, tw_lds + lds_base[0]);
         if constexpr (NP > 2) {
-            wg_exchange<T, L, RL, 0, SPLIT, true, XPB>(cur, smem_raw, tau, slot);
+            TileExchange<T, L, RL, XPB, SPLIT>::template run<0>(cur, smem_raw, tau, slot);
             reg_pass_lds<T, RL, XPB>(cur, tw_lds + lds_base[NP > 2 ? 1 : 0]);
         }
         if constexpr (NP > 3) {
-            wg_exchange<T, L, RL, 1, SPLIT, true, XPB>(cur, smem_raw, tau, slot);
+            TileExchange<T, L, RL, XPB, SPLIT>::template run<1>(cur, smem_raw, tau, slot);
             reg_pass_lds<T, RL, XPB>(cur, tw_lds + lds_base[NP > 3 ? 2 : 0]);
         }
-        wg_exchange<T, L, RL, NP - 2, SPLIT, true, XPB>(cur, smem_raw, tau, slot);
+        TileExchange<T, L, RL, XPB, SPLIT>::template run<NP - 2>(cur, smem_raw, tau, slot);
 #pragma unroll
         for (int g = 0; g < GRP; ++g) reg_pass_r<T, QL>(cur + g * (1 << QL), twl + g * ((1 << QL) - 1));
         const rsrc_t d = make_rsrc(io.out + (size_t)tb * io.n, xf_bytes);
