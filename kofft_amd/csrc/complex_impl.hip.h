@@ -142,7 +142,7 @@ int fft_big_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t ba
     // Two factors while both stay <= 2^10 points (tiles of 8 adjacent columns / rows, 64..128-byte segments); from 2^22
     // on, three factors of 7..9 bits: one more pass over HBM, but every pass keeps full-width tiles (two factors of
     // 11..13 bits shrink the tiles to 4, 2, 1 columns and fall to 0.05..0.16 of the roofline).
-    const bool three = L >= 22 && !ctx->big_two_only;  // measured crossover (2^21: two factors still ahead)
+    const bool three = L >= ctx->big_three_min && !ctx->big_two_only;  // measured crossover, KOFFT_HIP_BIG_THREE_MIN
     const int L1 = three ? (L + 2) / 3 : L / 2;
     const int L2 = three ? (L - L1 + 1) / 2 : 0;
     const int L3 = L - L1 - L2;

@@ -35,6 +35,7 @@ struct kofft_hip_ctx {
     bool use_persist = true;  // KOFFT_HIP_NO_PERSIST=1 forces the generic kernels (A/B measurements, tests)
     int persist_grid_pct = 0; // KOFFT_HIP_PERSIST_GRID_PCT: scale the persistent grids (measurements only)
     bool big_two_only = false; // KOFFT_HIP_BIG_TWO_FACTORS=1: never split into three factors (A/B measurements)
+    int big_three_min = 22;    // KOFFT_HIP_BIG_THREE_MIN: smallest log2 n split into three factors
     bool small32 = true;       // KOFFT_HIP_SMALL32=0: f32 n = 32 on the thread-group kernel instead of one thread per transform (A/B)
     bool big_persist = true;   // KOFFT_HIP_BIG_PERSIST=0: factors on the one-tile-per-workgroup kernel (A/B measurements)
     size_t big_persist_min_units = 32;  // KOFFT_HIP_BIG_PERSIST_MIN_UNITS: units (columns / rows) per CU from which the persistent factor kernels run

@@ -459,6 +459,7 @@ int kofft_hip_create(int device, kofft_hip_ctx **out)
     if (const char *e = getenv("KOFFT_HIP_NO_PERSIST")) ctx->use_persist = !(e[0] == '1');
     if (const char *e = getenv("KOFFT_HIP_PERSIST_GRID_PCT")) ctx->persist_grid_pct = atoi(e);
     if (const char *e = getenv("KOFFT_HIP_BIG_TWO_FACTORS")) ctx->big_two_only = (e[0] == '1');
+    if (const char *e = getenv("KOFFT_HIP_BIG_THREE_MIN")) ctx->big_three_min = atoi(e);
     if (const char *e = getenv("KOFFT_HIP_SMALL32")) ctx->small32 = !(e[0] == '0');
     if (const char *e = getenv("KOFFT_HIP_BIG_PERSIST")) ctx->big_persist = !(e[0] == '0');
     if (const char *e = getenv("KOFFT_HIP_BIG_MID_NT")) ctx->big_mid_nt = atoi(e);
