@@ -152,6 +152,21 @@ struct PersistState {
     int g1, g2, g3, sc;  // LDS bases: gathers of passes 1, 2, 3; scatter
 };
 
+// The prefetched form of a policy's input: IO::Raw, or -- for a policy that pairs row elements k and m - k inside a
+// wavefront (io_pairs_in_wave, transforms of at most 64 threads) -- IO::RawPair plus one extra register for element m.
+template <class IO, int TPT, bool PAIR = io_pairs_in_wave<IO>::value && (TPT <= 64)>
+struct persist_raw {
+    using type = typename IO::Raw;
+    static constexpr int extra = 0;
+    static constexpr bool pair = false;
+};
+template <class IO, int TPT>
+struct persist_raw<IO, TPT, true> {
+    using type = typename IO::RawPair;
+    static constexpr int extra = 1;
+    static constexpr bool pair = true;
+};
+
 // One transform: raw[] holds its (already landed or still in flight) inputs.
 struct NoAcc {};
 template <class IO, bool HAS = io_has_acc<IO>::value>
@@ -160,7 +175,8 @@ template <class IO>
 struct persist_acc<IO, true> { using type = typename IO::Acc; };
 
 template <typename T, int L, int RL, int EPI, class CFG, class IO>
-__device__ __forceinline__ void persist_transform(const typename IO::Raw *raw, const PersistState<T, L, RL, EPI, IO, CFG> &st,
+__device__ __forceinline__ void persist_transform(const typename persist_raw<IO, ((1 << L) >> RL)>::type *raw,
+                                                  const PersistState<T, L, RL, EPI, IO, CFG> &st,
                                                   const IO &io, const cpx<T> *__restrict__ tw, cpx<T> *buf0, cpx<T> *buf1,
                                                   const size_t xf0, const int cnt, const int sub, const int tau,
                                                   typename persist_acc<IO>::type &acc)
@@ -179,7 +195,10 @@ __device__ __forceinline__ void persist_transform(const typename IO::Raw *raw, c
 
     cpx<T> cur[R];
     constexpr int GRP = TPT >= 64 ? 1 : 64 / TPT;
-    if (io.inside(xf0 + (GRP - 1))) {  // wave-uniform: every frame of the group lies inside the signal -> no range select
+    if constexpr (persist_raw<IO, TPT>::pair) {
+        static_assert(CFG::kInvInLds, "paired input: the table entries come from the LDS copy");
+        io.template finish_pairs<R, TPT>(raw, tau, cur, [&](int u) { return (st.inv_lds + tau)[FirstG::in_index(0, u)]; });
+    } else if (io.inside(xf0 + (GRP - 1))) {  // wave-uniform: every frame of the group lies inside the signal -> no range select
 #pragma unroll
         for (int u = 0; u < R; ++u) {
             if constexpr (CFG::kInvInLds) cur[u] = io.finish_in(raw[u], (st.inv_lds + tau)[FirstG::in_index(0, u)]);
@@ -297,7 +316,9 @@ __global__ __launch_bounds__(CFG::BLOCK, CFG::MINW) void fft_persist_kernel(cons
     static_assert(NP >= 2 && NP <= 4 && (NP < 4 || NBUF == 1), "persistent kernel is built for 2 to 4 register passes");
     static_assert(NBUF == 1 || (NBUF == 2 && !WAVE), "NBUF");
     using FirstG = PassGeom<L, RL, 0>;
-    using Raw = typename IO::Raw;
+    using RawSel = persist_raw<IO, TPT>;
+    using Raw = typename RawSel::type;
+    constexpr int RS = R + RawSel::extra;  // registers of one prefetch set
 
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int tid = threadIdx.x;
@@ -355,7 +376,7 @@ __global__ __launch_bounds__(CFG::BLOCK, CFG::MINW) void fft_persist_kernel(cons
     // computed, the others receive the loads of the transforms that follow.
     constexpr int DEPTH = persist_depth<CFG>::value;
     static_assert(DEPTH == 1 || DEPTH == 2, "prefetch distance");
-    Raw ra[R], rb[R];
+    Raw ra[RS], rb[RS];
     const int in_lane_bytes = tau * IO::kRawBytes;
     const int in_row_off = (G == 1) ? 0 : sub * (int)io.in_slot_bytes();
     // valid transforms of this wavefront's group when the workgroup sits at `b`
@@ -368,8 +389,14 @@ __global__ __launch_bounds__(CFG::BLOCK, CFG::MINW) void fft_persist_kernel(cons
     // register shuffles behind them).
     auto issue = [&](Raw *dst, const size_t b) {
         const rsrc_t d = io.in_desc_n(b + wslot, group_cnt(b));
+        if constexpr (RawSel::pair) {
 #pragma unroll
-        for (int u = 0; u < R; ++u) dst[u] = io.fetch_d(d, in_lane_bytes, FirstG::in_index(0, u), in_row_off);
+            for (int u = 0; u < R; ++u) dst[u] = io.fetch_pair_d(d, in_lane_bytes, FirstG::in_index(0, u), in_row_off);
+            dst[R] = io.fetch_last_d(d, in_row_off);
+        } else {
+#pragma unroll
+            for (int u = 0; u < R; ++u) dst[u] = io.fetch_d(d, in_lane_bytes, FirstG::in_index(0, u), in_row_off);
+        }
     };
     issue(ra, base);
     typename persist_acc<IO>::type acc{};
@@ -406,7 +433,7 @@ __global__ __launch_bounds__(CFG::BLOCK, CFG::MINW) void fft_persist_kernel(cons
         // Two transforms ahead (three sets): for configurations that run ONE wavefront per SIMD, where a transform's
         // own work (~3 us) is not enough time for its successor's loads to land under load.  While transform t is
         // computed, t+1 has been in flight for a whole transform and t+2 is issued.
-        Raw rc[R];
+        Raw rc[RS];
         issue(rb, base + step);
 #define KOFFT_PERSIST_STEP2(CUR, FAR, LEAVE)                                                                         \
     {                                                                                                                \

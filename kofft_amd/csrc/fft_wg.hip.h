@@ -32,6 +32,13 @@ struct io_has_acc { static constexpr bool value = false; };
 template <class IO>
 struct io_has_acc<IO, decltype((void)IO::kHasAcc)> { static constexpr bool value = IO::kHasAcc; };
 
+// A policy whose input value k needs row elements k AND m - k (irfft) can get the second one from the lane that loaded it
+// instead of loading it again, when a transform's threads share a wavefront: io_pairs_in_wave<IO> (see IrfftIO).
+template <class IO, class = void>
+struct io_pairs_in_wave { static constexpr bool value = false; };
+template <class IO>
+struct io_pairs_in_wave<IO, decltype((void)IO::kPairInWave)> { static constexpr bool value = IO::kPairInWave; };
+
 // Default for every IO policy of a stand-alone transform: plain table indexing, threads of a transform contiguous.
 struct PlainTw {
     static constexpr bool kSlotMinor = false;
@@ -356,6 +363,40 @@ struct IrfftIO : PlainTw {
     static constexpr bool kInvInLds = true;
     static constexpr bool kLeanRegisters = false;
     struct Raw { cpx<T> a, rb; };  // input[k], input[m-k]
+    // Transforms whose threads share a wavefront (m <= 64 points per thread-group of at most 64 lanes): thread tau holds
+    // k = tau + tpt*u, and m - k = (tpt - tau) + tpt*(R-1-u) is register R-1-u of lane tpt - tau -- one ds_bpermute per
+    // word instead of a second load (lane 0 pairs with itself: register R-u, and input[m] for u = 0, loaded once per
+    // transform as register R of the set).  Halves the load instructions and the prefetch registers.
+    static constexpr bool kPairInWave = sizeof(T) == 4;
+    using RawPair = cpx<T>;
+    __device__ __forceinline__ RawPair fetch_pair_d(rsrc_t d, int lane_bytes, int iu, int row_off) const
+    {
+        return buf_load_cpx<T, AUX_NT>(d, row_off + lane_bytes, iu * (int)sizeof(cpx<T>));
+    }
+    __device__ __forceinline__ RawPair fetch_last_d(rsrc_t d, int row_off) const  // input[m]: the same address for a transform's lanes
+    {
+        return buf_load_cpx<T, AUX_NT>(d, row_off, m * (int)sizeof(cpx<T>));
+    }
+    // cur[u] = scratch[k] for this thread's R values; raw[0..R-1] = input[tau + tpt*u], raw[R] = input[m]
+    template <int R, int TPT, class InvAt>
+    __device__ __forceinline__ void finish_pairs(const RawPair *raw, const int tau, cpx<T> *cur, const InvAt inv_at) const
+    {
+        static_assert(sizeof(T) == 4, "pairing by ds_bpermute is written for c32");
+        const int lane = (int)(threadIdx.x & 63);
+        const int partner = ((lane & ~(TPT - 1)) | ((TPT - tau) & (TPT - 1))) << 2;  // byte address of the source lane
+        const bool self = tau == 0;
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const cpx<T> src = raw[R - 1 - u];
+            cpx<T> rb;
+            rb.re = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(partner, __builtin_bit_cast(int, src.re)));
+            rb.im = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(partner, __builtin_bit_cast(int, src.im)));
+            const cpx<T> own = raw[R - u];  // lane 0: m - k = tpt*(R-u) is its own register R-u (u = 0: input[m])
+            if (self) rb = own;
+            // k == 0 only for (tau == 0, u == 0): pre()'s select on k is compile-time false for u > 0
+            cur[u] = pre(u == 0 ? tau : 1, raw[u], rb, inv_at(u));
+        }
+    }
     using Inv = cpx<T>;            // W[k] of build_twiddle_table(m)
     const cpx<T> *__restrict__ in;  // batch rows of m+1 complex
     cpx<T> *__restrict__ out;       // batch rows of m complex == 2*m reals

@@ -250,9 +250,18 @@ template <> struct PersistCfg<10, StftMagIO> : PersistCfgBase<StftMagIO> {
     static constexpr int BLOCK = 256, MINW = 2, WG_PER_CU = 2, DEPTH = KOFFT_STFT10_DEPTH;
 };
 // irfft prefetches two row elements per output: the last pass reads its twiddles from LDS to stay inside 256 VGPRs
+#ifndef KOFFT_IRFFT10_WG
+#define KOFFT_IRFFT10_WG 2
+#endif
+#ifndef KOFFT_IRFFT10_DEPTH
+#define KOFFT_IRFFT10_DEPTH 1
+#endif
+#ifndef KOFFT_IRFFT10_TWLDS
+#define KOFFT_IRFFT10_TWLDS true
+#endif
 template <> struct PersistCfg<10, IrfftIO<float>> {
-    static constexpr int BLOCK = 256, NBUF = 1, RL = 4, MINW = 2, WG_PER_CU = 2;
-    static constexpr bool kInvInLds = true, kTwLastInLds = true;
+    static constexpr int BLOCK = 256, NBUF = 1, RL = 4, MINW = KOFFT_IRFFT10_WG, WG_PER_CU = KOFFT_IRFFT10_WG, DEPTH = KOFFT_IRFFT10_DEPTH;
+    static constexpr bool kInvInLds = true, kTwLastInLds = KOFFT_IRFFT10_TWLDS;
 };
 template <> struct PersistCfg<11, IrfftIO<float>> {
     static constexpr int BLOCK = 256, NBUF = 1, RL = 4, MINW = 2, WG_PER_CU = 2;
