@@ -257,6 +257,30 @@ int get_bluestein(kofft_hip_ctx *ctx, size_t n, size_t m, const cpx<T> **chirp, 
     return KOFFT_OK;
 }
 
+// The whole arm in one launch (bluestein_wg_kernel): m = 2^5 .. 2^12 (c32) / 2^10 (c64).
+template <typename T, int L, bool INVERSE>
+int launch_bluestein_wg(kofft_hip_ctx *ctx, const cpx<T> *in, cpx<T> *out, const cpx<T> *chirp, const cpx<T> *bfft, const cpx<T> *tw,
+                        size_t n, size_t batch, T scale_m, T scale_n)
+{
+    constexpr int RL = rl_for(L);
+    constexpr int BLOCK = block_for(L);
+    constexpr int TPT = (1 << L) >> RL;
+    constexpr int XPB = BLOCK / TPT;
+    constexpr size_t lds = lds_wg_bytes<T, false, false, XPB>(1 << L);
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = bluestein_wg_kernel<T, L, RL, BLOCK, INVERSE>;
+    if (lds > 64 * 1024) {
+        static std::atomic<unsigned long long> attr_done{0};
+        const int arc = set_dyn_lds_once(ctx, attr_done, reinterpret_cast<const void *>(kern), lds);
+        if (arc) return arc;
+    }
+    const size_t blocks = (batch + XPB - 1) / XPB;
+    if (blocks > 0x7fffffffULL) return KOFFT_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BLOCK), lds, ctx->stream, in, out, chirp, bfft, tw, (int)n, scale_m, scale_n, batch);
+    KOFFT_HIP_TRY(ctx, hipGetLastError());
+    return KOFFT_OK;
+}
+
 template <typename T, bool INVERSE>
 int fft_bluestein_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t batch)
 {
@@ -265,6 +289,33 @@ int fft_bluestein_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, siz
     const cpx<T> *chirp = nullptr, *bfft = nullptr;
     int rc = get_bluestein<T>(ctx, n, m, &chirp, &bfft);
     if (rc) return rc;
+    if (ctx->blue_fused && ctx->blue_one_kernel) {
+        const int L = ilog2(m);
+        // measured (tools/bench_bluestein.py): one launch wins 15..50 % up to m = 4096 (c32) / 1024 (c64); beyond, the kernel
+        // needs more than 256 registers (one wavefront per SIMD) and the two launches are faster (n = 4095: 1.09 vs 1.70 ms)
+        if (L >= 5 && L <= (sizeof(T) == 4 ? 12 : 10)) {
+            const cpx<T> *tw = nullptr;
+            rc = get_table<T>(ctx, Kind<T>::tw, m, &tw);
+            if (rc) return rc;
+            const T sm = (T)1 / (T)(float)m, sn = (T)1 / (T)(float)n;
+            const cpx<T> *src = reinterpret_cast<const cpx<T> *>(d_in);
+            cpx<T> *dst = reinterpret_cast<cpx<T> *>(d_out);
+            switch (L) {
+#define KOFFT_CASE(LL) \
+    case LL: return launch_bluestein_wg<T, LL, INVERSE>(ctx, src, dst, chirp, bfft, tw, n, batch, sm, sn);
+                KOFFT_CASE(5)
+                KOFFT_CASE(6)
+                KOFFT_CASE(7)
+                KOFFT_CASE(8)
+                KOFFT_CASE(9)
+                KOFFT_CASE(10)
+                KOFFT_CASE(11)
+                KOFFT_CASE(12)
+#undef KOFFT_CASE
+            default: break;
+            }
+        }
+    }
     const size_t xf_bytes = m * sizeof(cpx<T>);
     size_t chunk = (size_t(512) << 20) / xf_bytes;
     if (chunk < 1) chunk = 1;

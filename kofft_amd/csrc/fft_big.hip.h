@@ -681,6 +681,94 @@ struct BlueSecondIO : PlainTw {  // store: conj, * 1/m (ifft's way out), * chirp
     }
 };
 
+// ---- the whole Bluestein arm in ONE kernel (m = 2^L up to the single-workgroup sizes) -------------------------------------
+// fft.rs:1088-1132 for one transform per TPT threads: a = x * chirp (zero-padded to m), fft(a), a *= fft(b), ifft(a) = conj,
+// fft, conj, * 1/m, out = a * chirp -- the m-point intermediate never leaves the CU (registers + the LDS exchange buffer), so
+// HBM sees n points in and n points out instead of n + 3m + n (BlueFirstIO / BlueSecondIO: two launches through a scratch).
+// Between the two transforms the values go through the exchange buffer once more: the first transform leaves element
+// out_index(tau, u) in register u, the second one wants in_index(tau, u).  Same butterflies, same table entries, same
+// pointwise expressions as the two policies above: bit-identical results.
+template <typename T, int L, int RL, int BLOCK, bool INVERSE>
+__global__ __launch_bounds__(BLOCK) void bluestein_wg_kernel(const cpx<T> *__restrict__ in, cpx<T> *__restrict__ out,
+                                                             const cpx<T> *__restrict__ chirp, const cpx<T> *__restrict__ bfft,
+                                                             const cpx<T> *__restrict__ tw, const int n, const T scale_m, const T scale_n,
+                                                             const size_t batch)
+{
+    constexpr int N = 1 << L;
+    constexpr int R = 1 << RL;
+    constexpr int TPT = N / R;
+    static_assert(TPT >= 1 && BLOCK % TPT == 0, "bad geometry");
+    constexpr int XPB = BLOCK / TPT;
+    constexpr int NP = (L + RL - 1) / RL;
+    static_assert(NP >= 2 && NP <= 5, "pass count");
+    using G0 = WgGeom<L, RL, 0>;
+    using GL = WgGeom<L, RL, NP - 1>;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x;
+    const int tau = tid % TPT, slot = tid / TPT;
+    const size_t xf = (size_t)blockIdx.x * XPB + slot;
+    const bool active = xf < batch;
+    const PlainTw io{};
+
+    cpx<T> v[R];
+    if (active) {  // one branch around all loads
+        const cpx<T> *row = in + xf * (size_t)n;
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const int i = G0::in_index(tau, u);
+            const int ic = i < n ? i : n - 1;  // branch-free: clamp the address, select the value
+            cpx<T> x = ld_stream(row + ic);
+            if (INVERSE) x.im = -x.im;  // ifft: conj on the way in (fft.rs:1163-1165)
+            const cpx<T> a = cmul(x, chirp[ic]);
+            v[u] = i < n ? a : mk<T>(T(0), T(0));
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < R; ++u) v[u] = mk<T>(T(0), T(0));
+    }
+    auto transform = [&]() {
+        wg_compute<T, L, RL, 0>(v, io, tw, xf, tau);
+        if constexpr (NP > 1) { wg_exchange<T, L, RL, 0, false, false, XPB>(v, smem_raw, tau, slot); wg_compute<T, L, RL, 1>(v, io, tw, xf, tau); }
+        if constexpr (NP > 2) { wg_exchange<T, L, RL, 1, false, false, XPB>(v, smem_raw, tau, slot); wg_compute<T, L, RL, 2>(v, io, tw, xf, tau); }
+        if constexpr (NP > 3) { wg_exchange<T, L, RL, 2, false, false, XPB>(v, smem_raw, tau, slot); wg_compute<T, L, RL, 3>(v, io, tw, xf, tau); }
+        if constexpr (NP > 4) { wg_exchange<T, L, RL, 3, false, false, XPB>(v, smem_raw, tau, slot); wg_compute<T, L, RL, 4>(v, io, tw, xf, tau); }
+    };
+    transform();
+    // a *= fft(b) (fft.rs:1119-1121), then ifft's conj on the way in; natural order -> the first pass's register layout
+    cpx<T> *buf = reinterpret_cast<cpx<T> *>(smem_raw) + (size_t)slot * lds_elems(N);
+    __syncthreads();  // the last gathers of the first transform are done
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+        const int o = GL::out_index(tau, u);
+        cpx<T> w = cmul(v[u], bfft[o]);
+        w.im = -w.im;
+        buf[lds_pad(o)] = w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < R; ++u) v[u] = buf[lds_pad(G0::in_index(tau, u))];
+    __syncthreads();  // ... before the second transform's first scatter
+    transform();
+    if (active) {
+        cpx<T> *orow = out + xf * (size_t)n;
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const int o = GL::out_index(tau, u);
+            if (o < n) {
+                cpx<T> a = v[u];
+                a.im = -a.im;  // ifft: conj, * 1/m (fft.rs:1168-1172)
+                a = mk<T>(a.re * scale_m, a.im * scale_m);
+                cpx<T> r = cmul(a, chirp[o]);
+                if (INVERSE) {
+                    const T im = -r.im;
+                    r = mk<T>(r.re * scale_n, im * scale_n);
+                }
+                st_stream(orow + o, r);
+            }
+        }
+    }
+}
+
 template <typename T, bool INVERSE>
 __global__ __launch_bounds__(256) void bluestein_pre_kernel(const cpx<T> *__restrict__ in, cpx<T> *__restrict__ a,
                                                             const cpx<T> *__restrict__ chirp, const size_t n, const size_t m,

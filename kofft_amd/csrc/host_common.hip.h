@@ -42,6 +42,7 @@ struct kofft_hip_ctx {
     bool big_rows_resident = true;  // KOFFT_HIP_BIG_ROWS_RESIDENT=0: last factor on the generic tile kernel (A/B measurements)
     int big_mid_nt = -1;       // KOFFT_HIP_BIG_MID_NT=0/1: force plain / streaming loads of the intermediate (default: by chunk size)
     bool blue_fused = true;    // KOFFT_HIP_BLUESTEIN_FUSED=0: pointwise steps as separate kernels at every size
+    bool blue_one_kernel = true;  // KOFFT_HIP_BLUESTEIN_ONE=0: two launches through a scratch even where one workgroup holds m points
     bool nd_transpose = true;  // KOFFT_HIP_ND_TRANSPOSE=0: long strided axes through the strided kernel
     int nd_transpose_min = 4096;  // KOFFT_HIP_ND_TRANSPOSE_MIN: shortest axis that takes the transpose route (measured: 1024 loses, 2048 ties)
     bool zero_copy = true;     // KOFFT_HIP_ZERO_COPY=0: small host calls through staged copies like large ones

@@ -660,6 +660,33 @@ def test_fft_non_power_of_two_f64(fft64, oracle, n):
     assert_parity(y, oracle.fft(x), f"bluestein fft c64 n={n}", REL_TOL_F64)
 
 
+@pytest.mark.parametrize("one_kernel", ["1", "0"])
+def test_bluestein_one_launch_and_two_launch_routes(oracle, one_kernel, monkeypatch):
+    """m = 32 ... 4096 (c32) / 1024 (c64) run the whole arm in one launch (bluestein_wg_kernel), larger m and
+    KOFFT_HIP_BLUESTEIN_ONE=0 the two fused launches through a scratch: both must be the oracle's bytes, forward and
+    inverse, at the m boundaries of either route (n = 17 -> m = 64, 2048 -> 4096, 2049 -> 8192, ...)."""
+    import kofft_amd
+
+    monkeypatch.setenv("KOFFT_HIP_BLUESTEIN_ONE", one_kernel)  # read when the context is created
+    f32, f64 = kofft_amd.HipFftImpl(np.float32), kofft_amd.HipFftImpl(np.float64)
+    for n in (9, 17, 33, 100, 255, 500, 513, 1025, 2047, 2049, 4097):
+        x = rand_c(seeded(2100 + n), (5, n))
+        y = x.copy()
+        f32.fft_batch(y)
+        want = oracle.fft(x)
+        assert_parity(y, want, f"bluestein route {one_kernel} fft c32 n={n}", REL_TOL_F32)
+        f32.fft_batch(y, inverse=True)
+        assert_parity(y, oracle.ifft(want), f"bluestein route {one_kernel} ifft c32 n={n}", REL_TOL_F32)
+    for n in (9, 33, 100, 257, 511, 513, 1030):
+        x = rand_c(seeded(2200 + n), (3, n), np.complex128)
+        y = x.copy()
+        f64.fft_batch(y)
+        want = oracle.fft(x)
+        assert_parity(y, want, f"bluestein route {one_kernel} fft c64 n={n}", REL_TOL_F64)
+        f64.fft_batch(y, inverse=True)
+        assert_parity(y, oracle.ifft(want), f"bluestein route {one_kernel} ifft c64 n={n}", REL_TOL_F64)
+
+
 def test_bluestein_reference_tests(fft32, fft64, oracle):
     # tests/bluestein.rs:32-66: n = 15 against the naive f32 DFT within 1e-3
     n = 15
