@@ -223,6 +223,68 @@ def cpu_baseline_fft4096(target_seconds: float):
 
 
 # ---------------------------------------------------------------------------------------------------
+# the reference's OWN published benchmark: one transform per call (benchmarks/README.md)
+# ---------------------------------------------------------------------------------------------------
+REFERENCE_PUBLISHED_US = {  # kofft single-thread, Xeon 8370C, host memory, f32 (benchmarks/README.md lines cited in BASELINE.md)
+    "c32_1024": 81.07, "c32_4096": 1046.0, "c32_1048576": 59270.0, "rfft_1024": 60.1, "rfft_2048": 97.7, "rfft_1048576": 66950.0,
+}
+
+
+def reference_single_transform(fft32, stream, budget_s: float = 0.25):
+    """Per-call time of ONE transform, the unit the reference publishes.  `host_us`: the trait method on a host array
+    (upload, kernel, download, synchronise -- what `fft.fft(&mut buf)` costs a drop-in caller); `device_us`: the same
+    transform on device-resident data (HIP events over back-to-back calls on the bench stream)."""
+    import numpy as np
+    import torch
+
+    rng = np.random.default_rng(7)
+    out = {}
+    for key, ref_us in REFERENCE_PUBLISHED_US.items():
+        kind, n = key.split("_")[0], int(key.split("_")[1])
+        if kind == "c32":
+            x = (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(np.complex64)
+            d = torch.from_numpy(x.view(np.float32)).to("cuda")
+            host = lambda: fft32.fft(x)  # noqa: E731  (in place, like the trait method; values may grow, timing does not care)
+            devc = lambda: fft32.fft_dev(d.data_ptr(), n, 1)  # noqa: E731
+        else:
+            xr = rng.uniform(-1, 1, n).astype(np.float32)
+            yo = np.zeros(n // 2 + 1, np.complex64)
+            scratch = np.zeros(n // 2, np.complex64)
+            di = torch.from_numpy(xr).to("cuda")
+            do = torch.zeros(2 * (n // 2 + 1), dtype=torch.float32, device="cuda")
+            host = lambda: fft32.rfft_with_scratch(xr, yo, scratch)  # noqa: E731
+            devc = lambda: fft32.rfft_dev(di.data_ptr(), do.data_ptr(), None, n, 1)  # noqa: E731
+        x0 = x.copy() if kind == "c32" else None
+        for _ in range(3):
+            host()
+        reps, busy = 0, 0.0
+        while busy < budget_s and reps < 2000:
+            if x0 is not None:
+                np.copyto(x, x0)  # untimed: repeated in-place transforms would overflow
+            t0 = time.perf_counter()
+            host()
+            busy += time.perf_counter() - t0
+            reps += 1
+        host_us = busy / reps * 1e6
+        for _ in range(3):
+            devc()
+        torch.cuda.synchronize()
+        k = 50 if n > 65536 else 200
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(k):
+            devc()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        dev_us = e0.elapsed_time(e1) / k * 1e3
+        out[key] = {"host_us": round(host_us, 2), "device_us": round(dev_us, 2), "reference_published_us": ref_us,
+                    "speedup_host": round(ref_us / host_us, 1)}
+    out["note"] = ("one transform per call, f32; reference_published_us = kofft single-thread on a Xeon 8370C (its benchmarks/README.md, "
+                   "other hardware, first criterion sample); host_us includes PCIe both ways and the synchronisation")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
 # one rank
 # ---------------------------------------------------------------------------------------------------
 class Workload:
@@ -525,6 +587,11 @@ def run_rank(args) -> None:
             out["allgather"] = allgather
         if extras:
             out["workloads"] = extras
+        if extras_on and world == 1:
+            try:
+                out["reference_single_transform"] = reference_single_transform(fft32, stream)
+            except Exception as e:  # informational: never at the cost of the line
+                out["reference_single_transform"] = {"error": f"{type(e).__name__}: {e}"}
         if args.workload == "fft4096" and not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline_fft4096(args.cpu_seconds)
         elif args.workload == "fft4096" and world > 1:
