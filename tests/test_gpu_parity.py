@@ -981,6 +981,21 @@ def test_host_pointer_pipeline_large_batches(fft32, fft64, oracle):
     assert_parity(yd, oracle.fft(xd), "pipelined host fft c64", REL_TOL_F64)
 
 
+def test_host_pointer_stft_large(fft32, oracle):
+    """stft() from host memory with >= 128 MiB of spectra (one upload, one launch, one download: chunking the download
+    behind the kernels measured slower) -- frames past the end of the signal included."""
+    import kofft_amd as K
+
+    rng = seeded(9600)
+    hop, win_len = 256, 1024
+    sig = rng.uniform(-1, 1, 16_500 * hop + 77).astype(np.float32)
+    win = oracle.hann(win_len)
+    frames = -(-sig.size // hop) + 5  # five frames wholly past the end: zero spectra (stft.rs:95-99)
+    got = fft32.stft_into(sig, win, hop, frames)
+    assert got.nbytes >= 128 << 20
+    assert_parity(got, oracle.stft(sig, win, hop, frames), "large host stft", REL_TOL_F32)
+
+
 @pytest.mark.parametrize("depth,rows,cols", [(1, 2048, 16), (1, 1024, 64), (1, 4096, 128), (1024, 2, 8), (4, 1024, 32), (2, 2048, 4),
                                              (1, 4096, 512), (2, 4096, 256), (4096, 2, 256)])
 def test_ndfft_long_strided_axes(fft32, fft64, oracle, depth, rows, cols):
