@@ -48,7 +48,10 @@ int launch_rows_persist(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size
     constexpr int RL = rl_for(LS);
     // (c32 rows of 2^10 points: 16-row tiles need 1024 threads at 128 registers and spill 30 of them -- measured slower
     // than 8-row tiles at 512 threads, 2^19: 0.244 vs 0.282 of the roofline)
-    constexpr int BLOCK = big_block<T, IO, LS, (sizeof(T) == 4 ? 80 : 128) * 1024>();
+#ifndef KOFFT_ROWS_C32_CAP_KB
+#define KOFFT_ROWS_C32_CAP_KB 80
+#endif
+    constexpr int BLOCK = big_block<T, IO, LS, (sizeof(T) == 4 ? KOFFT_ROWS_C32_CAP_KB : 128) * 1024>();
     constexpr int TPT = (1 << LS) >> RL;
     constexpr int XPB = BLOCK / TPT;
     constexpr size_t lds = TileExchange<T, LS, RL, XPB, IO::kSplitLds>::bytes + (size_t)rows_tw_entries<LS, RL>() * XPB * sizeof(cpx<T>);

@@ -199,11 +199,36 @@ __device__ __forceinline__ void wg_exchange_b128(cpx<T> *v, char *base, const in
     constexpr int R = 1 << RL;
     cpx<T> *buf = reinterpret_cast<cpx<T> *>(base);
     if (P > 0) __syncthreads();  // every gather of the previous exchange is done
+    // Every access below is "one per-thread base + a compile-time constant" (an immediate offset).  Written as
+    // lds_cell_b128(index(tau, u), slot) the XOR hides that from the compiler, which then keeps one address register PER
+    // REGISTER u alive across the tile loop (32 VGPRs for the two gathers) -- in the last-factor kernel, next to the 48
+    // registers of resident twiddles, three of them spilled and every reload's s_waitcnt vmcnt(0) also waited for the
+    // next tile's prefetch (found in the ISA; round 2).
+    static_assert(Gs::TPT == 64 && (P == 0 || P == 1), "2^10 points, 16 per thread, three passes");
+    {   // scatter: index = (bits >= 6 from u) | tau, and bit 2 of the index is bit 2 of tau
+        cpx<T> *p = buf + (((tau ^ ((tau >> 2) & 1)) << 3) + slot);
 #pragma unroll
-    for (int u = 0; u < R; ++u) buf[lds_cell_b128(Gs::out_index(tau, u), slot)] = v[u];
+        for (int u = 0; u < R; ++u) p[Gs::out_index(0, u) << 3] = v[u];
+    }
     __syncthreads();
+    if constexpr (P == 0) {
+        // gather of the middle pass: index = [tau >> 2][u][tau & 3]; bit 2 of the index is bit 0 of u, the XOR flips bit 0
+        // (a tau bit): one base for even u, one for odd u
+        const int it = ((tau >> 2) << 6) | (tau & 3);
+        const cpx<T> *pe = buf + ((it << 3) + slot), *po = buf + (((it ^ 1) << 3) + slot);
 #pragma unroll
-    for (int u = 0; u < R; ++u) v[u] = buf[lds_cell_b128(Gg::in_index(tau, u), slot)];
+        for (int u = 0; u < R; ++u) v[u] = ((u & 1) ? po : pe)[u << 5];
+    } else {
+        // gather of the last pass: u = 4g + c, index = [tau + 64g][c]; bit 2 of the index is bit 0 of tau, the XOR turns c
+        // into c ^ t0 = c + t0 (c even) or c - t0 (c odd): one base for even c, one for odd c
+        const int t0 = tau & 1;
+        const cpx<T> *pe = buf + ((((tau << 2) + t0) << 3) + slot), *po = buf + ((((tau << 2) - t0) << 3) + slot);
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const int g = u >> 2, c = u & 3;
+            v[u] = ((c & 1) ? po : pe)[(((64 * g) << 2) + c) << 3];
+        }
+    }
 }
 
 // which exchange a persistent factor kernel uses, and how many bytes it needs

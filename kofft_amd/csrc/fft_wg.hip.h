@@ -534,8 +534,57 @@ __device__ __forceinline__ void wg_exchange(cpx<T> *v, char *base, const int tau
     using Gg = WgGeom<L, RL, P + 1>;
     constexpr int N = 1 << L;
     constexpr int R = 1 << RL;
-    auto cell = [&](int idx) -> int { return SM ? lds_cell_sm<XPB>(idx, slot) : slot * lds_elems(N) + lds_pad(idx); };
     if (P > 0) __syncthreads();  // every gather of the previous exchange is done
+    if constexpr (SM) {
+        // Slot-minor cells as "one of at most four per-thread bases + a compile-time constant".  index(tau, u) is the OR of
+        // two disjoint bit fields, T = index(tau, 0) and U = index(0, u), and lds_cell_sm is XOR-linear in the index bits:
+        //   cell = [(T >> 2)*4X + 2*slot] + (U >> 2)*4X + 2X*(t13 ^ u13) + (t02 ^ u02),   t13 = T1 ^ T3, t02 = T0 ^ T2, same for U,
+        // with u13, u02 constants of the register number.  Left as lds_cell_sm(index(tau, u), slot) the compiler cannot see
+        // this and keeps one address register per register u alive across a persistent kernel's tile loop (2 x 16 VGPRs).
+        auto bases = [&](const int ti, int (&b)[2][2]) {  // ti = index(tau, 0)
+            const int t13 = ((ti >> 1) ^ (ti >> 3)) & 1, t02 = (ti ^ (ti >> 2)) & 1;
+            const int core = (ti >> 2) * (4 * XPB) + slot * 2;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[i][j] = core + ((t13 ^ i) * (2 * XPB)) + (t02 ^ j);
+        };
+        int bs[2][2], bg[2][2];
+        bases(Gs::out_index(tau, 0), bs);
+        bases(Gg::in_index(tau, 0), bg);
+        auto cs = [&](int u) -> int {
+            const int U = Gs::out_index(0, u);
+            return bs[((U >> 1) ^ (U >> 3)) & 1][(U ^ (U >> 2)) & 1] + (U >> 2) * (4 * XPB);
+        };
+        auto cg = [&](int u) -> int {
+            const int U = Gg::in_index(0, u);
+            return bg[((U >> 1) ^ (U >> 3)) & 1][(U ^ (U >> 2)) & 1] + (U >> 2) * (4 * XPB);
+        };
+        if constexpr (!SPLIT) {
+            cpx<T> *buf = reinterpret_cast<cpx<T> *>(base);
+#pragma unroll
+            for (int u = 0; u < R; ++u) buf[cs(u)] = v[u];
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < R; ++u) v[u] = buf[cg(u)];
+        } else {
+            T *buf = reinterpret_cast<T *>(base);
+            T re[R];
+#pragma unroll
+            for (int u = 0; u < R; ++u) buf[cs(u)] = v[u].re;
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < R; ++u) re[u] = buf[cg(u)];
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < R; ++u) buf[cs(u)] = v[u].im;
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < R; ++u) v[u] = mk<T>(re[u], buf[cg(u)]);
+        }
+        return;
+    }
+    auto cell = [&](int idx) -> int { return slot * lds_elems(N) + lds_pad(idx); };
     if constexpr (!SPLIT) {
         cpx<T> *buf = reinterpret_cast<cpx<T> *>(base);
 #pragma unroll
