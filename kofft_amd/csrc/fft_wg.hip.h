@@ -525,6 +525,28 @@ struct WgGeom {
     }
 };
 
+// ---- slot-minor cells for tiles of 8 or 16 adjacent units: conflict-free by construction (round 2) -------------------------
+// Banking is per instruction (MI355X_MICROARCH.md, LDS): ds_write_b64 serves 4 groups of 16 contiguous lanes on 32 dword
+// banks, ds_read_b64 2 groups of 32 lanes on 64.  With lanes = [thread tau][slot], a write group is 2 (XPB = 8) or 1 (16)
+// consecutive threads x all slots and a read group 4 or 2 consecutive threads x all slots.  Cells
+//     cell(idx, slot) = g(idx) * XPB + slot,      g(idx) = idx with bit 0 ^= parity(idx & M0) and (XPB = 8) bit 1 ^= parity(idx & M1),
+// keep a thread's slots contiguous, so a group is conflict-free iff its threads' g(idx) differ in the low one / two bits.
+// The threads of a group differ in thread bits 0 (and 1); M0 / M1 collect the index bit each gather shape of this (L, RL)
+// puts thread bit 0 / 1 at (scatters keep them at index bits 0 / 1).  Simulated for every pass of L = 5 .. 10 under the
+// documented grouping: no conflict; measured on the c32 first factor (16 columns, where the earlier two-element-grain
+// formula -- built for 8 -- put slots s and s + 8 of a write group on one bank pair): SQ_LDS_BANK_CONFLICT 1.5e7 -> 0.
+template <int L, int RL>
+__host__ __device__ constexpr int sm_thread_bit_mask(int which)
+{
+    constexpr int NP = (L + RL - 1) / RL;
+    int m = 0;
+    if (NP > 1) m |= WgGeom<L, RL, (NP > 1 ? 1 : 0)>::in_index(1 << which, 0);
+    if (NP > 2) m |= WgGeom<L, RL, (NP > 2 ? 2 : 0)>::in_index(1 << which, 0);
+    if (NP > 3) m |= WgGeom<L, RL, (NP > 3 ? 3 : 0)>::in_index(1 << which, 0);
+    if (NP > 4) m |= WgGeom<L, RL, (NP > 4 ? 4 : 0)>::in_index(1 << which, 0);
+    return m | (1 << which);
+}
+
 // LDS exchange between pass P and pass P+1: scatter pass P's outputs, gather pass P+1's inputs.
 // `base` is the workgroup's exchange region; SM selects the slot-minor interleaved layout.
 template <typename T, int L, int RL, int P, bool SPLIT, bool SM, int XPB>
@@ -541,25 +563,40 @@ __device__ __forceinline__ void wg_exchange(cpx<T> *v, char *base, const int tau
         //   cell = [(T >> 2)*4X + 2*slot] + (U >> 2)*4X + 2X*(t13 ^ u13) + (t02 ^ u02),   t13 = T1 ^ T3, t02 = T0 ^ T2, same for U,
         // with u13, u02 constants of the register number.  Left as lds_cell_sm(index(tau, u), slot) the compiler cannot see
         // this and keeps one address register per register u alive across a persistent kernel's tile loop (2 x 16 VGPRs).
+        // Tiles of 8 / 16 units: the conflict-free cells g(idx) * XPB + slot above; g is XOR-linear too:
+        //   cell = [(T & ~LM) + (low(T) ^ low(U))] * XPB + slot + (U & ~LM) * XPB,   LM = the low one / two index bits g alters.
+        constexpr bool UNI = (XPB == 8 || XPB == 16) && (N >> RL) >= 4;
+        constexpr int M0 = sm_thread_bit_mask<L, RL>(0), M1 = sm_thread_bit_mask<L, RL>(1), LM = XPB == 8 ? 3 : 1;
+        auto low = [&](const int x) -> int {
+            return (__builtin_popcount(x & M0) & 1) | (XPB == 8 ? (__builtin_popcount(x & M1) & 1) << 1 : 0);
+        };
         auto bases = [&](const int ti, int (&b)[2][2]) {  // ti = index(tau, 0)
-            const int t13 = ((ti >> 1) ^ (ti >> 3)) & 1, t02 = (ti ^ (ti >> 2)) & 1;
-            const int core = (ti >> 2) * (4 * XPB) + slot * 2;
+            if constexpr (UNI) {
+                const int lt = low(ti), core = (ti & ~LM) * XPB + slot;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                for (int j = 0; j <= LM; ++j) b[j >> 1][j & 1] = core + ((lt ^ j) * XPB);
+            } else {
+                const int t13 = ((ti >> 1) ^ (ti >> 3)) & 1, t02 = (ti ^ (ti >> 2)) & 1;
+                const int core = (ti >> 2) * (4 * XPB) + slot * 2;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) b[i][j] = core + ((t13 ^ i) * (2 * XPB)) + (t02 ^ j);
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) b[i][j] = core + ((t13 ^ i) * (2 * XPB)) + (t02 ^ j);
+            }
         };
         int bs[2][2], bg[2][2];
         bases(Gs::out_index(tau, 0), bs);
         bases(Gg::in_index(tau, 0), bg);
-        auto cs = [&](int u) -> int {
-            const int U = Gs::out_index(0, u);
-            return bs[((U >> 1) ^ (U >> 3)) & 1][(U ^ (U >> 2)) & 1] + (U >> 2) * (4 * XPB);
+        auto pick = [&](const int (&b)[2][2], const int U) -> int {  // U = index(0, u): a compile-time constant
+            if constexpr (UNI) {
+                const int lu = low(U);
+                return b[lu >> 1][lu & 1] + (U & ~LM) * XPB;
+            } else {
+                return b[((U >> 1) ^ (U >> 3)) & 1][(U ^ (U >> 2)) & 1] + (U >> 2) * (4 * XPB);
+            }
         };
-        auto cg = [&](int u) -> int {
-            const int U = Gg::in_index(0, u);
-            return bg[((U >> 1) ^ (U >> 3)) & 1][(U ^ (U >> 2)) & 1] + (U >> 2) * (4 * XPB);
-        };
+        auto cs = [&](int u) -> int { return pick(bs, Gs::out_index(0, u)); };
+        auto cg = [&](int u) -> int { return pick(bg, Gg::in_index(0, u)); };
         if constexpr (!SPLIT) {
             cpx<T> *buf = reinterpret_cast<cpx<T> *>(base);
 #pragma unroll
