@@ -127,7 +127,12 @@ int stft_mag_dev(kofft_hip_ctx *ctx, const float *d_samples, size_t len, size_t 
             kofft_tables::hann_f32(win_len, w.data());
             void *d = nullptr;
             KOFFT_HIP_TRY(ctx, hipMalloc(&d, win_len * sizeof(float)));
-            KOFFT_HIP_TRY(ctx, hipMemcpy(d, w.data(), win_len * sizeof(float), hipMemcpyHostToDevice));
+            const hipError_t ce = hipMemcpy(d, w.data(), win_len * sizeof(float), hipMemcpyHostToDevice);
+            if (ce != hipSuccess) {  // nothing is cached, nothing is left behind
+                (void)hipFree(d);
+                ctx->last_error = std::string("stft_magnitudes window upload: ") + hipGetErrorString(ce);
+                return KOFFT_ERR_HIP;
+            }
             ctx->tables[key] = d;
             d_win = static_cast<const float *>(d);
         } else {

@@ -19,6 +19,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -39,10 +40,16 @@ struct Rccl {
 };
 constexpr int kNcclFloat32 = 7;  // ncclFloat32 (rccl.h: ncclDataType_t)
 
+void rccl_bind(Rccl &r);
 Rccl &rccl()
 {
     static Rccl r;
-    if (r.handle || !r.error.empty()) return r;
+    static std::once_flag once;  // the first gathers of two handles may come from two threads
+    std::call_once(once, [] { rccl_bind(r); });
+    return r;
+}
+void rccl_bind(Rccl &r)
+{
     const char *env = getenv("KOFFT_HIP_RCCL_LIB");
     // a copy that is already mapped (PyTorch's, or the application's) wins; otherwise the ROCm one
     const char *noload[] = {"librccl.so", "librccl.so.1"};
@@ -58,7 +65,7 @@ Rccl &rccl()
     if (!r.handle) {
         const char *e = dlerror();
         r.error = std::string("RCCL not found (set KOFFT_HIP_RCCL_LIB): ") + (e ? e : "?");
-        return r;
+        return;
     }
     auto sym = [&](const char *name) -> void * {
         void *p = dlsym(r.handle, name);
@@ -72,7 +79,6 @@ Rccl &rccl()
     r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
     if (!r.error.empty()) r.handle = nullptr;
-    return r;
 }
 
 struct DevBuf {
@@ -243,8 +249,32 @@ int kofft_hip_multi_last_timing(const kofft_hip_multi *m, float *compute_ms, flo
     return KOFFT_OK;
 }
 
+namespace {
+// A failure on one device must not return while the others still have copies in flight that read or write the CALLER's
+// host buffers: drain every stream first (errors of the drain itself are ignored, the first error is the one reported).
+void drain_all(kofft_hip_multi *m)
+{
+    for (int r = 0; r < m->ngpu; ++r) {
+        if (hipSetDevice(m->devices[r]) == hipSuccess && m->stream[r]) (void)hipStreamSynchronize(m->stream[r]);
+    }
+    (void)hipGetLastError();
+}
+int multi_stft_impl(kofft_hip_multi *m, const float *signal, size_t len, const float *window, size_t win_len, size_t hop, float *out,
+                    size_t frames, int allgather, float **d_out_per_gpu);
+int multi_fft_impl(kofft_hip_multi *m, float *data, size_t n, size_t batch, int inverse);
+}  // namespace
+
 int kofft_hip_multi_stft_f32(kofft_hip_multi *m, const float *signal, size_t len, const float *window, size_t win_len,
                              size_t hop, float *out, size_t frames, int allgather, float **d_out_per_gpu)
+{
+    const int rc = multi_stft_impl(m, signal, len, window, win_len, hop, out, frames, allgather, d_out_per_gpu);
+    if (rc != KOFFT_OK && m) drain_all(m);  // possibly with work of other devices already enqueued
+    return rc;
+}
+
+namespace {
+int multi_stft_impl(kofft_hip_multi *m, const float *signal, size_t len, const float *window, size_t win_len, size_t hop, float *out,
+                    size_t frames, int allgather, float **d_out_per_gpu)
 {
     // stft::stft's checks in its order (stft.rs:83-87), then the transform's (fft.rs:1056)
     if (hop == 0) return KOFFT_ERR_INVALID_HOP_SIZE;
@@ -338,6 +368,7 @@ int kofft_hip_multi_stft_f32(kofft_hip_multi *m, const float *signal, size_t len
     m->gather_ms = allgather ? gmax : 0.0f;
     return KOFFT_OK;
 }
+}  // namespace
 
 int kofft_hip_stft_f32_multi(int ngpu, const float *signal, size_t len, const float *window, size_t win_len, size_t hop,
                              float *out, size_t frames, int allgather)
@@ -358,6 +389,14 @@ int kofft_hip_stft_f32_multi(int ngpu, const float *signal, size_t len, const fl
 }
 
 int kofft_hip_multi_fft_c32(kofft_hip_multi *m, float *data, size_t n, size_t batch, int inverse)
+{
+    const int rc = multi_fft_impl(m, data, n, batch, inverse);
+    if (rc != KOFFT_OK && m) drain_all(m);
+    return rc;
+}
+
+namespace {
+int multi_fft_impl(kofft_hip_multi *m, float *data, size_t n, size_t batch, int inverse)
 {
     // fft::batch (fft.rs:2156-2175) with the batch split into G contiguous blocks: no exchange of any kind
     if (batch == 0) return KOFFT_OK;
@@ -387,5 +426,6 @@ int kofft_hip_multi_fft_c32(kofft_hip_multi *m, float *data, size_t n, size_t ba
     }
     return KOFFT_OK;
 }
+}  // namespace
 
 }  // extern "C"
