@@ -190,12 +190,35 @@ struct BigMidIO {
 //   thread's bit 0 -- the XOR makes both shapes differ where they must.  (Derived for L = 10, RL = 4 only.)
 __host__ __device__ constexpr int lds_cell_b128(int idx, int slot) { return ((idx ^ ((idx >> 2) & 1)) << 3) + slot; }
 
+// compile-time proof that the base + constant forms used in wg_exchange_b128 are lds_cell_b128(index(tau, u), slot)
+template <int P>
+constexpr bool b128_forms_match()
+{
+    using Gs = WgGeom<10, 4, P>;
+    using Gg = WgGeom<10, 4, P + 1>;
+    for (int tau = 0; tau < 64; ++tau)
+        for (int u = 0; u < 16; ++u) {
+            const int slot = (tau + u) & 7;
+            if ((((tau ^ ((tau >> 2) & 1)) << 3) + slot) + (Gs::out_index(0, u) << 3) != lds_cell_b128(Gs::out_index(tau, u), slot)) return false;
+            int g = 0;
+            if (P == 0) {
+                const int it = ((tau >> 2) << 6) | (tau & 3);
+                g = ((((u & 1) ? (it ^ 1) : it) << 3) + slot) + (u << 5);
+            } else {
+                const int t0 = tau & 1, gg = u >> 2, c = u & 3;
+                g = (((((c & 1) ? (tau << 2) - t0 : (tau << 2) + t0)) << 3) + slot) + ((((64 * gg) << 2) + c) << 3);
+            }
+            if (g != lds_cell_b128(Gg::in_index(tau, u), slot)) return false;
+        }
+    return true;
+}
+
 template <typename T, int L, int RL, int P, int XPB>
 __device__ __forceinline__ void wg_exchange_b128(cpx<T> *v, char *base, const int tau, const int slot)
 {
+    static_assert(b128_forms_match<P>(), "explicit-base addressing must equal lds_cell_b128(index(tau, u), slot)");
     static_assert(L == 10 && RL == 4 && XPB == 8 && sizeof(cpx<T>) == 16, "layout derived for 2^10-point c64 tiles of 8 units");
     using Gs = WgGeom<L, RL, P>;
-    using Gg = WgGeom<L, RL, P + 1>;
     constexpr int R = 1 << RL;
     cpx<T> *buf = reinterpret_cast<cpx<T> *>(base);
     if (P > 0) __syncthreads();  // every gather of the previous exchange is done

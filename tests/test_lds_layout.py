@@ -1,0 +1,100 @@
+"""The slot-minor LDS cells of the tile kernels (fft_wg.hip.h: wg_exchange, sm_thread_bit_mask) -- restated and checked on CPU.
+
+cell(idx, slot) = g(idx) * XPB + slot with g = idx, bit 0 ^= parity(idx & M0) and (XPB = 8) bit 1 ^= parity(idx & M1), M0 / M1 the
+index bits that carry thread bits 0 / 1 in the gather shapes of (L, RL).  Claims checked for every pass of L = 5 .. 10 and
+XPB = 8, 16: the cells are a bijection onto [0, XPB * 2^L), the "per-thread base + constant" form the kernel computes equals
+the definition, and no access conflicts under the per-instruction banking of MI355X_MICROARCH.md (ds_write_b64: groups of 16
+contiguous lanes on 32 dword banks; ds_read_b64: groups of 32 lanes on 64)."""
+import pytest
+
+
+def bitrev(x, b):
+    r = 0
+    for i in range(b):
+        r = (r << 1) | ((x >> i) & 1)
+    return r
+
+
+def rl_for(L):  # host_common.hip.h
+    return 2 if L in (5, 6) else 3 if L in (7, 9) else 4
+
+
+def par(x):
+    return bin(x).count("1") & 1
+
+
+def geometry(L, RL, P):  # WgGeom<L, RL, P>
+    R, N = 1 << RL, 1 << L
+    TPT, NP = N // R, (L + RL - 1) // RL
+    S0 = P * RL
+    Q = (L - RL * (NP - 1)) if P == NP - 1 else RL
+    JB = L - S0 - Q
+
+    def in_index(tau, u):
+        g, c = u >> Q, u & ((1 << Q) - 1)
+        m = tau + g * TPT
+        return ((m >> JB) << (L - S0)) | (c << JB) | (m & ((1 << JB) - 1))
+
+    def out_index(tau, u):
+        g, c = u >> Q, u & ((1 << Q) - 1)
+        return (bitrev(c, Q) << (L - Q)) | (tau + g * TPT)
+
+    return in_index, out_index
+
+
+def extra_cycles(cells, group, banks):
+    extra = 0
+    for g0 in range(0, len(cells), group):
+        per = {}
+        for c in set(cells[g0:g0 + group]):  # identical addresses broadcast
+            for d in (2 * c, 2 * c + 1):     # an 8-byte cell covers two dword banks
+                per.setdefault(d % banks, set()).add(d)
+        extra += max(len(v) for v in per.values()) - 1
+    return extra
+
+
+@pytest.mark.parametrize("xpb", [8, 16])
+@pytest.mark.parametrize("L", [5, 6, 7, 8, 9, 10])
+def test_slot_minor_cells_bijective_decomposable_conflict_free(L, xpb):
+    RL = rl_for(L)
+    R, N = 1 << RL, 1 << L
+    TPT, NP = N // R, (L + RL - 1) // RL
+    block = xpb * TPT
+    if TPT < 4 or block > 1024:
+        pytest.skip("geometry not used")
+    m0, m1 = 1, 2
+    for P in range(1, NP):
+        inn, _ = geometry(L, RL, P)
+        m0 |= inn(1, 0)
+        m1 |= inn(2, 0)
+    lm = 3 if xpb == 8 else 1
+    low = lambda x: par(x & m0) | ((par(x & m1) << 1) if xpb == 8 else 0)  # noqa: E731
+    cell = lambda idx, slot: ((idx & ~lm) | low(idx)) * xpb + slot           # noqa: E731
+    assert sorted(cell(i, s) for i in range(N) for s in range(xpb)) == list(range(N * xpb))
+    for P in range(NP - 1):
+        _, out = geometry(L, RL, P)
+        inn, _ = geometry(L, RL, P + 1)
+        for fn in (out, inn):
+            for tau in range(TPT):
+                ti = fn(tau, 0)
+                for u in range(R):
+                    U = fn(0, u)
+                    base = (ti & ~lm) * xpb + 3 + ((low(ti) ^ low(U)) * xpb)  # slot 3
+                    assert base + (U & ~lm) * xpb == cell(fn(tau, u), 3)
+        if block < 64:
+            continue
+        for wave in range(block // 64):
+            lanes = range(wave * 64, wave * 64 + 64)
+            for u in range(R):
+                assert extra_cycles([cell(out(t // xpb, u), t % xpb) for t in lanes], 16, 32) == 0, ("write", L, xpb, P, u)
+                assert extra_cycles([cell(inn(t // xpb, u), t % xpb) for t in lanes], 32, 64) == 0, ("read", L, xpb, P, u)
+
+
+def test_two_element_grain_formula_conflicts_with_16_units():
+    """The formula this replaced (built for 8 units, L = 10): with 16 units every ds_write_b64 group is 2-way conflicted --
+    what SQ_LDS_BANK_CONFLICT showed on the c32 first factor (1.47e7 per launch, 0 after)."""
+    L, RL, xpb = 10, 4, 16
+    old = lambda idx, slot: (idx >> 2) * (4 * xpb) + ((((idx >> 1) ^ (idx >> 3)) & 1) * (2 * xpb)) + slot * 2 + ((idx ^ (idx >> 2)) & 1)  # noqa: E731
+    _, out = geometry(L, RL, 0)
+    lanes = range(64)
+    assert extra_cycles([old(out(t // xpb, 0), t % xpb) for t in lanes], 16, 32) == 4  # one extra cycle in each of the 4 groups
