@@ -79,3 +79,49 @@ def test_release_scratch_and_reuse(oracle):
     assert bits_equal(y, want)
     fft.release_scratch()
     fft.release_scratch()     # idempotent
+
+
+def test_device_calls_can_be_captured_into_a_hip_graph(oracle):
+    """Once a context has seen a (size, kind) -- tables uploaded, scratch allocated, kernel attributes set -- its *_dev calls
+    are nothing but kernel launches on the context's stream, so a launch-bound loop of small calls (one STFT frame batch, one
+    transform after another) can be captured into a hipGraph and replayed: same bytes as the direct calls."""
+    import torch
+
+    import kofft_amd
+
+    dev = torch.device("cuda", 0)
+    fft = kofft_amd.HipFftImpl(np.float32)
+    s = torch.cuda.Stream(device=dev)
+    fft.set_stream(s.cuda_stream)
+    rng = seeded(31)
+    n, batch, calls = 1024, 4, 12
+    xs = [rand_c(rng, (batch, n)) for _ in range(calls)]
+    sig = rng.uniform(-1, 1, 6000).astype(np.float32)
+    win = kofft_amd.hann(256)
+    frames = -(-sig.size // 64)
+    with torch.cuda.stream(s):
+        ds = [torch.from_numpy(x.view(np.float32).reshape(batch, n, 2)).to(dev) for x in xs]
+        outs = [torch.empty_like(d) for d in ds]
+        dsig, dwin = torch.from_numpy(sig).to(dev), torch.from_numpy(win).to(dev)
+        spec = torch.empty((frames, 256, 2), dtype=torch.float32, device=dev)
+        # warm-up outside the capture: planner tables and kernel attributes are set up on first use
+        fft.fft_dev_oop(ds[0].data_ptr(), outs[0].data_ptr(), n, batch)
+        fft.stft_dev(dsig.data_ptr(), sig.size, dwin.data_ptr(), 256, 64, spec.data_ptr(), 0, frames)
+        for o in outs:
+            o.zero_()
+        spec.zero_()
+    torch.cuda.synchronize(dev)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        for d, o in zip(ds, outs):
+            fft.fft_dev_oop(d.data_ptr(), o.data_ptr(), n, batch)
+        fft.stft_dev(dsig.data_ptr(), sig.size, dwin.data_ptr(), 256, 64, spec.data_ptr(), 0, frames)
+    torch.cuda.synchronize(dev)
+    assert float(outs[-1].abs().sum()) == 0.0  # captured, not run
+    for _ in range(2):
+        g.replay()
+    torch.cuda.synchronize(dev)
+    for x, o in zip(xs, outs):
+        assert bits_equal(o.cpu().numpy().view(np.complex64).reshape(batch, n), oracle.fft(x))
+    assert bits_equal(spec.cpu().numpy().view(np.complex64).reshape(frames, 256), oracle.stft(sig, win, 64, frames))
+    fft.set_stream(0)
