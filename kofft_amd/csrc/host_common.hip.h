@@ -193,11 +193,23 @@ inline int set_dyn_lds_once(kofft_hip_ctx *ctx, std::atomic<unsigned long long> 
     return KOFFT_OK;
 }
 
+// Points per thread of the one-workgroup-per-transform kernel at n = 8192 / 16384: 32 (half the threads, one exchange less)
+// or 16.  Measured per kind on one box (tools/sweep.py, KOFFT_RL_BIG=4 against 5): 16 wins for every f64 kernel of 8192
+// points (c64 +7 %, rfft64 n = 16384 +18 %, irfft64 +8 %) and for the f32 real-input kernels (rfft32 n = 16384 +22 %,
+// 32768 +4 %); 32 wins for c32 16384 (+4 %) and STFT 16384 (+14 %); irfft32 does not care.
+template <typename T, int EPI>
+constexpr int rl_for_kind(int L)
+{
+    return (L >= 13 && (sizeof(T) == 8 || EPI == EPI_RFFT)) ? 4 : rl_for(L);
+}
+
 template <typename T, int L, int EPI, class IO, int BLOCK_OVERRIDE = 0>
 int launch_wg(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t batch)
 {
-    constexpr int RL = rl_for(L);
-    constexpr int BLOCK = BLOCK_OVERRIDE ? BLOCK_OVERRIDE : block_for(L);
+    // (sub-transforms of the large-n path come with their own block size, computed for rl_for)
+    constexpr int RL = BLOCK_OVERRIDE ? rl_for(L) : rl_for_kind<T, EPI>(L);
+    constexpr int TPT0 = (1 << L) >> RL;
+    constexpr int BLOCK = BLOCK_OVERRIDE ? BLOCK_OVERRIDE : (TPT0 > 256 ? TPT0 : 256);
     constexpr int TPT = (1 << L) >> RL;
     constexpr int XPB = BLOCK / TPT;
     constexpr size_t lds = lds_wg_bytes<T, wg_split_lds<T, L, EPI, IO>(), IO::kSlotMinor, XPB>(1 << L);
