@@ -154,17 +154,19 @@ struct PersistState {
 
 // The prefetched form of a policy's input: IO::Raw, or -- for a policy that pairs row elements k and m - k inside a
 // wavefront (io_pairs_in_wave, transforms of at most 64 threads) -- IO::RawPair plus one extra register for element m.
-template <class IO, int TPT, bool PAIR = io_pairs_in_wave<IO>::value && (TPT <= 64)>
+// Transforms of more than one wavefront pair through the exchange buffer instead (pair_lds): the row goes into LDS in natural
+// order once and every thread reads its partners back -- one extra exchange, still half the loads and prefetch registers.
+template <class IO, int TPT, bool PAIR = io_pairs_in_wave<IO>::value>
 struct persist_raw {
     using type = typename IO::Raw;
     static constexpr int extra = 0;
-    static constexpr bool pair = false;
+    static constexpr bool pair = false, pair_lds = false;
 };
 template <class IO, int TPT>
 struct persist_raw<IO, TPT, true> {
     using type = typename IO::RawPair;
     static constexpr int extra = 1;
-    static constexpr bool pair = true;
+    static constexpr bool pair = TPT <= 64, pair_lds = TPT > 64;
 };
 
 // One transform: raw[] holds its (already landed or still in flight) inputs.
@@ -198,6 +200,17 @@ __device__ __forceinline__ void persist_transform(const typename persist_raw<IO,
     if constexpr (persist_raw<IO, TPT>::pair) {
         static_assert(CFG::kInvInLds, "paired input: the table entries come from the LDS copy");
         io.template finish_pairs<R, TPT>(raw, tau, cur, [&](int u) { return (st.inv_lds + tau)[FirstG::in_index(0, u)]; });
+    } else if constexpr (persist_raw<IO, TPT>::pair_lds) {
+        static_assert(CFG::kInvInLds && NBUF == 1 && !WAVE, "paired input through the exchange buffer");
+        // natural order, UNPADDED (N + 1 cells fit the padded buffer): ascending writes and descending reads are runs of
+        // consecutive cells.  The buffer is free once the previous transform's last gather is behind a barrier; the barrier
+        // in front of this transform's first scatter (NBUF == 1) closes the reads below.
+        exchange_sync<WAVE>();
+#pragma unroll
+        for (int u = 0; u < R; ++u) buf0[tau + u * TPT] = raw[u];
+        if (tau == 0) buf0[N] = raw[R];
+        exchange_sync<WAVE>();
+        io.template finish_pairs_lds<R, TPT>(raw, tau, buf0 + (N - tau), cur, [&](int u) { return (st.inv_lds + tau)[FirstG::in_index(0, u)]; });
     } else if (io.inside(xf0 + (GRP - 1))) {  // wave-uniform: every frame of the group lies inside the signal -> no range select
 #pragma unroll
         for (int u = 0; u < R; ++u) {
@@ -389,7 +402,7 @@ __global__ __launch_bounds__(CFG::BLOCK, CFG::MINW) void fft_persist_kernel(cons
     // register shuffles behind them).
     auto issue = [&](Raw *dst, const size_t b) {
         const rsrc_t d = io.in_desc_n(b + wslot, group_cnt(b));
-        if constexpr (RawSel::pair) {
+        if constexpr (RawSel::pair || RawSel::pair_lds) {
 #pragma unroll
             for (int u = 0; u < R; ++u) dst[u] = io.fetch_pair_d(d, in_lane_bytes, FirstG::in_index(0, u), in_row_off);
             dst[R] = io.fetch_last_d(d, in_row_off);

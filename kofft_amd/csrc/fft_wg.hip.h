@@ -358,7 +358,7 @@ template <typename T>
 struct IrfftIO : PlainTw {
     static constexpr bool kStreams = false;  // generic kernels: per-element loads (two row elements + a table entry each)
     static constexpr bool kPersist = sizeof(T) == 4;  // persistent kernel: both row elements prefetched, table in LDS
-    static constexpr int kPersistMaxLog2 = 11;        // 64 prefetch registers per thread: up to m = 2048
+    static constexpr int kPersistMaxLog2 = 12;        // up to m = 4096 (paired input: 34 prefetch registers per thread)
     static constexpr int kPersistMinLog2 = 6;
     static constexpr bool kInvInLds = true;
     static constexpr bool kLeanRegisters = false;
@@ -442,6 +442,13 @@ struct IrfftIO : PlainTw {
     __device__ __forceinline__ cpx<T> finish(size_t, int k, Raw r, Inv tw) const { return pre(k, r.a, r.rb, tw); }
     __device__ __forceinline__ bool inside(size_t) const { return false; }  // finish needs the element index: one form only
     __device__ __forceinline__ cpx<T> finish_in(Raw r, Inv tw) const { return pre(1, r.a, r.rb, tw); }
+    // the same from a natural-order LDS copy of the row: mirror points at cell m - tau, so input[m - k] = mirror[-tpt * u]
+    template <int R, int TPT, class InvAt>
+    __device__ __forceinline__ void finish_pairs_lds(const RawPair *raw, const int tau, const cpx<T> *mirror, cpx<T> *cur, const InvAt inv_at) const
+    {
+#pragma unroll
+        for (int u = 0; u < R; ++u) cur[u] = pre(u == 0 ? tau : 1, raw[u], mirror[-u * TPT], inv_at(u));
+    }
     // scratch[k] of irfft_direct (rfft.rs:487-506) from input[k], input[m-k], W[k]; then ifft's conj on the way in
     __device__ __forceinline__ cpx<T> pre(int k, cpx<T> a, cpx<T> rb, cpx<T> tw) const
     {

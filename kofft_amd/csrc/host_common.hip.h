@@ -420,7 +420,7 @@ int dispatch(kofft_hip_ctx *ctx, const IO &io, size_t n, size_t batch)
             if (L == 13 && batch >= (size_t)ctx->num_cus * 4) return launch_persist<T, 13, EPI>(ctx, io, tw, batch);
             if (L == 12 && batch >= (size_t)ctx->num_cus * 4) return launch_persist<T, 12, EPI>(ctx, io, tw, batch);
         }
-        if constexpr (EPI == EPI_RFFT) {
+        if constexpr (EPI == EPI_RFFT || (EPI == EPI_STORE && IO::kPersistMaxLog2 == 12)) {
             if (L == 12 && batch >= (size_t)ctx->num_cus * 4) return launch_persist<T, 12, EPI>(ctx, io, tw, batch);
         }
         if (L == 11 && batch >= (size_t)ctx->num_cus * 16) return launch_persist<T, 11, EPI>(ctx, io, tw, batch);

@@ -864,8 +864,9 @@ def test_n512_streaming_paths(fft32, oracle, batch):
 
 @pytest.mark.parametrize("n,batch", [(1024, 16390), (2048, 8200), (4096, 4101), (8192, 1029)])
 def test_irfft_streaming_paths(fft32, oracle, n, batch):
-    """irfft on the persistent kernel: input[k] and input[m-k] both prefetched through the row's descriptor (the second
-    with a reversed lane index), the W table in LDS, k = 0 selected branch-free; rows are (m+1)*8 bytes, 8-byte aligned."""
+    """irfft on the persistent kernel: input[k] prefetched through the row's descriptor, input[m-k] from the partner lane
+    (m <= 1024: ds_bpermute) or from a natural-order LDS copy of the row (m = 2048, 4096: more than one wavefront per
+    transform), the W table in LDS, k = 0 selected branch-free; rows are (m+1)*8 bytes, 8-byte aligned."""
     rng = seeded(5000 + n)
     spec = rand_c(rng, (batch, n // 2 + 1))
     spec[:, 0].imag = 0
