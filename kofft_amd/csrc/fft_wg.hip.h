@@ -35,6 +35,10 @@ struct io_has_acc<IO, decltype((void)IO::kHasAcc)> { static constexpr bool value
 // A policy whose input value k needs row elements k AND m - k (irfft) can get the second one from the lane that loaded it
 // instead of loading it again, when a transform's threads share a wavefront: io_pairs_in_wave<IO> (see IrfftIO).
 template <class IO, class = void>
+struct io_stages_pairs { static constexpr bool value = false; };
+template <class IO>
+struct io_stages_pairs<IO, decltype((void)IO::kStagePairs)> { static constexpr bool value = IO::kStagePairs; };
+template <class IO, class = void>
 struct io_pairs_in_wave { static constexpr bool value = false; };
 template <class IO>
 struct io_pairs_in_wave<IO, decltype((void)IO::kPairInWave)> { static constexpr bool value = IO::kPairInWave; };
@@ -368,6 +372,9 @@ struct IrfftIO : PlainTw {
     // word instead of a second load (lane 0 pairs with itself: register R-u, and input[m] for u = 0, loaded once per
     // transform as register R of the set).  Halves the load instructions and the prefetch registers.
     static constexpr bool kPairInWave = sizeof(T) == 4;
+    static constexpr bool kStagePairs = true;  // generic kernel: the row goes through LDS once instead of being loaded twice
+    __device__ __forceinline__ cpx<T> load_a(size_t xf, int k) const { return ld_stream(in + xf * (size_t)(m + 1) + k); }
+    __device__ __forceinline__ cpx<T> pre_staged(int k, cpx<T> a, cpx<T> rb) const { return pre(k, a, rb, rtab[k]); }
     using RawPair = cpx<T>;
     __device__ __forceinline__ RawPair fetch_pair_d(rsrc_t d, int lane_bytes, int iu, int row_off) const
     {
@@ -726,6 +733,33 @@ __global__ __launch_bounds__(BLOCK, (IO::kMinWaves > 1 && BLOCK == 512 && L >= 9
                 }
                 fetched = true;
             }
+        }
+        if constexpr (io_stages_pairs<IO>::value && !SPLIT && !SM) {
+            // irfft: value k needs row elements k and m - k.  Load every element ONCE, put the row into the transform's
+            // exchange buffer in natural order (unpadded: N + 1 cells fit the padded buffer; pass 0 holds k = tau + TPT*u),
+            // read the partners back: one LDS round trip instead of a second, reversed global load per element.
+            cpx<T> *nat = reinterpret_cast<cpx<T> *>(smem_raw) + (size_t)slot * lds_elems(N);
+            cpx<T> a[R];
+            if (active) {
+#pragma unroll
+                for (int u = 0; u < R; ++u) a[u] = io.load_a(xf, G0::in_index(tau, u));
+                if (tau == 0) nat[N] = io.load_a(xf, N);
+#pragma unroll
+                for (int u = 0; u < R; ++u) nat[G0::in_index(tau, u)] = a[u];
+            }
+            __syncthreads();
+            if (active) {
+#pragma unroll
+                for (int u = 0; u < R; ++u) {
+                    const int k = G0::in_index(tau, u);
+                    v[u] = io.pre_staged(k, a[u], nat[N - k]);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < R; ++u) v[u] = mk<T>(T(0), T(0));
+            }
+            if (NP > 1) __syncthreads();  // the partners are read before the first exchange's scatter reuses the buffer
+            fetched = true;
         }
         if (!fetched) {
             // one branch around ALL loads (a per-element test would put a branch and a wait between them)
