@@ -795,24 +795,40 @@ __global__ __launch_bounds__(BLOCK, (IO::kMinWaves > 1 && BLOCK == 512 && L >= 9
             const int k0 = tau - (TPT >= LINE ? (io.row_misalign(xf) & (LINE - 1)) : 0);  // narrower rows: as they come
             // all table entries first, then all results, then all stores: interleaving them makes every store wait
             // for the next table load (the compiler cannot prove the table and the output disjoint)
-            cpx<T> w[R + 1], xo[R + 1];
-#pragma unroll
-            for (int g = 0; g <= R; ++g) {
-                const int k = k0 + g * TPT;
-                w[g] = io.rtab[k < 0 ? 0 : (k > N - 1 ? N - 1 : k)];
-            }
+            // (f64, 16 points per thread: in two halves -- 2 x 17 values of 4 registers each held at once made this
+            // epilogue, not the transform, set the kernel's register count: 206 VGPRs = 2 waves per SIMD)
+            constexpr int CH = (sizeof(T) == 8 && R >= 16) ? 2 : 1;
+            constexpr int PER = (R + 1 + CH - 1) / CH;
             const cpx<T> y0 = buf[lds_pad(0)];
 #pragma unroll
-            for (int g = 0; g <= R; ++g) {
-                const int k = k0 + g * TPT;
-                const int kc = k < 1 ? 1 : (k > N - 1 ? N - 1 : k);  // LDS addressing only
-                const cpx<T> p = io.post_w(w[g], buf[lds_pad(kc)], buf[lds_pad(N - kc)]);
-                xo[g] = (g == 0 && k == 0) ? mk<T>(y0.re + y0.im, T(0)) : (g == R && k == N) ? mk<T>(y0.re - y0.im, T(0)) : p;
-            }
-            if (k0 >= 0) st_stream(orow + k0, xo[0]);
+            for (int ch = 0; ch < CH; ++ch) {
+                cpx<T> w[PER], xo[PER];
 #pragma unroll
-            for (int g = 1; g < R; ++g) st_stream(orow + k0 + g * TPT, xo[g]);
-            if (k0 <= 0) st_stream(orow + k0 + N, xo[R]);
+                for (int j = 0; j < PER; ++j) {
+                    const int g = ch * PER + j, k = k0 + g * TPT;
+                    if (g <= R) w[j] = io.rtab[k < 0 ? 0 : (k > N - 1 ? N - 1 : k)];
+                }
+#pragma unroll
+                for (int j = 0; j < PER; ++j) {
+                    const int g = ch * PER + j, k = k0 + g * TPT;
+                    if (g <= R) {
+                        const int kc = k < 1 ? 1 : (k > N - 1 ? N - 1 : k);  // LDS addressing only
+                        const cpx<T> p = io.post_w(w[j], buf[lds_pad(kc)], buf[lds_pad(N - kc)]);
+                        xo[j] = (g == 0 && k == 0) ? mk<T>(y0.re + y0.im, T(0)) : (g == R && k == N) ? mk<T>(y0.re - y0.im, T(0)) : p;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < PER; ++j) {
+                    const int g = ch * PER + j;
+                    if (g == 0) {
+                        if (k0 >= 0) st_stream(orow + k0, xo[j]);
+                    } else if (g < R) {
+                        st_stream(orow + k0 + g * TPT, xo[j]);
+                    } else if (g == R) {
+                        if (k0 <= 0) st_stream(orow + k0 + N, xo[j]);
+                    }
+                }
+            }
         }
     } else {
         if constexpr (io_has_acc<IO>::value) {
