@@ -82,6 +82,38 @@ int launch_rows_persist(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size
     return KOFFT_OK;
 }
 
+// Few units -- ONE large transform, or a handful: tiles of the full width leave most CUs without a workgroup (2^20 points
+// = 1024 columns = 128 tiles of 8), and a single transform is all latency.  Halve the tile width (once or twice) until
+// every CU has a workgroup; segments get narrower, but such a transform lives in the L2 / Infinity Cache anyway.
+template <class IO>
+inline void narrow_tile_adjust(IO &, size_t) {}
+template <typename T, bool INVERSE>
+inline void narrow_tile_adjust(BigRowsIO<T, INVERSE> &io, size_t segment_bytes)
+{
+    if (segment_bytes < 64) io.nt = false;  // streaming stores only for segments of at least half a line (as in fft_big_dev)
+}
+template <typename T, int LL, class IO>
+int launch_sub_one_tile(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t units)
+{
+    constexpr int B0 = big_block<T, IO, LL>();
+    constexpr int TPT = (1 << LL) >> rl_for(LL);
+    const size_t cus = (size_t)ctx->num_cus * (size_t)ctx->big_narrow_per_cu;
+    if constexpr (B0 / 2 >= 64 && (B0 / 2) % TPT == 0) {
+        if (ctx->big_narrow && units / (B0 / TPT) < cus) {
+            IO nio = io;
+            if constexpr (B0 / 4 >= 64 && (B0 / 4) % TPT == 0) {
+                if (units / (B0 / 2 / TPT) < cus) {
+                    narrow_tile_adjust(nio, (size_t)(B0 / 4 / TPT) * sizeof(cpx<T>));
+                    return launch_wg<T, LL, EPI_STORE, IO, B0 / 4>(ctx, nio, tw, units);
+                }
+            }
+            narrow_tile_adjust(nio, (size_t)(B0 / 2 / TPT) * sizeof(cpx<T>));
+            return launch_wg<T, LL, EPI_STORE, IO, B0 / 2>(ctx, nio, tw, units);
+        }
+    }
+    return launch_wg<T, LL, EPI_STORE, IO, B0>(ctx, io, tw, units);
+}
+
 // Launch the generic kernel for a sub-transform of log2 size LS with an arbitrary IO policy.
 template <typename T, class IO>
 int launch_sub(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, int LS, size_t units)
@@ -101,12 +133,12 @@ int launch_sub(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, int LS, size_
     switch (LS) {
     // 16 (c32) / 8 (c64) adjacent columns or rows per workgroup = 128-byte segments while the tile fits the LDS budget
     // (sub-transforms up to 2^9 points; 2^10: 8; larger ones fewer still -- big_block).
+    case 7: return launch_sub_one_tile<T, 7, IO>(ctx, io, tw, units);
+    case 8: return launch_sub_one_tile<T, 8, IO>(ctx, io, tw, units);
+    case 9: return launch_sub_one_tile<T, 9, IO>(ctx, io, tw, units);
+    case 10: return launch_sub_one_tile<T, 10, IO>(ctx, io, tw, units);
 #define KOFFT_CASE(LL) \
     case LL: return launch_wg<T, LL, EPI_STORE, IO, big_block<T, IO, LL>()>(ctx, io, tw, units);
-        KOFFT_CASE(7)
-        KOFFT_CASE(8)
-        KOFFT_CASE(9)
-        KOFFT_CASE(10)
         KOFFT_CASE(11)
         KOFFT_CASE(12)
         KOFFT_CASE(13)

@@ -982,6 +982,29 @@ def test_host_pointer_pipeline_large_batches(fft32, fft64, oracle):
     assert_parity(yd, oracle.fft(xd), "pipelined host fft c64", REL_TOL_F64)
 
 
+@pytest.mark.parametrize("log2n,batch", [(15, 1), (16, 3), (17, 1), (18, 2), (19, 1), (20, 1)])
+def test_single_large_transforms_narrow_tiles(fft32, fft64, oracle, log2n, batch, monkeypatch):
+    """One large transform (or a handful) runs its factors on narrower tiles so that every CU gets a workgroup
+    (launch_sub_one_tile: 8 -> 4 -> 2 columns); KOFFT_HIP_BIG_NARROW=0 keeps the full-width tiles.  Same bytes either way."""
+    import kofft_amd
+
+    n = 1 << log2n
+    x32 = rand_c(seeded(9700 + log2n), (batch, n))
+    x64 = rand_c(seeded(9800 + log2n), (batch, n), np.complex128)
+    w32, w64 = oracle.fft(x32), oracle.fft(x64)
+    for narrow in ("1", "0"):
+        monkeypatch.setenv("KOFFT_HIP_BIG_NARROW", narrow)  # read when the context is created
+        f32, f64 = kofft_amd.HipFftImpl(np.float32), kofft_amd.HipFftImpl(np.float64)
+        y = x32.copy()
+        f32.fft_batch(y)
+        assert_parity(y, w32, f"single large c32 2^{log2n} x {batch} narrow={narrow}", REL_TOL_F32)
+        f32.fft_batch(y, inverse=True)
+        assert_parity(y, oracle.ifft(w32), f"single large c32 inverse 2^{log2n} narrow={narrow}", REL_TOL_F32)
+        y = x64.copy()
+        f64.fft_batch(y)
+        assert_parity(y, w64, f"single large c64 2^{log2n} x {batch} narrow={narrow}", REL_TOL_F64)
+
+
 def test_host_pointer_stft_large(fft32, oracle):
     """stft() from host memory with >= 128 MiB of spectra (one upload, one launch, one download: chunking the download
     behind the kernels measured slower) -- frames past the end of the signal included."""
