@@ -412,7 +412,7 @@ def test_fft_c64_large_n(fft64, oracle, log2n, batch):
 
 
 @pytest.mark.parametrize("dtype,log2n,batch", [("c64", 20, 18), ("c64", 16, 300), ("c64", 22, 3), ("c32", 17, 200), ("c32", 20, 40),
-                                               ("c32", 22, 6), ("c64", 19, 40)])
+                                               ("c32", 22, 6), ("c64", 19, 40), ("c32", 21, 11), ("c64", 21, 5)])
 def test_large_n_persistent_factor_kernels(fft32, fft64, oracle, dtype, log2n, batch):
     """Batches large enough for the persistent factor kernels (fft_tile_persist_kernel / fft_rows_persist_kernel: every
     resident workgroup walks several tiles, prefetching the next; the last factor keeps its table entries resident per row

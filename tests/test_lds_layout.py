@@ -54,7 +54,7 @@ def extra_cycles(cells, group, banks):
 
 
 @pytest.mark.parametrize("xpb", [8, 16])
-@pytest.mark.parametrize("L", [5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("L", [5, 6, 7, 8, 9, 10, 11])
 def test_slot_minor_cells_bijective_decomposable_conflict_free(L, xpb):
     RL = rl_for(L)
     R, N = 1 << RL, 1 << L
