@@ -128,7 +128,7 @@ int launch_sub(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, int LS, size_
             KOFFT_CASE(10)
 #undef KOFFT_CASE
         case 11:  // c32 only: 8 columns x 2^11 points at 1024 threads (c64 would need 2 x 64 data registers per thread at 128)
-            if constexpr (sizeof(T) == 4 && IO::kTileInvariantTw) {
+            if constexpr (IO::kTileInvariantTw) {
                 if (ctx->big_first11) return launch_tile_persist<T, 11, IO>(ctx, io, tw, units);
             }
             break;
@@ -185,7 +185,7 @@ int fft_big_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t ba
     const bool three = L >= ctx->big_three_min && !ctx->big_two_only;  // measured crossover, KOFFT_HIP_BIG_THREE_MIN
     // two factors of an odd L: the larger one first when the persistent first-factor kernel covers it (c32, 2^11 points)
     // (only for batches the persistent kernels take: a single 2^21-point transform is faster as 2^10 x 2^11, 31.7 vs 33.6 us)
-    const bool first11 = sizeof(T) == 4 && ctx->big_first11 && ctx->big_persist && L == 21 && !three &&
+    const bool first11 = ctx->big_first11 && ctx->big_persist && L == 21 && !three &&
                          (batch << 10) >= (size_t)ctx->num_cus * ctx->big_persist_min_units;
     const int L1 = three ? (L + 2) / 3 : (first11 ? 11 : L / 2);
     const int L2 = three ? (L - L1 + 1) / 2 : 0;

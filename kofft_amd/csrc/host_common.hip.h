@@ -391,7 +391,8 @@ constexpr int big_block()
 {
     const int tpt = (1 << LS) >> rl_for(LS);
     int xpb = KOFFT_BIG_XPB(T);
-    while (xpb > 1 && (xpb * tpt > 1024 || (size_t)xpb * (1 << LS) * 8 > LDS_CAP)) xpb /= 2;
+    // (f64: at most 512 threads -- two register sets of 16 values are 128 VGPRs, a 1024-thread block has 128 in all)
+    while (xpb > 1 && (xpb * tpt > (sizeof(T) == 8 ? 512 : 1024) || (size_t)xpb * (1 << LS) * 8 > LDS_CAP)) xpb /= 2;
     int block = xpb * tpt;
     if (block < 64) block = 64;
     return block;
