@@ -21,7 +21,8 @@ int launch_tile_persist(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size
     constexpr int TPT = (1 << LS) >> RL;
     constexpr int XPB = BLOCK / TPT;
     constexpr size_t lds = TileExchange<T, LS, RL, XPB, IO::kSplitLds>::bytes +
-                           (IO::kTileInvariantTw ? (size_t(1) << LS) / 2 * sizeof(cpx<T>) : 0);  // + the first factor's table copy
+                           (IO::kTileInvariantTw ? (size_t(1) << LS) / 2 * sizeof(cpx<T>) : 0) +  // + the first factor's table copy
+                           (io_tile_group_tw<IO>::value ? (size_t(1) << LS) * sizeof(cpx<T>) : 0);  // or the middle factor's per-run table
     constexpr int WG_PER_CU = BLOCK >= 512 ? 1 : 512 / BLOCK;
     static_assert(lds * WG_PER_CU <= 160 * 1024, "LDS budget");
     if (units % XPB != 0) return KOFFT_ERR_UNSUPPORTED;  // (never: units = transforms << bits, bits >= 7)
@@ -36,7 +37,17 @@ int launch_tile_persist(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size
     if (ctx->persist_grid_pct > 0) blocks = blocks * (size_t)ctx->persist_grid_pct / 100;
     if (blocks < 1) blocks = 1;
     if (blocks > ntiles) blocks = ntiles;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BLOCK), lds, ctx->stream, io, tw, ntiles);
+    IO kio = io;
+    if constexpr (io_tile_group_tw<IO>::value) {
+        // runs of tiles that share a table: as long as possible while every workgroup still gets a run
+        size_t tpg = (size_t(1) << kio.JB) / XPB;
+        if (tpg < 1 || ((size_t(1) << kio.JB) % XPB) != 0) tpg = 1;
+        while (tpg > 1 && ntiles / tpg < blocks) tpg /= 2;
+        if (!ctx->big_mid_group) tpg = 1;
+        kio.tpg = (int)tpg;
+        if (blocks > ntiles / tpg) blocks = ntiles / tpg;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BLOCK), lds, ctx->stream, kio, tw, ntiles);
     KOFFT_HIP_TRY(ctx, hipGetLastError());
     return KOFFT_OK;
 }

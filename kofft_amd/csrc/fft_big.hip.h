@@ -141,6 +141,10 @@ struct BigMidIO {
     }
     static constexpr bool kConjIn = false, kConjScaleOut = false, kNtOut = false;
     static constexpr bool kTileInvariantTw = false;
+    // The table entries of a tile depend on its prefix K only, and the 2^JB / XPB tiles of one (transform, K) are consecutive:
+    // the persistent kernel walks them in runs of `tpg` and keeps the run's 2^LS - 1 entries in LDS (kTileGroupTw).
+    static constexpr bool kTileGroupTw = true;
+    int tpg = 1;  // tiles per table load (divides 2^JB / XPB); set by launch_tile_persist
     __device__ __forceinline__ bool nt_in() const { return true; }
     __device__ __forceinline__ T out_scale() const { return T(1); }
     __device__ __forceinline__ size_t xf_transform(size_t xf) const { return xf >> (S + JB); }
@@ -271,6 +275,17 @@ struct TileExchange {
     }
 };
 
+template <class IO, class = void>
+struct io_tile_group_tw { static constexpr bool value = false; };
+template <class IO>
+struct io_tile_group_tw<IO, decltype((void)IO::kTileGroupTw)> { static constexpr bool value = IO::kTileGroupTw; };
+// LDS copy of a sub-transform's table entries by stage: entry (1 << s) - 1 + kk holds the entry of stage s, group kk
+// (reg_pass asks for (idx_local, s) with idx_local = kk << (L - 1 - s)).
+template <int L>
+struct TwLdsStage {
+    __device__ __forceinline__ int operator()(int idx_local, int s_local) const { return (1 << s_local) - 1 + (idx_local >> (L - 1 - s_local)); }
+};
+
 template <typename T, int L, int RL, int BLOCK, class IO>
 __global__ __launch_bounds__(BLOCK, (BLOCK >= 1024 ? 4 : 2)) void fft_tile_persist_kernel(const IO io, const cpx<T> *__restrict__ tw,
                                                                               const size_t ntiles)
@@ -294,8 +309,16 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 1024 ? 4 : 2)) void fft_tile_persi
     const int tau = tid / XPB;
     const int slot = tid % XPB;
 
-    size_t tile = blockIdx.x;
+    constexpr bool GROUPED = io_tile_group_tw<IO>::value;
+    size_t tpg = 1;
+    if constexpr (GROUPED) tpg = (size_t)io.tpg;
+    size_t tile = (size_t)blockIdx.x * tpg;
     if (tile >= ntiles) return;  // the whole workgroup leaves together
+    // tile walk: runs of tpg consecutive tiles (one table load each), runs strided by the grid
+    auto next_tile = [&](const size_t t) -> size_t {
+        if constexpr (GROUPED) return (((t + 1) & (tpg - 1)) != 0) ? t + 1 : (t + 1 - tpg) + (size_t)gridDim.x * tpg;  // tpg: a power of two
+        else return t + gridDim.x;
+    };
     // First factor: the sub-transform's table entries T_n[idx << shift], idx < N/2, do not depend on the tile.  One LDS copy
     // per workgroup (8 KiB for 2^10 c64 points) replaces 27 global loads per thread and tile; the 8 lanes of a unit group
     // read one address (broadcast).  Behind the exchange region.
@@ -306,9 +329,27 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 1024 ? 4 : 2)) void fft_tile_persi
         tw_lds = tl;
         __syncthreads();
     }
+    auto fill_group_table = [&](const size_t t) {  // GROUPED: the 2^L - 1 entries of the run that starts at tile t
+        if constexpr (GROUPED) {
+            cpx<T> *tl = reinterpret_cast<cpx<T> *>(smem_raw + TileExchange<T, L, RL, XPB, SPLIT>::bytes);
+            const auto map = io.tw_map(t * XPB);
+            for (int e = tid; e < N - 1; e += BLOCK) {
+                const int s = 31 - __builtin_clz(e + 1), kk = e + 1 - (1 << s);
+                tl[e] = tw[map(kk << (L - 1 - s), s)];
+            }
+            tw_lds = tl;
+            __syncthreads();
+        }
+    };
+    fill_group_table(tile);
     auto compute = [&](auto pass, cpx<T> *v, const size_t xf) {
         constexpr int P = decltype(pass)::value;
-        if constexpr (IO::kTileInvariantTw) {
+        if constexpr (GROUPED) {
+            using Gm = WgGeom<L, RL, P>;
+#pragma unroll
+            for (int g = 0; g < Gm::G; ++g)
+                reg_pass<T, L, Gm::S0, Gm::Q, false>(&v[g * (1 << Gm::Q)], (tau + g * Gm::TPT) >> Gm::JB, tw_lds, TwLdsStage<L>{});
+        } else if constexpr (IO::kTileInvariantTw) {
             using Gm = WgGeom<L, RL, P>;
 #pragma unroll
             for (int g = 0; g < Gm::G; ++g)
@@ -388,7 +429,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 1024 ? 4 : 2)) void fft_tile_persi
 #endif
 #define KOFFT_TILE_STEP(CUR, NXT)                                                                        \
     {                                                                                                    \
-        const size_t ntile = tile + gridDim.x;                                                           \
+        const size_t ntile = next_tile(tile);                                                            \
         const bool more = ntile < ntiles; /* workgroup-uniform */                                        \
         KOFFT_TILE_PREFETCH(CUR, NXT)                                                                    \
         __builtin_amdgcn_sched_barrier(0); /* keep the prefetch ahead of the first use of CUR */         \
@@ -396,6 +437,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 1024 ? 4 : 2)) void fft_tile_persi
         if (!more) break;                                                                                \
         tile = ntile;                                                                                    \
         __syncthreads(); /* the last gathers of this tile are done before the next tile's first scatter */ \
+        if constexpr (GROUPED) {                                                                         \
+            if ((tile & (tpg - 1)) == 0) fill_group_table(tile); /* a new run: its table (uniform) */    \
+        }                                                                                                \
     }
     do {  // first step peeled: see fft_rows_persist_kernel
         KOFFT_TILE_STEP(ra, rb)
