@@ -125,3 +125,42 @@ def test_device_calls_can_be_captured_into_a_hip_graph(oracle):
         assert bits_equal(o.cpu().numpy().view(np.complex64).reshape(batch, n), oracle.fft(x))
     assert bits_equal(spec.cpu().numpy().view(np.complex64).reshape(frames, 256), oracle.stft(sig, win, 64, frames))
     fft.set_stream(0)
+
+
+def test_two_contexts_in_two_threads(oracle):
+    """ScalarFftImpl is Send + !Sync: one context per thread.  Two threads, each with its own contexts, run
+    different transforms at the same time (ctypes drops the GIL around every call): the library's only shared state is
+    read-only after the first use per device (kernel attributes, the RCCL binding), so every result is the oracle's."""
+    import threading
+
+    import kofft_amd
+
+    errors = []
+
+    def worker(seed, sizes):
+        try:
+            f32, f64 = kofft_amd.HipFftImpl(np.float32), kofft_amd.HipFftImpl(np.float64)
+            rng = seeded(seed)
+            for rep in range(3):
+                for n, batch in sizes:
+                    x = rand_c(rng, (batch, n))
+                    y = x.copy()
+                    f32.fft_batch(y)
+                    if not bits_equal(y, oracle.fft(x)):
+                        errors.append(("c32", n, batch, rep))
+                    xd = rand_c(rng, (max(batch // 4, 1), n), np.complex128)
+                    yd = xd.copy()
+                    f64.fft_batch(yd)
+                    if not bits_equal(yd, oracle.fft(xd)):
+                        errors.append(("c64", n, batch, rep))
+                    r = rng.uniform(-1, 1, (batch, 2 * n)).astype(np.float32)
+                    spec = f32.rfft_batch(r)
+                    if not bits_equal(spec, oracle.rfft(r, None)) or not bits_equal(f32.irfft_batch(spec, 2 * n), oracle.irfft(spec, 2 * n)):
+                        errors.append(("real", n, batch, rep))
+        except Exception as e:  # noqa: BLE001 -- reported below, in the main thread
+            errors.append(repr(e))
+
+    a = threading.Thread(target=worker, args=(41, [(1024, 300), (1000, 40), (1 << 16, 6), (64, 5000)]))
+    b = threading.Thread(target=worker, args=(42, [(4096, 130), (12, 700), (1 << 15, 9), (512, 900)]))
+    a.start(); b.start(); a.join(); b.join()
+    assert not errors, errors
