@@ -216,7 +216,7 @@ def cpu_baseline_fft4096(target_seconds: float):
         "cores": cores,
         "kind": "port",
         "sample": f"{transforms} x 4096-pt c32 transforms ({cores} threads x {reps} calls x {chunk}, one planner per call), "
-                  f"oracle/ C restatement of kofft's Stockham path (-O2, no FMA), busiest thread {dt:.1f} s",
+                  f"oracle/ C restatement of kofft's Stockham path (-O3, no FMA), busiest thread {dt:.1f} s",
         "reference_published": "kofft's own benchmarks/README.md:27: 1.046 ms per 4096-pt transform, one thread = 0.0039 GPoints/s "
                                "(other hardware; the port above is ~36x faster per core)",
     }
