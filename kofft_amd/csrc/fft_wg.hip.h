@@ -374,6 +374,7 @@ struct IrfftIO : PlainTw {
     static constexpr bool kPairInWave = sizeof(T) == 4;
     static constexpr bool kStagePairs = true;  // generic kernel: the row goes through LDS once instead of being loaded twice
     __device__ __forceinline__ cpx<T> load_a(size_t xf, int k) const { return ld_stream(in + xf * (size_t)(m + 1) + k); }
+    __device__ __forceinline__ cpx<T> load_raw(size_t e) const { return ld_stream(in + e); }  // element e of the whole input, rows back to back
     __device__ __forceinline__ cpx<T> pre_staged(int k, cpx<T> a, cpx<T> rb) const { return pre(k, a, rb, rtab[k]); }
     using RawPair = cpx<T>;
     __device__ __forceinline__ RawPair fetch_pair_d(rsrc_t d, int lane_bytes, int iu, int row_off) const
@@ -931,6 +932,27 @@ __global__ __launch_bounds__(kSmallBlock) void fft_small_kernel(const IO io, con
                 fetched = true;
             }
         }
+        // (N <= 8 only: at 16 / 32 the N + 1 staging registers next to the N data registers cost more than the second load --
+        // measured irfft32 n = 32 0.71 -> 0.66, n = 64 0.62 -> 0.48 with it, n = 8 / 16 0.76 / 0.74 -> 0.80 / 0.79)
+        constexpr bool STAGE_ROWS = io_stages_pairs<IO>::value && N <= 8;
+        if constexpr (STAGE_ROWS) {
+            // irfft: an input row is N + 1 values = exactly one LDS row, and the workgroup's rows are contiguous in memory:
+            // copy them in memory order (every element ONCE), then scratch[k] from the row's cells k and N - k.
+            const size_t first = xf0 * (size_t)S;
+            const size_t avail = (batch - xf0 < (size_t)B ? batch - xf0 : (size_t)B) * (size_t)S;  // elements that exist
+            cpx<T> tmp[S];
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                const size_t e = (size_t)j * B + t;
+                tmp[j] = e < avail ? io.load_raw(first + e) : mk<T>(T(0), T(0));
+            }
+#pragma unroll
+            for (int j = 0; j < S; ++j) buf[(size_t)j * B + t] = tmp[j];
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < N; ++i) x[i] = io.pre_staged(i, buf[t * S + i], buf[t * S + (N - i)]);
+            fetched = true;
+        }
         if (!fetched) {
             if (xf0 + B <= batch) {  // full workgroup: no per-element test between the loads
                 cpx<T> tmp[N];
@@ -952,9 +974,11 @@ __global__ __launch_bounds__(kSmallBlock) void fft_small_kernel(const IO io, con
                 }
             }
         }
-        __syncthreads();
+        if constexpr (!STAGE_ROWS) {
+            __syncthreads();
 #pragma unroll
-        for (int i = 0; i < N; ++i) x[i] = buf[t * S + i];
+            for (int i = 0; i < N; ++i) x[i] = buf[t * S + i];
+        }
     }
     if constexpr (N == 2) small_fft2(x);
     if constexpr (N == 4) small_fft4(x);
