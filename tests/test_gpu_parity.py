@@ -1039,3 +1039,33 @@ def test_ndfft_long_strided_axes(fft32, fft64, oracle, depth, rows, cols):
         impl.fftnd(data, depth, rows, cols, inverse=True)
         # (the f64 kernels for n <= 16 carry the reference's f32-literal constants: 1e-7, not 1e-13)
         assert np.max(np.abs(data.reshape(depth, rows, cols) - x)) < (2e-3 if dt == np.complex64 else 1e-6)
+
+
+@pytest.mark.parametrize("n,batch", [(4096, 4095), (4096, 4097), (8192, 1023), (8192, 1025), (2048, 8191), (2048, 8193)])
+def test_irfft_dispatch_boundaries(fft32, oracle, n, batch):
+    """Either side of the batch sizes where irfft moves from the generic kernel (row staged once through LDS) to the persistent
+    ones (partner lane for m <= 1024, natural-order LDS copy for m = 2048 / 4096): the same bytes on both sides."""
+    rng = seeded(9900 + n + batch)
+    spec = rand_c(rng, (batch, n // 2 + 1))
+    spec[:, 0].imag = 0
+    spec[:, -1].imag = 0
+    pick = sorted({0, 1, batch // 3, batch - 2, batch - 1})
+    got = fft32.irfft_batch(spec, n)
+    assert_parity(got[pick], oracle.irfft(spec[pick], n), f"irfft n={n} batch={batch}", REL_TOL_F32)
+
+
+@pytest.mark.parametrize("dtype,log2n,batches", [("c32", 17, (1, 2, 3, 5, 8, 9)), ("c32", 15, (1, 4, 15, 17, 33)), ("c64", 16, (1, 2, 7, 9, 31, 33))])
+def test_large_n_batches_around_the_tile_width_steps(fft32, fft64, oracle, dtype, log2n, batches):
+    """Batch counts on either side of the points where the large-n factors switch tile width (every CU must get a workgroup)
+    and from the one-tile-per-workgroup kernels to the persistent ones."""
+    n = 1 << log2n
+    cdt = np.complex128 if dtype == "c64" else np.complex64
+    fft = fft64 if dtype == "c64" else fft32
+    tol = REL_TOL_F64 if dtype == "c64" else REL_TOL_F32
+    rng = seeded(9950 + log2n)
+    x = rand_c(rng, (max(batches), n), cdt)
+    want = oracle.fft(x)
+    for b in batches:
+        y = x[:b].copy()
+        fft.fft_batch(y)
+        assert_parity(y, want[:b], f"{dtype} 2^{log2n} batch {b}", tol)
