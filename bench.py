@@ -69,6 +69,9 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inplace", action="store_true", help="fft4096 only: transform the buffer in place (values overflow after ~10 steps; timing study only)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work for the cpu_baseline sample")
+    ap.add_argument("--extras-timeout", type=float, default=None,
+                    help="seconds the extra workloads may take before rank 0 prints the headline alone and exits "
+                         "(0 = no limit; default 240 at N > 1, where a hanging collective cannot be caught, none at N = 1)")
     ap.add_argument("--rehearse-one-card", action="store_true",
                     help="rehearsal only (invalidates the metric): every rank uses cuda:0 and the process group is gloo, so the "
                          "N-rank protocol (launcher, barriers, reductions, sharding, gather) can run on a one-GPU box")
@@ -546,6 +549,35 @@ def run_rank(args) -> None:
     if extras_on:
         extra_names = [k for k in ("rfft2048", "stft1024", "c64_2p20") if k != args.workload] if world == 1 else \
                       [k for k in ("stft1024",) if k != args.workload]
+    # The headline exists from here on.  The extra workloads (at N > 1: the RCCL all-gather of config 4) must never cost the
+    # line: if they have not finished after --extras-timeout seconds (a collective that hangs cannot be caught as an
+    # exception), rank 0 prints the headline alone and the process ends -- still exactly one JSON line.
+    def headline_line():
+        return {
+            "metric": head["metric"], "value": head["value"], "unit": head["unit"], "n_gpus": n_seen, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": head["scaling"],
+            "vs_baseline": None, "dtype": head["dtype"], "data": "synthetic", "config": head["config"], "roofline": head["roofline"],
+            "blocks": head["blocks"], "blocks_ms_per_step": head["blocks_ms_per_step"], "launches_total": launches[0],
+            "launcher": "self" if os.environ.get("KOFFT_BENCH_LAUNCHED") else ("torchrun" if world > 1 else "single"),
+            **({"rehearsal": "every rank on cuda:0, gloo process group: NOT a measurement"} if args.rehearse_one_card else {}),
+        }
+
+    watchdog = None
+    if args.extras_timeout is None:
+        args.extras_timeout = 240.0 if world > 1 else 0.0
+    if extra_names and args.extras_timeout > 0:
+        def give_up():
+            if rank == 0:
+                line = headline_line()
+                if allgather is not None:
+                    line["allgather"] = allgather
+                line["workloads"] = {"error": f"extra workloads did not finish within {args.extras_timeout:.0f} s; headline only"}
+                line["cpu_baseline"] = None
+                print(json.dumps(line), flush=True)
+            os._exit(0)  # every rank: the headline is a complete, valid measurement
+        watchdog = threading.Timer(args.extras_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
     extras = {}
     for name in extra_names:
         try:
@@ -561,28 +593,10 @@ def run_rank(args) -> None:
             extras[name] = {"error": f"{type(e).__name__}: {e}"}
         torch.cuda.empty_cache()
 
+    if watchdog is not None:
+        watchdog.cancel()
     if rank == 0:
-        out = {
-            "metric": head["metric"],
-            "value": head["value"],
-            "unit": head["unit"],
-            "n_gpus": n_seen,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": head["ms_per_step"],
-            "higher_is_better": True,
-            "scaling": head["scaling"],
-            "vs_baseline": None,
-            "dtype": head["dtype"],
-            "data": "synthetic",
-            "config": head["config"],
-            "roofline": head["roofline"],
-            "blocks": head["blocks"],
-            "blocks_ms_per_step": head["blocks_ms_per_step"],
-            "launches_total": launches[0],
-            "launcher": "self" if os.environ.get("KOFFT_BENCH_LAUNCHED") else ("torchrun" if world > 1 else "single"),
-            **({"rehearsal": "every rank on cuda:0, gloo process group: NOT a measurement"} if args.rehearse_one_card else {}),
-        }
+        out = headline_line()
         if allgather is not None:
             out["allgather"] = allgather
         if extras:
