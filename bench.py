@@ -479,6 +479,8 @@ def measure(w: Workload, steps, warmup, ramp_ms, min_seconds, dev, stream, barri
 
 
 def run_rank(args) -> None:
+    # under torchrun nothing has set this for us; it must be in the environment before the HIP runtime starts
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this host driver
     import numpy as np
     import torch
     import torch.distributed as dist
