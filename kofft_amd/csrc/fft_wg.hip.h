@@ -678,6 +678,9 @@ constexpr bool wg_split_lds()
     return IO::kSplitLds || (EPI == 0 && !IO::kSlotMinor && sizeof(T) == 4 && L == 14);
 }
 
+#ifndef KOFFT_RFFT_CHUNK_STORE
+#define KOFFT_RFFT_CHUNK_STORE 1
+#endif
 template <typename T, int L, int RL, int BLOCK, int EPI, class IO>
 __global__ __launch_bounds__(BLOCK, (IO::kMinWaves > 1 && BLOCK == 512 && L >= 9 && L <= 11) ? IO::kMinWaves : (wg_split_lds<T, L, EPI, IO>() && !IO::kSplitLds ? 2 : 1)) void fft_wg_kernel(const IO io, const cpx<T> *__restrict__ tw, const size_t batch)
 {
@@ -787,7 +790,38 @@ __global__ __launch_bounds__(BLOCK, (IO::kMinWaves > 1 && BLOCK == 512 && L >= 9
 #pragma unroll
         for (int u = 0; u < R; ++u) buf[lds_pad(GL::out_index(tau, u))] = v[u];
         __syncthreads();
-        if (active) {
+        // (measured per case, same box: f64 n = 64 0.67 -> 0.80, n = 128 0.74 -> 0.79; f64 n = 256 and f32 n = 128 / 256 no change,
+        // f64 n = 512 0.71 -> 0.63: only the first two take this route)
+        if constexpr (KOFFT_RFFT_CHUNK_STORE && XPB >= 4 && sizeof(T) == 8 && N <= 64 && !SPLIT) {
+            // Short rows (N + 1 <= 257 values, several transforms per workgroup): the workgroup's XPB output rows are ONE
+            // contiguous piece of memory.  X goes back into the (now free) LDS rows and the piece is written in memory order
+            // by all threads -- whole lines whatever the row length, instead of XPB misaligned row tails per store.
+            cpx<T> xo[R];
+            const cpx<T> y0 = buf[lds_pad(0)];
+#pragma unroll
+            for (int g = 0; g < R; ++g) {
+                const int k = tau + g * TPT;
+                const int kc = k < 1 ? 1 : k;  // LDS addressing only
+                const cpx<T> p = io.post_w(io.rtab[k], buf[lds_pad(kc)], buf[lds_pad(N - kc)]);
+                xo[g] = (k == 0) ? mk<T>(y0.re + y0.im, T(0)) : p;
+            }
+            __syncthreads();  // every Y has been read
+#pragma unroll
+            for (int g = 0; g < R; ++g) buf[tau + g * TPT] = xo[g];
+            if (tau == 0) buf[N] = mk<T>(y0.re - y0.im, T(0));
+            __syncthreads();
+            const size_t row0 = blk * XPB;
+            if (row0 < batch) {
+                const size_t rows = batch - row0 < (size_t)XPB ? batch - row0 : (size_t)XPB;
+                const int total = (int)rows * (N + 1);
+                cpx<T> *ochunk = io.out + row0 * (size_t)(N + 1);
+                const cpx<T> *all = reinterpret_cast<const cpx<T> *>(smem_raw);
+                for (int e = tid; e < total; e += BLOCK) {
+                    const int r = e / (N + 1), i = e - r * (N + 1);
+                    st_stream(ochunk + e, all[(size_t)r * lds_elems(N) + i]);
+                }
+            }
+        } else if (active) {
             // Rows are N+1 values back to back, so row xf starts `a` elements past a 128-byte line.  Lane tau of
             // store g handles k = g*TPT + tau - a: each store instruction then covers whole lines per row (see the
             // persistent kernel's epilogue; there: +8 %).  g = 0 and g = R are partial, g = R also carries X[N].
