@@ -239,7 +239,12 @@ int fft_big_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t ba
         BigRowsIO<T, INVERSE> b{last_in, dst, LP, L3, L - L3, L - 1 - LP, n, scale, big_rows_per_wg<T>(L3) * sizeof(cpx<T>) >= 64};
         // an intermediate small enough to stay in the 256 MiB Infinity Cache is read with plain loads (measured on a
         // copy model, tools/ubench_mall: streaming hints on the caller's buffers only, 3.1 -> 2.5 ms per 2 x 4 GiB)
-        b.nt_load = ctx->big_mid_nt >= 0 ? ctx->big_mid_nt != 0 : nb * xf_bytes > (size_t(192) << 20);
+        // ... and only where a wavefront's load instruction covers at least half a line per row: with 16-row c32 tiles (rows up
+        // to 2^9 points) a load is sixteen 32-byte pieces, the rest of each line is wanted by the neighbouring wavefronts a
+        // moment later, and a streaming load does not keep it for them (measured, 2 GiB batches: c32 2^15..2^18 0.275-0.295 ->
+        // 0.304-0.314 with plain loads, 2^22 0.190 -> 0.198; c32 2^19..2^21 and every c64 size lose 3-10 % without the hint).
+        const size_t load_piece = (size_t)(64 / big_rows_per_wg<T>(L3)) * sizeof(cpx<T>);
+        b.nt_load = ctx->big_mid_nt >= 0 ? ctx->big_mid_nt != 0 : (nb * xf_bytes > (size_t(192) << 20) && load_piece >= 64);
         rc = KOFFT_ERR_UNSUPPORTED;
         if (ctx->big_persist && ctx->big_rows_resident && (nb << LP) >= (size_t)ctx->num_cus * ctx->big_persist_min_units) {
             switch (L3) {
