@@ -102,6 +102,12 @@ template <typename T, bool INVERSE>
 inline void narrow_tile_adjust(BigRowsIO<T, INVERSE> &io, size_t segment_bytes)
 {
     if (segment_bytes < 64) io.nt = false;  // streaming stores only for segments of at least half a line (as in fft_big_dev)
+    io.nt_load = false;                     // (a single transform's intermediate sits in the caches anyway)
+}
+template <typename T, bool INVERSE>
+inline void narrow_tile_adjust(BigColsIO<T, INVERSE> &io, size_t segment_bytes)
+{
+    if (segment_bytes < 64) io.nt_in_pieces = false;  // pieces of less than half a line: the neighbours want the rest
 }
 template <typename T, int LL, class IO>
 int launch_sub_one_tile(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t units)

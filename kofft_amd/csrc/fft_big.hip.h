@@ -45,12 +45,13 @@ struct BigColsIO {
     int LB;     // log2 of the column count
     int shift;  // L - LA
     size_t n;   // full transform length
+    bool nt_in_pieces = true;  // streaming loads: off for tiles narrower than half a line (narrow tiles of a single transform)
     static constexpr bool nt = false;  // the intermediate is read back by the next factor: plain stores
     __device__ __forceinline__ TwSubFirst tw_map(size_t) const { return TwSubFirst{shift}; }
     // tile forms (fft_tile_persist_kernel): local index i of unit xf lives at  transform(xf) * n + off(xf) + (i << sl)
     static constexpr bool kConjIn = INVERSE, kConjScaleOut = false, kNtOut = false;
     static constexpr bool kTileInvariantTw = true;  // no frequency prefix yet: every tile uses the same 2^(L_sub-1) table entries
-    __device__ __forceinline__ bool nt_in() const { return true; }
+    __device__ __forceinline__ bool nt_in() const { return nt_in_pieces; }
     __device__ __forceinline__ T out_scale() const { return T(1); }
     __device__ __forceinline__ size_t xf_transform(size_t xf) const { return xf >> LB; }
     __device__ __forceinline__ unsigned in_off(size_t xf) const { return (unsigned)(xf & ((size_t(1) << LB) - 1)); }
@@ -60,7 +61,8 @@ struct BigColsIO {
     __device__ __forceinline__ cpx<T> load(size_t xf, int c) const
     {
         const size_t b = xf >> LB, j = xf & ((size_t(1) << LB) - 1);
-        cpx<T> v = ld_stream(in + b * n + ((size_t)c << LB) + j);  // read once
+        const cpx<T> *p = in + b * n + ((size_t)c << LB) + j;
+        cpx<T> v = nt_in_pieces ? ld_stream(p) : *p;  // read once
         if (INVERSE) v.im = -v.im;  // ifft: conj on the way in (fft.rs:1163-1165)
         return v;
     }
