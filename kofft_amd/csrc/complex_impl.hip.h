@@ -204,7 +204,12 @@ int fft_big_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t ba
     // (only for batches the persistent kernels take: a single 2^21-point transform is faster as 2^10 x 2^11, 31.7 vs 33.6 us)
     const bool first11 = ctx->big_first11 && ctx->big_persist && L == 21 && !three &&
                          (batch << 10) >= (size_t)ctx->num_cus * ctx->big_persist_min_units;
-    const int L1 = three ? (L + 2) / 3 : (first11 ? 11 : L / 2);
+    const bool first_larger = (ctx->big_first_larger >= 0 ? ctx->big_first_larger != 0 : sizeof(T) == 4) && L <= 20 && ctx->big_persist &&
+                              (batch << (L - (L + 1) / 2)) >= (size_t)ctx->num_cus * ctx->big_persist_min_units;  // batches only
+    // (odd log2 n: the first factor -- the cheaper kernel: one table for all its tiles -- takes the extra bit in f32: 2^15 / 2^17 /
+    // 2^19 +1.5..3 % on the same box; c64 shows no difference and keeps the smaller first factor; a single transform
+    // -- the one-tile-per-workgroup kernels -- is faster the other way at 2^19, 14.0 vs 15.2 us, and keeps it too)
+    const int L1 = three ? (L + 2) / 3 : (first11 ? 11 : (first_larger ? (L + 1) / 2 : L / 2));
     const int L2 = three ? (L - L1 + 1) / 2 : 0;
     const int L3 = L - L1 - L2;
     const cpx<T> *tw = nullptr;

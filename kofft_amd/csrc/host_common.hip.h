@@ -39,6 +39,7 @@ struct kofft_hip_ctx {
     bool small32 = true;       // KOFFT_HIP_SMALL32=0: f32 n = 32 on the thread-group kernel instead of one thread per transform (A/B)
     bool big_first11 = true;   // KOFFT_HIP_BIG_FIRST11=0: 2^21 as 2^10 x 2^11 with the one-tile-per-workgroup kernel for the 2^11 factor (A/B)
     bool big_mid_group = true; // KOFFT_HIP_BIG_MID_GROUP=0: the middle factor reloads its table entries for every tile (A/B)
+    int big_first_larger = -1; // KOFFT_HIP_BIG_FIRST_LARGER=0/1: odd log2 n: which factor takes the extra bit (default: the first in f32)
     bool big_narrow = true;    // KOFFT_HIP_BIG_NARROW=0: full-width tiles even when they leave CUs without a workgroup (A/B)
     int big_narrow_per_cu = 1; // KOFFT_HIP_BIG_NARROW_PER_CU: workgroups per CU the narrowing aims for
     bool big_persist = true;   // KOFFT_HIP_BIG_PERSIST=0: factors on the one-tile-per-workgroup kernel (A/B measurements)

@@ -472,6 +472,7 @@ int kofft_hip_create(int device, kofft_hip_ctx **out)
     if (const char *e = getenv("KOFFT_HIP_BLUESTEIN_FUSED")) ctx->blue_fused = !(e[0] == '0');
     if (const char *e = getenv("KOFFT_HIP_BLUESTEIN_ONE")) ctx->blue_one_kernel = !(e[0] == '0');
     if (const char *e = getenv("KOFFT_HIP_BIG_NARROW")) ctx->big_narrow = !(e[0] == '0');
+    if (const char *e = getenv("KOFFT_HIP_BIG_FIRST_LARGER")) ctx->big_first_larger = e[0] == '1' ? 1 : 0;
     if (const char *e = getenv("KOFFT_HIP_BIG_MID_GROUP")) ctx->big_mid_group = !(e[0] == '0');
     if (const char *e = getenv("KOFFT_HIP_BIG_FIRST11")) ctx->big_first11 = !(e[0] == '0');
     if (const char *e = getenv("KOFFT_HIP_BIG_NARROW_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 16) ctx->big_narrow_per_cu = v; }
