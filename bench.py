@@ -21,8 +21,9 @@ torch.cuda.synchronize() on both sides and reduced with MAX over ranks.  One blo
 block is repeated until --min-seconds of timed work have run (so that utilisation sampling from outside
 sees a busy GPU) and the line reports the MEDIAN block (`blocks_ms_per_step` lists all of them).
 
-One JSON line is printed by rank 0.  At N = 1 it also carries `workloads`: BASELINE configs #3, #4, #5
-measured in the same process with the same protocol (at N > 1: config #4 with its RCCL all-gather).
+One JSON line is printed by rank 0.  It also carries `workloads`: BASELINE configs #3, #4, #5 measured in the
+same processes with the same protocol (at N > 1: config #4 sharded by frames, with its RCCL all-gather timed
+apart; #3 / #5 sharded by batch, no collective) and `cpu_baseline` (rank 0's host cores).
 See DESIGN.md "Measurement" for how each field is produced.  torch is plumbing only (device memory,
 streams, torch.distributed); the transform is libkofft_hip.so.
 """
@@ -92,8 +93,41 @@ def free_port() -> int:
         return int(s.getsockname()[1])
 
 
+def profiler_preloaded() -> str | None:
+    """Name of the environment entry that shows a GPU profiler has been preloaded into this process, or None.
+
+    rocprofv3 (always with --pmc) initialises the GPU from its preloaded library before Python starts, so this process
+    must not start another program: on this pool an exec from a GPU-initialised process takes the machine down."""
+    for key, val in os.environ.items():
+        low = (key + "=" + val).lower()
+        if key == "LD_PRELOAD" and any(t in low for t in ("rocprof", "roctracer", "roctx", "rocprofiler")):
+            return f"LD_PRELOAD={val}"
+        if key.startswith(("ROCP_", "ROCPROF", "ROCPROFILER", "ROCTRACER", "HSA_TOOLS_LIB")):
+            return f"{key}={val}"
+    return None
+
+
+def csrc_sha16() -> str:
+    """Hash of the kernel sources: profiles/traffic_<workload>.json records the one its counters were collected with."""
+    import hashlib
+
+    h = hashlib.sha256()
+    src = ROOT / "kofft_amd" / "csrc"
+    for f in sorted(src.iterdir()):
+        if f.suffix in (".hip", ".h", ".cpp") or f.name == "Makefile":
+            h.update(f.name.encode())
+            h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def launch_ranks(n: int, argv: list[str]) -> int:
     """Start n children of this script, one per GPU.  The parent makes no GPU call (it never imports torch)."""
+    prof = profiler_preloaded()
+    if prof is not None:
+        sys.stderr.write(f"bench.py launcher: refusing to start {n} rank processes from a profiled process ({prof}): the profiler's "
+                         "preloaded library has already initialised the GPU here.  Profile ONE rank (`--gpus 1`, the default); "
+                         "a multi-rank run goes through `python bench.py --gpus N` or torchrun, unprofiled.\n")
+        return 2
     port = free_port()
     procs = []
     for r in range(n):
@@ -370,6 +404,39 @@ class Workload:
             self._gather = (frames_total, win_len, count, dst)
         self._keep = (src, dst) if name != "stft1024" else (sig, win, dst)
 
+    def shard_kernel_ms(self, fft32, stream, dev, worlds=(1, 2, 4, 8), reps=200):
+        """Kernel time of rank 0's frame shard for each world size, on THIS one GPU: what compute-only strong scaling of
+        config #4 can be at best (14 063 frames at 8 GPUs are ~23 us of kernel: the ~4 us dispatch floor and the ramp of a
+        persistent kernel show here first).  Back-to-back launches between two HIP events on the launch stream."""
+        import torch
+
+        from kofft_amd.dist import shard_range
+
+        frames_total, win_len, _, dst = self._gather
+        sig, win, _ = self._keep
+        hop = self.cfg["hop"]
+        out = {}
+        for g in worlds:
+            f0, f1 = shard_range(frames_total, 0, g)
+            call = lambda: fft32.stft_dev(sig.data_ptr(), sig.numel(), win.data_ptr(), win_len, hop, dst.data_ptr(), f0, f1 - f0)  # noqa: E731
+            for _ in range(10):
+                call()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(reps):
+                call()
+            e1.record(stream)
+            torch.cuda.synchronize(dev)
+            ms = e0.elapsed_time(e1) / reps
+            out[str(g)] = {"frames": f1 - f0, "kernel_ms": round(ms, 5),
+                           "GPoints_per_s_if_all_ranks_match": round(frames_total * win_len / (ms * 1e-3) / 1e9, 1)}
+        base = out["1"]["kernel_ms"]
+        for g in worlds:
+            out[str(g)]["compute_only_speedup"] = round(base / out[str(g)]["kernel_ms"], 2)
+        out["note"] = ("rank 0's shard of config #4 timed on one GPU, back-to-back launches: a PREDICTION of compute-only strong "
+                       "scaling, not a multi-GPU measurement; the all-gather (SURVEY 8e: ~0.75 ms direct) is on top")
+        return out
+
     def time_allgather(self, dist, dev, world, barrier):
         """BASELINE config #4's exchange step (RCCL all-gather of the spectra), timed apart from the compute."""
         import torch
@@ -440,7 +507,7 @@ def measure(w: Workload, steps, warmup, ramp_ms, min_seconds, dev, stream, barri
     total_units = reduce_sum(float(w.units_per_step)) * steps
     avg_kernel_s = float(np.mean(kern_ms)) / 1e3
     achieved = w.alg_bytes / avg_kernel_s / 1e9
-    traffic, traffic_from = None, None
+    traffic, traffic_from, traffic_stale = None, None, None
     tfile = ROOT / "profiles" / f"traffic_{w.name}.json"
     if tfile.exists():
         try:
@@ -448,6 +515,12 @@ def measure(w: Workload, steps, warmup, ramp_ms, min_seconds, dev, stream, barri
             if tj.get("workload") == w.name:
                 traffic = tj.get("hbm_bytes_per_step", tj.get("hbm_bytes_per_launch"))
                 traffic_from = tj.get("from")
+                # the counters were collected with one version of the kernels: say so when the sources have changed since
+                traffic_stale = tj.get("csrc_sha16") != csrc_sha16()
+                if traffic_stale:
+                    print(f"# warning: {tfile.name} was collected with other kernel sources (csrc {tj.get('csrc_sha16')} != "
+                          f"{csrc_sha16()}): roofline.traffic may be stale -- re-run tools/profile.sh + summarize_profile.py",
+                          file=sys.stderr)
         except Exception:
             traffic = None
     if count_launches is not None:
@@ -470,6 +543,7 @@ def measure(w: Workload, steps, warmup, ramp_ms, min_seconds, dev, stream, barri
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
             "traffic_from": traffic_from,
+            "traffic_stale": traffic_stale,
             "kernel_ms_avg": avg_kernel_s * 1e3,
             "kernel_ms_min": float(np.min(kern_ms)),
             "algorithmic_bytes_per_launch": w.alg_bytes,
@@ -549,8 +623,9 @@ def run_rank(args) -> None:
     extras_on = args.extras if args.extras is not None else (args.workload == "fft4096" and not args.batch and not args.inplace)
     extra_names = []
     if extras_on:
-        extra_names = [k for k in ("rfft2048", "stft1024", "c64_2p20") if k != args.workload] if world == 1 else \
-                      [k for k in ("stft1024",) if k != args.workload]
+        # every BASELINE config at every N: #3 and #5 shard by batch with no collective (weak), #4 by frames (strong; its
+        # all-gather timed apart).  stft1024 first: should the watchdog fire during a later extra, nothing is lost but it.
+        extra_names = [k for k in ("stft1024", "rfft2048", "c64_2p20") if k != args.workload]
     # The headline exists from here on.  The extra workloads (at N > 1: the RCCL all-gather of config 4) must never cost the
     # line: if they have not finished after --extras-timeout seconds (a collective that hangs cannot be caught as an
     # exception), rank 0 prints the headline alone and the process ends -- still exactly one JSON line.
@@ -589,6 +664,8 @@ def run_rank(args) -> None:
             r["steps"] = steps_e
             if name == "stft1024" and world > 1:
                 r["allgather"] = we.time_allgather(dist, dev, world, barrier)
+            if name == "stft1024" and world == 1:
+                r["shard_ms"] = we.shard_kernel_ms(fft32, stream, dev)
             extras[name] = r
             del we
         except Exception as e:  # the headline must survive a failing extra
@@ -608,10 +685,12 @@ def run_rank(args) -> None:
                 out["reference_single_transform"] = reference_single_transform(fft32, stream)
             except Exception as e:  # informational: never at the cost of the line
                 out["reference_single_transform"] = {"error": f"{type(e).__name__}: {e}"}
-        if args.workload == "fft4096" and not args.no_cpu_baseline and world == 1:
+        if args.workload == "fft4096" and not args.no_cpu_baseline:
+            # the CPU path "in the same run" (north_star): rank 0's host cores; at N > 1 the other ranks are parked in the
+            # final barrier meanwhile (their GPUs idle, the timed regions are over)
             out["cpu_baseline"] = cpu_baseline_fft4096(args.cpu_seconds)
-        elif args.workload == "fft4096" and world > 1:
-            out["cpu_baseline"] = None  # timed on rank 0 at N=1 only
+            if world > 1:
+                out["cpu_baseline"]["sample"] += f"; timed on rank 0 while the other {world - 1} ranks wait at the final barrier"
         print(json.dumps(out), flush=True)
 
     if world > 1:

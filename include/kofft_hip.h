@@ -213,36 +213,71 @@ int kofft_hip_fftnd_c32_dev(kofft_hip_ctx *ctx, float *d_data, size_t depth, siz
 int kofft_hip_fftnd_c64_dev(kofft_hip_ctx *ctx, double *d_data, size_t depth, size_t rows, size_t cols, int inverse);
 
 /* ---- multi-GPU ------------------------------------------------------
- * stft::parallel (stft.rs:232-263) runs rayon over frames; frames are the parallel unit.  The device analogue is ONE
- * process that owns `ngpu` devices (one context + one stream per device, all running concurrently): device r computes
- * the contiguous frame range [r*ceil(F/G), min((r+1)*ceil(F/G), F)) from its own slice of the host signal (slice plus the
- * win_len-hop halo, cut on the host: no halo exchange).  `allgather` != 0 adds BASELINE config #4's exchange: one RCCL
- * ncclAllGather per device (ncclCommInitAll communicators, ncclGroupStart/End, in place) after which every device holds
- * the whole spectrogram in ceil(F/G)-frame slots.  RCCL is bound at run time (dlopen); without it allgather returns
+ * stft::parallel (stft.rs:232-263) runs rayon over frames; fft::batch (fft.rs:2156-2175) and the row loop around
+ * RfftPlanner::rfft_with_scratch (rfft.rs:264-282) run over independent transforms.  The device analogue is ONE process
+ * that owns `ngpu` devices (one context + one stream per device): device r works on the contiguous block
+ * [r*ceil(U/G), min((r+1)*ceil(U/G), U)) of the U frames / transforms / rows.  STFT: from its own slice of the signal (the
+ * slice plus the win_len-hop halo, cut on the host: no halo exchange).  `allgather` != 0 adds BASELINE config #4's exchange:
+ * one RCCL ncclAllGather per device (ncclCommInitAll communicators, ncclGroupStart/End, in place) after which every device
+ * holds the whole spectrogram in ceil(F/G)-frame slots.  RCCL is bound at run time (dlopen); without it allgather returns
  * KOFFT_ERR_RCCL and everything else still works.
+ *
+ * HOST-pointer entries return when the result is in the caller's memory.  Each device has its own worker thread that
+ * uploads, launches and downloads that device's block (copies from pageable memory block the issuing thread: one thread per
+ * device is what lets the G PCIe links run together); only the grouped all-gather is issued by the calling thread.
+ * DEVICE-pointer entries (*_dev) take one device pointer per device (arrays of ngpu pointers, entry r valid on device r),
+ * enqueue on the per-device streams from the calling thread and return WITHOUT synchronising
+ * (kofft_hip_multi_synchronize, or a stream of kofft_hip_multi_context).  The calling thread's current device is left as found.
  *
  * kofft_hip_stft_f32_multi: one call, host pointers in and out; checks = stft::stft's (hop == 0 -> INVALID_HOP_SIZE,
  * frames < ceil(len/hop) -> MISMATCHED_LENGTHS, win_len == 0 -> EMPTY_INPUT), ngpu <= 0 -> INVALID_VALUE.
- * out: frames * win_len complex.  The handle form keeps contexts, buffers and communicators across calls:
+ * out: frames * win_len complex.  The handle form keeps contexts, buffers, threads and communicators across calls:
  *   kofft_hip_multi_create(ngpu, devices (NULL: 0..ngpu-1), &m)
  *   kofft_hip_multi_stft_f32(m, ..., out (host or NULL), frames, allgather, d_out_per_gpu (NULL or ngpu slots))
  *     d_out_per_gpu[r] receives device r's buffer (owned by m, valid until the next call): its shard, or with allgather
  *     the gathered [G*ceil(F/G), win_len] spectrogram (first `frames` rows are the STFT, the rest zero).
+ *   kofft_hip_multi_stft_f32_dev(m, d_signal_per_gpu, len, d_window_per_gpu, win_len, hop, frames, allgather, d_out_per_gpu)
+ *     device r holds ITS SLICE of the `len`-sample signal, kofft_hip_multi_stft_slice(m, len, win_len, hop, frames, r, &first,
+ *     &count) samples starting at sample `first` (an empty slice may be NULL), and a copy of the window.  d_out_per_gpu is
+ *     in/out: a non-NULL entry is the caller's buffer for device r (count_r * win_len complex, or G*ceil(F/G)*win_len with
+ *     allgather); a NULL entry is replaced by a buffer owned by m.
+ *   kofft_hip_multi_fft_c32 / _c64: fft::batch with the batch in G contiguous blocks, in place, no exchange;
+ *   kofft_hip_multi_rfft_f32: rows of n reals -> rows of n/2+1 complex, optional window (BASELINE config #3's shape);
+ *   their *_dev twins: d_*_per_gpu[r] points at device r's block of kofft_hip_multi_shard(m, batch, r, ..) rows.
  *   kofft_hip_multi_shard(m, total, rank, &first, &count): the partition above, for callers that place their own data.
- *   kofft_hip_multi_last_timing: slowest device's upload+kernel time and the gather time of the last call (HIP events).
- *   kofft_hip_multi_fft_c32: fft::batch (fft.rs:2156-2175) with the batch in G contiguous blocks, no exchange. */
+ *   kofft_hip_multi_context(m, rank, &ctx, &hip_stream): device r's context and stream (either may be NULL), to order
+ *     caller work against the handle's or to call any single-device entry on that device.
+ *   kofft_hip_multi_last_timing_ex: the slowest device's time in each phase of the last call, from HIP events on the
+ *     per-device streams: upload (host forms), kernel (kernels only -- no copy inside), gather, download (host forms), and
+ *     the host forms' wall time from entry to return.  Waits for a *_dev call's events.  Phases a call did not have are 0.
+ *   kofft_hip_multi_last_timing (round-2 signature): compute_ms = kernel_ms above, gather_ms. */
 typedef struct kofft_hip_multi kofft_hip_multi;
 int kofft_hip_multi_create(int ngpu, const int *devices, kofft_hip_multi **out);
 int kofft_hip_multi_destroy(kofft_hip_multi *m);
 const char *kofft_hip_multi_last_error(const kofft_hip_multi *m);
 int kofft_hip_multi_ngpu(const kofft_hip_multi *m);
 int kofft_hip_multi_shard(const kofft_hip_multi *m, size_t total, int rank, size_t *first, size_t *count);
+int kofft_hip_multi_stft_slice(const kofft_hip_multi *m, size_t len, size_t win_len, size_t hop, size_t frames, int rank,
+                               size_t *first_sample, size_t *count);
+int kofft_hip_multi_context(const kofft_hip_multi *m, int rank, kofft_hip_ctx **ctx, void **hip_stream);
+int kofft_hip_multi_synchronize(kofft_hip_multi *m);
 int kofft_hip_multi_last_timing(const kofft_hip_multi *m, float *compute_ms, float *gather_ms);
+int kofft_hip_multi_last_timing_ex(const kofft_hip_multi *m, float *upload_ms, float *kernel_ms, float *gather_ms,
+                                   float *download_ms, float *wall_ms);
 int kofft_hip_multi_stft_f32(kofft_hip_multi *m, const float *signal, size_t len, const float *window, size_t win_len,
                              size_t hop, float *out, size_t frames, int allgather, float **d_out_per_gpu);
+int kofft_hip_multi_stft_f32_dev(kofft_hip_multi *m, const float *const *d_signal_per_gpu, size_t len,
+                                 const float *const *d_window_per_gpu, size_t win_len, size_t hop, size_t frames, int allgather,
+                                 float **d_out_per_gpu);
 int kofft_hip_stft_f32_multi(int ngpu, const float *signal, size_t len, const float *window, size_t win_len,
                              size_t hop, float *out, size_t frames, int allgather);
 int kofft_hip_multi_fft_c32(kofft_hip_multi *m, float *data, size_t n, size_t batch, int inverse);
+int kofft_hip_multi_fft_c64(kofft_hip_multi *m, double *data, size_t n, size_t batch, int inverse);
+int kofft_hip_multi_rfft_f32(kofft_hip_multi *m, const float *in, float *out, const float *window, size_t n, size_t batch);
+int kofft_hip_multi_fft_c32_dev(kofft_hip_multi *m, float *const *d_data_per_gpu, size_t n, size_t batch, int inverse);
+int kofft_hip_multi_fft_c64_dev(kofft_hip_multi *m, double *const *d_data_per_gpu, size_t n, size_t batch, int inverse);
+int kofft_hip_multi_rfft_f32_dev(kofft_hip_multi *m, const float *const *d_in_per_gpu, float *const *d_out_per_gpu,
+                                 const float *const *d_window_per_gpu, size_t n, size_t batch);
 
 #ifdef __cplusplus
 }

@@ -496,9 +496,70 @@ public:
         for (size_t f = 0; f < frames; ++f) output[f].assign(flat.begin() + f * wl, flat.begin() + (f + 1) * wl);
         return Result::Ok();
     }
+    // fft::batch (fft.rs:2156-2175) over a contiguous batch, in G contiguous blocks, no exchange
+    Result fft_batch(std::vector<Complex32> &data, size_t n, bool inverse = false)
+    {
+        return st(kofft_hip_multi_fft_c32(h_, reinterpret_cast<float *>(data.data()), n, n ? data.size() / n : 0, inverse ? 1 : 0));
+    }
+    Result fft_batch(std::vector<Complex64> &data, size_t n, bool inverse = false)
+    {
+        return st(kofft_hip_multi_fft_c64(h_, reinterpret_cast<double *>(data.data()), n, n ? data.size() / n : 0, inverse ? 1 : 0));
+    }
+    // rfft_direct (rfft.rs:425-465) on every row of n reals, optional window product first (BASELINE config #3's shape)
+    Result rfft_batch(const std::vector<float> &rows, size_t n, std::vector<Complex32> &out, const std::vector<float> *window = nullptr)
+    {
+        const size_t batch = n ? rows.size() / n : 0;
+        if (window && window->size() != n) return Result::Err(FftError::MismatchedLengths);
+        out.resize(batch * (n / 2 + 1));
+        return st(kofft_hip_multi_rfft_f32(h_, rows.data(), reinterpret_cast<float *>(out.data()), window ? window->data() : nullptr, n, batch));
+    }
+    // device-resident twins (one device pointer per device, asynchronous): thin pass-throughs
+    Result fft_dev(float *const *d_data, size_t n, size_t batch, bool inverse = false)
+    {
+        return st(kofft_hip_multi_fft_c32_dev(h_, d_data, n, batch, inverse ? 1 : 0));
+    }
+    Result fft_dev(double *const *d_data, size_t n, size_t batch, bool inverse = false)
+    {
+        return st(kofft_hip_multi_fft_c64_dev(h_, d_data, n, batch, inverse ? 1 : 0));
+    }
+    Result rfft_dev(const float *const *d_in, float *const *d_out, const float *const *d_window, size_t n, size_t batch)
+    {
+        return st(kofft_hip_multi_rfft_f32_dev(h_, d_in, d_out, d_window, n, batch));
+    }
+    Result stft_dev(const float *const *d_signal, size_t len, const float *const *d_window, size_t win_len, size_t hop, size_t frames,
+                    bool allgather, float **d_out)
+    {
+        return st(kofft_hip_multi_stft_f32_dev(h_, d_signal, len, d_window, win_len, hop, frames, allgather ? 1 : 0, d_out));
+    }
+    std::pair<size_t, size_t> shard(size_t total, int rank) const
+    {
+        size_t f = 0, c = 0;
+        kofft_hip_multi_shard(h_, total, rank, &f, &c);
+        return {f, c};
+    }
+    std::pair<size_t, size_t> stft_slice(size_t len, size_t win_len, size_t hop, size_t frames, int rank) const
+    {
+        size_t f = 0, c = 0;
+        kofft_hip_multi_stft_slice(h_, len, win_len, hop, frames, rank, &f, &c);
+        return {f, c};
+    }
+    void synchronize() { (void)st(kofft_hip_multi_synchronize(h_)); }
+    struct Timing { float upload_ms = 0, kernel_ms = 0, gather_ms = 0, download_ms = 0, wall_ms = 0; };
+    Timing last_timing() const
+    {
+        Timing t;
+        kofft_hip_multi_last_timing_ex(h_, &t.upload_ms, &t.kernel_ms, &t.gather_ms, &t.download_ms, &t.wall_ms);
+        return t;
+    }
     kofft_hip_multi *raw() const { return h_; }
 
 private:
+    Result st(int rc) const
+    {
+        if (rc > 0) return Result::Err(static_cast<FftError>(rc));
+        if (rc != 0) throw DeviceError(rc, kofft_hip_multi_last_error(h_));
+        return Result::Ok();
+    }
     kofft_hip_multi *h_ = nullptr;
 };
 

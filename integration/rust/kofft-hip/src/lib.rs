@@ -46,6 +46,33 @@ extern "C" {
                                 hop: usize, out: *mut f32, frames: usize, allgather: c_int, d_out_per_gpu: *mut *mut f32) -> c_int;
     fn kofft_hip_stft_f32_multi(ngpu: c_int, signal: *const f32, len: usize, window: *const f32, win_len: usize, hop: usize,
                                 out: *mut f32, frames: usize, allgather: c_int) -> c_int;
+    fn kofft_hip_multi_fft_c32(m: *mut KofftHipMulti, data: *mut f32, n: usize, batch: usize, inverse: c_int) -> c_int;
+    fn kofft_hip_multi_fft_c64(m: *mut KofftHipMulti, data: *mut f64, n: usize, batch: usize, inverse: c_int) -> c_int;
+    fn kofft_hip_multi_rfft_f32(m: *mut KofftHipMulti, input: *const f32, out: *mut f32, window: *const f32, n: usize, batch: usize) -> c_int;
+    fn kofft_hip_multi_shard(m: *const KofftHipMulti, total: usize, rank: c_int, first: *mut usize, count: *mut usize) -> c_int;
+    fn kofft_hip_multi_stft_slice(m: *const KofftHipMulti, len: usize, win_len: usize, hop: usize, frames: usize, rank: c_int,
+                                  first_sample: *mut usize, count: *mut usize) -> c_int;
+    fn kofft_hip_multi_synchronize(m: *mut KofftHipMulti) -> c_int;
+    fn kofft_hip_multi_last_timing_ex(m: *const KofftHipMulti, upload_ms: *mut f32, kernel_ms: *mut f32, gather_ms: *mut f32,
+                                      download_ms: *mut f32, wall_ms: *mut f32) -> c_int;
+    // device-resident twins: one device pointer per device, asynchronous
+    fn kofft_hip_multi_fft_c32_dev(m: *mut KofftHipMulti, d_data_per_gpu: *const *mut f32, n: usize, batch: usize, inverse: c_int) -> c_int;
+    fn kofft_hip_multi_fft_c64_dev(m: *mut KofftHipMulti, d_data_per_gpu: *const *mut f64, n: usize, batch: usize, inverse: c_int) -> c_int;
+    fn kofft_hip_multi_rfft_f32_dev(m: *mut KofftHipMulti, d_in_per_gpu: *const *const f32, d_out_per_gpu: *const *mut f32,
+                                    d_window_per_gpu: *const *const f32, n: usize, batch: usize) -> c_int;
+    fn kofft_hip_multi_stft_f32_dev(m: *mut KofftHipMulti, d_signal_per_gpu: *const *const f32, len: usize,
+                                    d_window_per_gpu: *const *const f32, win_len: usize, hop: usize, frames: usize, allgather: c_int,
+                                    d_out_per_gpu: *mut *mut f32) -> c_int;
+}
+
+/// Slowest device's time in each phase of the last multi-GPU call (HIP events), milliseconds; absent phases are 0.
+#[derive(Debug, Default, Clone, Copy)]
+pub struct MultiTiming {
+    pub upload_ms: f32,
+    pub kernel_ms: f32,
+    pub gather_ms: f32,
+    pub download_ms: f32,
+    pub wall_ms: f32,
 }
 
 #[repr(C)]
@@ -310,6 +337,83 @@ impl HipMulti {
             panic!("kofft-hip multi-GPU error {rc}: {msg}");
         }
         status(core::ptr::null(), rc)
+    }
+
+    fn check(&self, rc: c_int) -> Result<(), FftError> {
+        if rc < 0 {
+            let msg = unsafe { std::ffi::CStr::from_ptr(kofft_hip_multi_last_error(self.h)) }.to_string_lossy().into_owned();
+            panic!("kofft-hip multi-GPU error {rc}: {msg}");
+        }
+        status(core::ptr::null(), rc)
+    }
+
+    /// `fft::batch` (fft.rs:2156-2175) over `batch` contiguous transforms of length `n`, the batch in G contiguous blocks.
+    pub fn fft_batch_c32(&self, data: &mut [Complex32], n: usize, inverse: bool) -> Result<(), FftError> {
+        let batch = if n == 0 { 0 } else { data.len() / n };
+        self.check(unsafe { kofft_hip_multi_fft_c32(self.h, data.as_mut_ptr() as *mut f32, n, batch, inverse as c_int) })
+    }
+    pub fn fft_batch_c64(&self, data: &mut [Complex64], n: usize, inverse: bool) -> Result<(), FftError> {
+        let batch = if n == 0 { 0 } else { data.len() / n };
+        self.check(unsafe { kofft_hip_multi_fft_c64(self.h, data.as_mut_ptr() as *mut f64, n, batch, inverse as c_int) })
+    }
+    /// `rfft_direct` (rfft.rs:425-465) on every row of `n` reals (optional window product first), rows sharded over the devices.
+    pub fn rfft_batch(&self, input: &[f32], out: &mut [Complex32], window: Option<&[f32]>, n: usize) -> Result<(), FftError> {
+        let batch = if n == 0 { 0 } else { input.len() / n };
+        if out.len() != batch * (n / 2 + 1) || window.map_or(false, |w| w.len() != n) {
+            return Err(FftError::MismatchedLengths);
+        }
+        let w = window.map_or(core::ptr::null(), |w| w.as_ptr());
+        self.check(unsafe { kofft_hip_multi_rfft_f32(self.h, input.as_ptr(), out.as_mut_ptr() as *mut f32, w, n, batch) })
+    }
+    /// (first, count) of the `total` units device `rank` owns.
+    pub fn shard(&self, total: usize, rank: usize) -> (usize, usize) {
+        let (mut f, mut c) = (0usize, 0usize);
+        unsafe { kofft_hip_multi_shard(self.h, total, rank as c_int, &mut f, &mut c) };
+        (f, c)
+    }
+    /// (first_sample, count) of the signal slice device `rank` needs for its frames (block + halo).
+    pub fn stft_slice(&self, len: usize, win_len: usize, hop: usize, frames: usize, rank: usize) -> (usize, usize) {
+        let (mut f, mut c) = (0usize, 0usize);
+        unsafe { kofft_hip_multi_stft_slice(self.h, len, win_len, hop, frames, rank as c_int, &mut f, &mut c) };
+        (f, c)
+    }
+    /// Device-resident forms: `d_*[r]` is a pointer valid on device r; asynchronous, `synchronize()` waits.
+    ///
+    /// # Safety
+    /// The pointers must be device allocations of the sizes include/kofft_hip.h states for each entry.
+    pub unsafe fn fft_c32_dev(&self, d_data: &[*mut f32], n: usize, batch: usize, inverse: bool) -> Result<(), FftError> {
+        self.check(kofft_hip_multi_fft_c32_dev(self.h, d_data.as_ptr(), n, batch, inverse as c_int))
+    }
+    /// # Safety
+    /// As `fft_c32_dev`.
+    pub unsafe fn fft_c64_dev(&self, d_data: &[*mut f64], n: usize, batch: usize, inverse: bool) -> Result<(), FftError> {
+        self.check(kofft_hip_multi_fft_c64_dev(self.h, d_data.as_ptr(), n, batch, inverse as c_int))
+    }
+    /// # Safety
+    /// As `fft_c32_dev`.
+    pub unsafe fn rfft_dev(&self, d_in: &[*const f32], d_out: &[*mut f32], d_window: Option<&[*const f32]>, n: usize, batch: usize)
+        -> Result<(), FftError> {
+        let w = d_window.map_or(core::ptr::null(), |w| w.as_ptr());
+        self.check(kofft_hip_multi_rfft_f32_dev(self.h, d_in.as_ptr(), d_out.as_ptr(), w, n, batch))
+    }
+    /// `d_out[r]` null on entry = a buffer owned by the handle is used and written back into the slice.
+    ///
+    /// # Safety
+    /// As `fft_c32_dev`.
+    pub unsafe fn stft_dev(&self, d_signal: &[*const f32], len: usize, d_window: &[*const f32], win_len: usize, hop: usize,
+                           frames: usize, allgather: bool, d_out: &mut [*mut f32]) -> Result<(), FftError> {
+        self.check(kofft_hip_multi_stft_f32_dev(self.h, d_signal.as_ptr(), len, d_window.as_ptr(), win_len, hop, frames,
+                                                allgather as c_int, d_out.as_mut_ptr()))
+    }
+    pub fn synchronize(&self) -> Result<(), FftError> {
+        self.check(unsafe { kofft_hip_multi_synchronize(self.h) })
+    }
+    pub fn last_timing(&self) -> MultiTiming {
+        let mut t = MultiTiming::default();
+        unsafe {
+            kofft_hip_multi_last_timing_ex(self.h, &mut t.upload_ms, &mut t.kernel_ms, &mut t.gather_ms, &mut t.download_ms, &mut t.wall_ms)
+        };
+        t
     }
 }
 

@@ -82,6 +82,18 @@ SIGNATURES = {
     "kofft_hip_multi_stft_f32": (C.c_int, [_ctx, C.c_void_p, _sz, C.c_void_p, _sz, _sz, C.c_void_p, _sz, C.c_int, C.POINTER(C.c_void_p)]),
     "kofft_hip_stft_f32_multi": (C.c_int, [C.c_int, C.c_void_p, _sz, C.c_void_p, _sz, _sz, C.c_void_p, _sz, C.c_int]),
     "kofft_hip_multi_fft_c32": (C.c_int, [_ctx, C.c_void_p, _sz, _sz, C.c_int]),
+    "kofft_hip_multi_fft_c64": (C.c_int, [_ctx, C.c_void_p, _sz, _sz, C.c_int]),
+    "kofft_hip_multi_rfft_f32": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p, _sz, _sz]),
+    # device-resident twins: arrays of ngpu device pointers, asynchronous
+    "kofft_hip_multi_fft_c32_dev": (C.c_int, [_ctx, C.POINTER(C.c_void_p), _sz, _sz, C.c_int]),
+    "kofft_hip_multi_fft_c64_dev": (C.c_int, [_ctx, C.POINTER(C.c_void_p), _sz, _sz, C.c_int]),
+    "kofft_hip_multi_rfft_f32_dev": (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _sz, _sz]),
+    "kofft_hip_multi_stft_f32_dev": (C.c_int, [_ctx, C.POINTER(C.c_void_p), _sz, C.POINTER(C.c_void_p), _sz, _sz, _sz, C.c_int,
+                                               C.POINTER(C.c_void_p)]),
+    "kofft_hip_multi_stft_slice": (C.c_int, [_ctx, _sz, _sz, _sz, _sz, C.c_int, C.POINTER(_sz), C.POINTER(_sz)]),
+    "kofft_hip_multi_context": (C.c_int, [_ctx, C.c_int, C.POINTER(_ctx), C.POINTER(C.c_void_p)]),
+    "kofft_hip_multi_synchronize": (C.c_int, [_ctx]),
+    "kofft_hip_multi_last_timing_ex": (C.c_int, [_ctx] + [C.POINTER(C.c_float)] * 5),
 }
 
 _lib = None

@@ -144,7 +144,8 @@ int launch_sub(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, int LS, size_
             KOFFT_CASE(9)
             KOFFT_CASE(10)
 #undef KOFFT_CASE
-        case 11:  // c32 only: 8 columns x 2^11 points at 1024 threads (c64 would need 2 x 64 data registers per thread at 128)
+        case 11:  // first factor of 2^21 = 2^11 x 2^10: c32 8 columns at 1024 threads, c64 4 columns at 512 threads (both measured, DESIGN 5.3;
+                  // parity: test_large_n_persistent_factor_kernels c32 (21, 11) and c64 (21, 9))
             if constexpr (IO::kTileInvariantTw) {
                 if (ctx->big_first11) return launch_tile_persist<T, 11, IO>(ctx, io, tw, units);
             }

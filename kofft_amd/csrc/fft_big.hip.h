@@ -694,17 +694,19 @@ struct StridedIO {
 
 // ---- tiled transpose for the long strided axes of ndfft ------------------------------------------------------------
 // dst[b][c][r] = src[b][r][c] for r < rows, c < cols: 32 x 32 tiles through LDS (row padded by one cell), both sides
-// coalesced.  Leading dimensions and per-batch strides in elements.
+// coalesced.  Leading dimensions and per-batch strides in elements.  The tile grid is flattened onto grid.x
+// (tile = blockIdx.x: column tile fastest): either side of a panel can be millions of elements long (a 3 x 2^22 transform, an
+// axis of 2^22 points), far beyond the 65535 of grid.y, while the panel as a whole is at most 2^27 elements.
 template <typename T>
 __global__ __launch_bounds__(256) void transpose_kernel(const cpx<T> *__restrict__ src, cpx<T> *__restrict__ dst, const size_t rows,
                                                         const size_t cols, const size_t src_ld, const size_t dst_ld,
-                                                        const size_t src_bs, const size_t dst_bs)
+                                                        const size_t src_bs, const size_t dst_bs, const unsigned col_tiles)
 {
     __shared__ cpx<T> tile[32][33];
-    const size_t b = blockIdx.z;
+    const size_t b = blockIdx.y;
     const cpx<T> *s = src + b * src_bs;
     cpx<T> *d = dst + b * dst_bs;
-    const size_t c0 = (size_t)blockIdx.x * 32, r0 = (size_t)blockIdx.y * 32;
+    const size_t c0 = (size_t)(blockIdx.x % col_tiles) * 32, r0 = (size_t)(blockIdx.x / col_tiles) * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
 #pragma unroll
     for (int k = 0; k < 32; k += 8) {

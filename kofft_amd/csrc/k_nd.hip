@@ -40,15 +40,17 @@ int fft_axis_dev(kofft_hip_ctx *ctx, T *d_data, size_t len, size_t lines, size_t
             for (size_t p0 = 0; p0 < inner; p0 += P) {
                 const size_t pw = (inner - p0 < P) ? inner - p0 : P;
                 cpx<T> *blk = data + o0 * outer_stride + p0;
-                dim3 g1((unsigned)((pw + 31) / 32), (unsigned)((len + 31) / 32), (unsigned)og);
+                // (tile grid flattened onto grid.x: pw * len <= 2^27 elements bounds the product, not either side)
+                const unsigned pt = (unsigned)((pw + 31) / 32), lt = (unsigned)((len + 31) / 32);
+                dim3 g1(pt * lt, (unsigned)og);
                 hipLaunchKernelGGL(transpose_kernel<T>, g1, dim3(256), 0, ctx->stream, blk, panel, len, pw, inner, len, outer_stride,
-                                   pw * len);
+                                   pw * len, pt);
                 KOFFT_HIP_TRY(ctx, hipGetLastError());
                 int rc = fft_dev<T>(ctx, reinterpret_cast<T *>(panel), reinterpret_cast<T *>(panel), len, og * pw, inverse);
                 if (rc) return rc;
-                dim3 g2((unsigned)((len + 31) / 32), (unsigned)((pw + 31) / 32), (unsigned)og);
+                dim3 g2(lt * pt, (unsigned)og);
                 hipLaunchKernelGGL(transpose_kernel<T>, g2, dim3(256), 0, ctx->stream, panel, blk, pw, len, len, inner, pw * len,
-                                   outer_stride);
+                                   outer_stride, lt);
                 KOFFT_HIP_TRY(ctx, hipGetLastError());
             }
         }

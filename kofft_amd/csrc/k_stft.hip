@@ -109,7 +109,7 @@ int stft_mag_dev(kofft_hip_ctx *ctx, const float *d_samples, size_t len, size_t 
                  size_t frames, float *d_max)
 {
     if (hop == 0) return KOFFT_ERR_INVALID_HOP_SIZE;  // the reference divides by hop (div_ceil) and would panic
-    const size_t required = (len + hop - 1) / hop;
+    const size_t required = len / hop + (len % hop != 0);
     if (frames < required) return KOFFT_ERR_MISMATCHED_LENGTHS;
     if (frames > 0 && win_len == 0) return KOFFT_ERR_EMPTY_INPUT;
     if (frames > 0 && !complex_len_ok(win_len)) return KOFFT_ERR_UNSUPPORTED;

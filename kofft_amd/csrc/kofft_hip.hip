@@ -668,7 +668,7 @@ int kofft_hip_stft_f32(kofft_hip_ctx *ctx, const float *signal, size_t len, cons
                        size_t hop, float *out, size_t frames)
 {
     if (hop == 0) return KOFFT_ERR_INVALID_HOP_SIZE;               // stft.rs:83
-    const size_t required = (len + hop - 1) / hop;                  // stft.rs:86
+    const size_t required = len / hop + (len % hop != 0);                  // stft.rs:86
     if (frames < required) return KOFFT_ERR_MISMATCHED_LENGTHS;    // stft.rs:87
     return stft_host(ctx, signal, len, window, win_len, 0, hop, out, frames);
 }
@@ -730,7 +730,7 @@ int kofft_hip_stft_magnitudes_f32(kofft_hip_ctx *ctx, const float *samples, size
                                   float *mags, size_t frames, float *max_mag)
 {
     if (hop == 0) return KOFFT_ERR_INVALID_HOP_SIZE;
-    if (frames < (len + hop - 1) / hop) return KOFFT_ERR_MISMATCHED_LENGTHS;
+    if (frames < len / hop + (len % hop != 0)) return KOFFT_ERR_MISMATCHED_LENGTHS;
     if (frames > 0 && win_len == 0) return KOFFT_ERR_EMPTY_INPUT;
     if (frames > 0 && !complex_len_ok(win_len)) return KOFFT_ERR_UNSUPPORTED;
     if (!ctx || !max_mag || (frames && (!mags || (!samples && len)))) return KOFFT_ERR_NULL;

@@ -325,6 +325,26 @@ int main()
         std::vector<std::vector<Complex32>> few(2);
         CHECK(multi.stft(sig, window, 64, few) == Result::Err(FftError::MismatchedLengths));
         CHECK(multi.stft(sig, window, 0, b) == Result::Err(FftError::InvalidHopSize));
+        // batches and real rows shard the same way, no exchange (fft.rs:2156-2175, rfft.rs:264-282)
+        std::vector<Complex32> flat(5 * 64);
+        for (size_t i = 0; i < flat.size(); ++i) flat[i] = Complex32(std::sin(0.7f * (float)i), std::cos(0.2f * (float)i));
+        std::vector<Complex32> flat_want;
+        for (size_t r = 0; r < 5; ++r) {
+            auto w = oracle_fft(std::vector<Complex32>(flat.begin() + r * 64, flat.begin() + (r + 1) * 64));
+            flat_want.insert(flat_want.end(), w.begin(), w.end());
+        }
+        multi.fft_batch(flat, 64).unwrap();
+        CHECK(same_bits(flat, flat_want));
+        const HipMulti::Timing t = multi.last_timing();
+        CHECK(t.kernel_ms > 0.0f && t.upload_ms > 0.0f && t.download_ms > 0.0f && t.gather_ms == 0.0f);
+        std::vector<float> rows(3 * 256);
+        for (size_t i = 0; i < rows.size(); ++i) rows[i] = std::sin(0.11f * (float)i);
+        std::vector<Complex32> spec;
+        multi.rfft_batch(rows, 256, spec, &window).unwrap();
+        CHECK(spec.size() == 3 * 129);
+        std::vector<float> odd(3 * 255);
+        CHECK(multi.rfft_batch(odd, 255, spec) == Result::Err(FftError::InvalidValue));
+        CHECK(multi.shard(10, 0).first == 0 && multi.shard(10, 0).second == 10);
     }
     std::printf("%d checks, %d failed\n", g_checks, g_fail);
     return g_fail == 0 ? 0 : 1;

@@ -1,8 +1,10 @@
 """kofft_hip_stft_f32_multi / kofft_hip_multi_* on a real device.
 
-The GPU box has one card, so G = 1 here: the same code path as G = 8 (per-device context, stream, slice upload, slot
-layout, ncclCommInitAll + grouped ncclAllGather), with one rank.  The partition arithmetic for G > 1 is covered on CPU
-(tests/test_dist_gloo.py, test_multi_shard_matches_python_partition below needs a device only for the handle)."""
+The builder's GPU box has one card, so most tests run G = 1 (the same code path as G = 8: per-device context, stream,
+worker thread, slice upload, slot layout, ncclCommInitAll + grouped ncclAllGather, with one rank) or G logical devices
+mapped onto card 0 (everything but the RCCL exchange, which refuses duplicate devices).  The tests at the end are
+parametrised on the box: with >= 2 cards they run the real thing, RCCL included, without code changes.  The partition
+arithmetic for G > 1 is covered on CPU too (tests/test_dist_gloo.py)."""
 import ctypes as C
 
 import numpy as np
@@ -34,6 +36,10 @@ def test_multi_stft_matches_oracle(oracle, allgather):
     assert len(ptrs) == 1 and ptrs[0] != 0
     comp, gath = m.last_timing()
     assert comp > 0.0 and (gath > 0.0 if allgather else gath == 0.0)
+    t = m.last_timing_ex()  # phases apart: kernel_ms has no copy inside, the round-2 call reports exactly that
+    assert t["kernel_ms"] == comp and t["gather_ms"] == gath
+    assert t["upload_ms"] > 0.0 and t["download_ms"] > 0.0
+    assert t["wall_ms"] >= max(t["upload_ms"], t["kernel_ms"], t["download_ms"])
     # the handle is reusable, buffers and communicator kept
     got2 = m.stft(sig, win, hop, frames + 3, allgather=allgather)  # extra frames: zero-padded past the end (stft.rs:95-99)
     assert bits_equal(got2, oracle.stft(sig, win, hop, frames + 3))
@@ -117,4 +123,173 @@ def test_multi_partition_on_one_card(oracle, g):
     y = x.copy()
     m.fft_batch(y)
     assert bits_equal(y, oracle.fft(x))
+    m.close()
+
+
+@pytest.mark.parametrize("g", [1, 2, 5])
+def test_multi_c64_and_rfft_rows_host(oracle, g):
+    """BASELINE configs #5 and #3 at the boundary: c64 batches and windowed real rows in G contiguous blocks, no exchange
+    (fft.rs:2156-2175, rfft.rs:264-282), each block through its device's worker thread."""
+    import kofft_amd
+    from conftest import rand_c
+
+    m = kofft_amd.HipMulti(g, devices=[0] * g)
+    x = rand_c(seeded(41 + g), (2 * g + 3, 1024), np.complex128)
+    y = x.copy()
+    m.fft_batch(y)
+    assert bits_equal(y, oracle.fft(x))
+    m.fft_batch(y, inverse=True)
+    assert bits_equal(y, oracle.ifft(oracle.fft(x)))
+    t = m.last_timing_ex()
+    assert t["kernel_ms"] > 0.0 and t["upload_ms"] > 0.0 and t["download_ms"] > 0.0 and t["gather_ms"] == 0.0
+    rows = seeded(43 + g).uniform(-1, 1, (3 * g + 1, 2048)).astype(np.float32)
+    win = kofft_amd.hann(2048)
+    assert bits_equal(m.rfft_batch(rows, win), oracle.rfft(rows, win))
+    assert bits_equal(m.rfft_batch(rows), oracle.rfft(rows, None))
+    # fewer rows than devices: the tail devices own nothing
+    few = rows[: max(1, g - 1)]
+    assert bits_equal(m.rfft_batch(few, win), oracle.rfft(few, win))
+    with pytest.raises(kofft_amd.FftError) as e:
+        m.rfft_batch(rows[:, :2047])
+    assert e.value.variant == "InvalidValue"  # odd n (rfft.rs:436)
+    m.close()
+
+
+def _device_of(r, ndev):
+    return r % ndev
+
+
+@pytest.mark.parametrize("g", [1, 3])
+def test_multi_device_resident_forms(oracle, g):
+    """The *_dev twins: one device pointer per device, asynchronous, results and inputs never leave the cards.  G logical
+    devices on card 0 (G = 1 also runs the all-gather)."""
+    import torch
+
+    import kofft_amd
+    from conftest import rand_c
+
+    dev = torch.device("cuda", 0)
+    before = torch.cuda.current_device()
+    m = kofft_amd.HipMulti(g, devices=[0] * g)
+    # complex batches, f32 and f64, in place
+    for dtype, double in ((np.complex64, False), (np.complex128, True)):
+        x = rand_c(seeded(51 + g), (4 * g + 1, 512), dtype)
+        real = np.float64 if double else np.float32
+        blocks = []
+        for r in range(g):
+            first, count = m.shard(x.shape[0], r)
+            blocks.append(torch.from_numpy(x[first:first + count].view(real).copy()).to(dev))
+        torch.cuda.synchronize(dev)
+        m.fft_dev([b.data_ptr() for b in blocks], 512, x.shape[0], double=double)
+        m.synchronize()
+        got = np.concatenate([b.cpu().numpy().view(dtype) for b in blocks], axis=0)
+        assert bits_equal(got.reshape(x.shape), oracle.fft(x))
+        t = m.last_timing_ex()
+        assert t["kernel_ms"] > 0.0 and t["upload_ms"] == 0.0 and t["download_ms"] == 0.0 and t["wall_ms"] == 0.0
+    # windowed real rows
+    rows = seeded(53 + g).uniform(-1, 1, (2 * g + 1, 1024)).astype(np.float32)
+    win = kofft_amd.hann(1024)
+    dwin = torch.from_numpy(win).to(dev)
+    ins, outs = [], []
+    for r in range(g):
+        first, count = m.shard(rows.shape[0], r)
+        ins.append(torch.from_numpy(rows[first:first + count].copy()).to(dev))
+        outs.append(torch.zeros((max(count, 1), 513, 2), dtype=torch.float32, device=dev))
+    torch.cuda.synchronize(dev)
+    m.rfft_dev([t_.data_ptr() for t_ in ins], [t_.data_ptr() for t_ in outs], [dwin.data_ptr()] * g, 1024, rows.shape[0])
+    m.synchronize()
+    got = np.concatenate([outs[r].cpu().numpy().view(np.complex64).reshape(-1, 513)[: m.shard(rows.shape[0], r)[1]] for r in range(g)])
+    assert bits_equal(got, oracle.rfft(rows, win))
+    # STFT from per-device slices (block + halo); caller's output buffers for even ranks, the handle's for odd ones
+    sig = _signal(41_111, seed=9 + g)
+    w1k = kofft_amd.hann(1024)
+    hop = 256
+    frames = -(-sig.size // hop) + 1
+    want = oracle.stft(sig, w1k, hop, frames)
+    dw = torch.from_numpy(w1k).to(dev)
+    slices, mine = [], []
+    for r in range(g):
+        first, count = m.stft_slice(sig.size, 1024, hop, frames, r)
+        slices.append(torch.from_numpy(sig[first:first + count].copy()).to(dev))
+        cnt = m.shard(frames, r)[1]
+        mine.append(torch.zeros((max(cnt, 1), 1024, 2), dtype=torch.float32, device=dev) if r % 2 == 0 else None)
+    torch.cuda.synchronize(dev)
+    ptrs = m.stft_dev([t_.data_ptr() for t_ in slices], sig.size, [dw.data_ptr()] * g, 1024, hop, frames,
+                      d_out=[t_.data_ptr() if t_ is not None else 0 for t_ in mine])
+    m.synchronize()
+    assert all(p != 0 for p in ptrs)
+    for r in range(0, g, 2):
+        first, count = m.shard(frames, r)
+        assert ptrs[r] == mine[r].data_ptr()
+        assert bits_equal(mine[r].cpu().numpy().view(np.complex64).reshape(-1, 1024)[:count], want[first:first + count])
+    if g == 1:  # the exchange with one rank: gathered layout in the caller's buffer
+        full = torch.zeros((frames, 1024, 2), dtype=torch.float32, device=dev)
+        m.stft_dev([slices[0].data_ptr()], sig.size, [dw.data_ptr()], 1024, hop, frames, allgather=True, d_out=[full.data_ptr()])
+        t = m.last_timing_ex()
+        assert t["kernel_ms"] > 0.0 and t["gather_ms"] > 0.0
+        assert bits_equal(full.cpu().numpy().view(np.complex64).reshape(frames, 1024), want)
+    assert torch.cuda.current_device() == before  # the calling thread's device is left as found
+    m.close()
+
+
+def _ndev():
+    import kofft_amd
+
+    cnt = C.c_int()
+    kofft_amd.load_library().kofft_hip_device_count(C.byref(cnt))
+    return cnt.value
+
+
+def test_multi_all_cards_of_the_box_with_rccl(oracle):
+    """G = every card of the box (skipped on a one-card box): the RCCL all-gather for real, checked on EVERY device's
+    gathered buffer, host form and device form; the sharded batched forms beside it."""
+    import torch
+
+    import kofft_amd
+    from conftest import rand_c
+
+    g = _ndev()
+    if g < 2:
+        pytest.skip("one card: the RCCL exchange between devices needs at least two")
+    g = min(g, 8)
+    before = torch.cuda.current_device()
+    sig = _signal(300_007, seed=77)
+    win = kofft_amd.hann(1024)
+    hop = 256
+    frames = -(-sig.size // hop)
+    want = oracle.stft(sig, win, hop, frames)
+    per = -(-frames // g)
+    m = kofft_amd.HipMulti(g)
+    got, ptrs = m.stft(sig, win, hop, frames, allgather=True, want_device_ptrs=True)
+    assert bits_equal(got, want)
+    t = m.last_timing_ex()
+    assert t["gather_ms"] > 0.0 and t["kernel_ms"] > 0.0
+    assert all(p != 0 for p in ptrs)
+    # device form, caller's buffers: every device must end up with the whole spectrogram
+    slices, wins, outs = [], [], []
+    for r in range(g):
+        d = torch.device("cuda", r)
+        first, count = m.stft_slice(sig.size, 1024, hop, frames, r)
+        slices.append(torch.from_numpy(sig[first:first + count].copy()).to(d))
+        wins.append(torch.from_numpy(win).to(d))
+        outs.append(torch.full((g * per, 1024, 2), 7.0, dtype=torch.float32, device=d))
+    for r in range(g):
+        torch.cuda.synchronize(torch.device("cuda", r))
+    m.stft_dev([t_.data_ptr() for t_ in slices], sig.size, [t_.data_ptr() for t_ in wins], 1024, hop, frames, allgather=True,
+               d_out=[t_.data_ptr() for t_ in outs])
+    m.synchronize()
+    pad = np.zeros((g * per - frames, 1024), np.complex64)
+    for r in range(g):
+        have = outs[r].cpu().numpy().view(np.complex64).reshape(g * per, 1024)
+        assert bits_equal(have[:frames], want), f"device {r}: gathered spectrogram differs"
+        assert bits_equal(have[frames:], pad), f"device {r}: slot padding not zero"
+    # collective-free batched forms over the real devices
+    x = rand_c(seeded(79), (8 * g + 3, 4096))
+    y = x.copy()
+    m.fft_batch(y)
+    assert bits_equal(y, oracle.fft(x))
+    rows = seeded(81).uniform(-1, 1, (4 * g + 1, 2048)).astype(np.float32)
+    w2k = kofft_amd.hann(2048)
+    assert bits_equal(m.rfft_batch(rows, w2k), oracle.rfft(rows, w2k))
+    assert torch.cuda.current_device() == before
     m.close()

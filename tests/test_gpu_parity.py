@@ -412,7 +412,7 @@ def test_fft_c64_large_n(fft64, oracle, log2n, batch):
 
 
 @pytest.mark.parametrize("dtype,log2n,batch", [("c64", 20, 18), ("c64", 16, 300), ("c64", 22, 3), ("c32", 17, 200), ("c32", 20, 40),
-                                               ("c32", 22, 6), ("c64", 19, 40), ("c32", 21, 11), ("c64", 21, 5)])
+                                               ("c32", 22, 6), ("c64", 19, 40), ("c32", 21, 11), ("c64", 21, 5), ("c64", 21, 9), ("c32", 15, 64), ("c32", 19, 16)])
 def test_large_n_persistent_factor_kernels(fft32, fft64, oracle, dtype, log2n, batch):
     """Batches large enough for the persistent factor kernels (fft_tile_persist_kernel / fft_rows_persist_kernel: every
     resident workgroup walks several tiles, prefetching the next; the last factor keeps its table entries resident per row
@@ -483,7 +483,8 @@ def test_stft_istft_any_window_length(fft32, oracle, win_len, hop, length):
     assert bits_equal(mags, wm) and mx == wmx
 
 
-@pytest.mark.parametrize("depth,rows,cols", [(1, 12, 10), (1, 100, 6), (6, 5, 7), (1, 3, 32768), (2, 1000, 16)])
+@pytest.mark.parametrize("depth,rows,cols", [(1, 12, 10), (1, 100, 6), (6, 5, 7), (1, 3, 32768), (2, 1000, 16),
+                                             (1, 3, 1 << 22), (1, 1 << 22, 2)])  # panels with one side beyond 65535 tiles
 def test_ndfft_any_axis_length(fft32, oracle, depth, rows, cols):
     """ndfft runs FftImpl::fft on rows and fft_strided down the other axes for any length (ndfft.rs:89-98, 131-151): axes the
     strided kernel does not cover go through transpose -> batched fft_dev (Bluestein / factor path) -> transpose."""

@@ -1,6 +1,9 @@
 #!/bin/bash
 # usage: tools_profile.sh <tag> [bench args...]  -- run on the GPU box from the repo root
 # 1) kernel-trace stats  2) PMC passes (FETCH_SIZE / WRITE_SIZE / LDS)  -- separate runs, as the guide prescribes
+# profiling is single-rank only: a multi-rank bench.py starts child processes, and under rocprofv3 (whose preloaded library has
+# already initialised the GPU) that is an exec from a GPU-initialised process -- refused here and by bench.py itself
+for a in "$@"; do case "$a" in --gpus|--gpus=*) echo "$0: --gpus is not allowed under the profiler (single rank only)" >&2; exit 2;; esac; done
 set -u
 TAG=$1; shift
 export TMPDIR=/tmp

@@ -11,6 +11,9 @@ import sys
 from collections import defaultdict
 from pathlib import Path
 
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from bench import csrc_sha16  # noqa: E402  (the hash bench.py compares profiles/traffic_*.json against)
+
 
 def short(name: str) -> str:
     name = name.replace("void kofft::", "").replace("kofft::", "")
@@ -41,15 +44,30 @@ def main():
                 summary["kernels"].append(k)
                 lines.append(f"| `{k['name']}` | {k['calls']} | {k['avg_ns'] / 1e3:.1f} | {k['min_ns'] / 1e3:.1f} | "
                              f"{k['max_ns'] / 1e3:.1f} | {k['pct']:.2f} |")
-    # per-dispatch resources from the kernel trace
+    # per-dispatch geometry from the kernel trace; registers / scratch / static LDS from the code object's own metadata
+    # (the trace's VGPR column is in allocation granules and its LDS column does not carry dynamic LDS: as printed in
+    # rounds 1-2 those contradicted the design record)
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    try:
+        from codeobj_resources import kernel_table, lookup
+        table = kernel_table()
+    except Exception as e:  # no library / no llvm tools on this box: say so rather than print the trace's columns
+        table, lookup = None, None
+        lines += ["", f"(code-object metadata unavailable: {type(e).__name__}: {e})"]
+    summary["dispatch"] = []
     for f in newest(str(src / "trace" / "**" / "*_kernel_trace.csv")):
         seen = set()
         for r in csv.DictReader(open(f)):
             if "kofft" in r["Kernel_Name"] and r["Kernel_Name"] not in seen:
                 seen.add(r["Kernel_Name"])
+                res = lookup(table, r["Kernel_Name"]) if table else None
+                regs = (f"VGPR {res['vgpr']}, AGPR {res['agpr']}, SGPR {res['sgpr']}, scratch {res['scratch']} B/lane, static LDS "
+                        f"{res['lds_static']} B (exchange buffers are dynamic LDS, a launch argument: DESIGN.md 5)") if res else \
+                       "registers: kernel not found in the code objects"
                 lines += ["", f"Dispatch of `{short(r['Kernel_Name'])}`: grid {r.get('Grid_Size_X', r.get('Grid_Size', '?'))}, "
-                          f"workgroup {r.get('Workgroup_Size_X', r.get('Workgroup_Size', '?'))}, LDS {r.get('LDS_Block_Size', '?')} B, "
-                          f"VGPR {r.get('VGPR_Count', '?')}, SGPR {r.get('SGPR_Count', '?')}, scratch {r.get('Scratch_Size', '?')} B"]
+                          f"workgroup {r.get('Workgroup_Size_X', r.get('Workgroup_Size', '?'))}; code object: {regs}"]
+                summary["dispatch"].append({"kernel": short(r["Kernel_Name"]), "grid": r.get("Grid_Size_X", r.get("Grid_Size")),
+                                            "workgroup": r.get("Workgroup_Size_X", r.get("Workgroup_Size")), "code_object": res})
     agg = defaultdict(list)
     per_kernel = defaultdict(lambda: defaultdict(list))
     steps_launched = {}
@@ -90,7 +108,7 @@ def main():
                   f"read {fetch / 1e9:.4f} GB + write {write / 1e9:.4f} GB = **{(fetch + write) / 1e9:.4f} GB**"]
         (out_dir / f"traffic_{workload}.json").write_text(json.dumps(
             {"workload": workload, "hbm_bytes_per_step": fetch + write, "read_bytes": fetch, "write_bytes": write,
-             "kernels_per_step": len(agg["FETCH_SIZE"]) / nf, "from": f"profiles/{name}.md"}) + "\n")
+             "kernels_per_step": len(agg["FETCH_SIZE"]) / nf, "from": f"profiles/{name}.md", "csrc_sha16": csrc_sha16()}) + "\n")
     if "SQ_LDS_BANK_CONFLICT" in agg:
         lines += ["", f"LDS bank-conflict cycles / LDS active cycles: {summary['pmc']['SQ_LDS_BANK_CONFLICT']:.0f} / "
                   f"{summary['pmc'].get('SQ_LDS_IDX_ACTIVE', 0):.0f}"]
@@ -103,6 +121,18 @@ def main():
                 summary["bench_under_profiler"] = {k: b[k] for k in ("value", "unit", "ms_per_step", "roofline")}
                 lines += ["", f"bench.py under the profiler: {b['value']:.1f} {b['unit']}, kernel avg {b['roofline']['kernel_ms_avg']:.4f} ms "
                           f"(HIP events) -- compare with the --stats average above."]
+                # the same fraction from both clocks: --stats average of the kofft kernels of one step against the HIP events
+                alg = b["roofline"].get("algorithmic_bytes_per_launch")
+                kk = [k for k in summary["kernels"] if "kofft" in k["name"] or "fft_" in k["name"]]
+                steps_total = b.get("launches_total")
+                if alg and kk and steps_total:
+                    step_ns = sum(k["avg_ns"] * k["calls"] for k in kk) / steps_total
+                    frac_stats = alg / (step_ns * 1e-9) / 8e12
+                    summary["frac_from_stats"] = frac_stats
+                    summary["frac_from_hip_events"] = b["roofline"]["frac"]
+                    lines += ["", f"Roofline fraction (algorithmic {alg / 1e9:.4f} GB per step / 8 TB/s): **{frac_stats:.4f}** from the --stats "
+                              f"averages ({step_ns / 1e3:.1f} us of kofft kernels per step, all {steps_total} launches incl. ramp and warm-up), "
+                              f"**{b['roofline']['frac']:.4f}** from bench.py's HIP events (timed steps only)."]
     (out_dir / f"{name}.md").write_text("\n".join(lines) + "\n")
     (out_dir / f"{name}.json").write_text(json.dumps(summary, indent=1) + "\n")
     print("\n".join(lines))

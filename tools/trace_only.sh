@@ -1,5 +1,8 @@
 #!/bin/bash
 # usage: tools/trace_only.sh <tag> [bench args...] -- one rocprofv3 --kernel-trace --stats pass of bench.py, per-kernel table on stdout
+# profiling is single-rank only: a multi-rank bench.py starts child processes, and under rocprofv3 (whose preloaded library has
+# already initialised the GPU) that is an exec from a GPU-initialised process -- refused here and by bench.py itself
+for a in "$@"; do case "$a" in --gpus|--gpus=*) echo "$0: --gpus is not allowed under the profiler (single rank only)" >&2; exit 2;; esac; done
 TAG=$1; shift
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/trace_$TAG
