@@ -133,9 +133,9 @@ int launch_sub_one_tile(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size
 
 // Launch the generic kernel for a sub-transform of log2 size LS with an arbitrary IO policy.
 template <typename T, class IO>
-int launch_sub(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, int LS, size_t units)
+int launch_sub(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, int LS, size_t units, bool persist)
 {
-    if (ctx->big_persist && units >= (size_t)ctx->num_cus * ctx->big_persist_min_units) {  // every resident workgroup gets several tiles
+    if (persist && units >= (size_t)ctx->num_cus * ctx->big_persist_min_units) {  // every resident workgroup gets several tiles
         switch (LS) {
 #define KOFFT_CASE(LL) \
     case LL: return launch_tile_persist<T, LL, IO>(ctx, io, tw, units);
@@ -237,7 +237,7 @@ int fft_big_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t ba
         cpx<T> *dst = reinterpret_cast<cpx<T> *>(d_out) + b0 * n;
         // first factor: stages 0 .. L1-1 down the columns of a 2^L1 x 2^(L-L1) matrix
         BigColsIO<T, INVERSE> a{src, mid, L - L1, L - L1, n};
-        rc = launch_sub<T>(ctx, a, tw, L1, nb << (L - L1));
+        rc = launch_sub<T>(ctx, a, tw, L1, nb << (L - L1), ctx->big_first_persist >= 0 ? ctx->big_first_persist != 0 : ctx->big_persist);
         if (rc) return rc;
         const cpx<T> *last_in = mid;
         if (three) {
@@ -258,7 +258,10 @@ int fft_big_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t ba
         const size_t load_piece = (size_t)(64 / big_rows_per_wg<T>(L3)) * sizeof(cpx<T>);
         b.nt_load = ctx->big_mid_nt >= 0 ? ctx->big_mid_nt != 0 : (nb * xf_bytes > (size_t(192) << 20) && load_piece >= 64);
         rc = KOFFT_ERR_UNSUPPORTED;
-        if (ctx->big_persist && ctx->big_rows_resident && (nb << LP) >= (size_t)ctx->num_cus * ctx->big_persist_min_units) {
+        // last factor: 2 = rows resident (table entries per row tile in LDS), 1 = the generic persistent tile kernel, 0 = one tile
+        // per workgroup (two 512-thread workgroups per CU at 128 registers); KOFFT_HIP_BIG_LAST_MODE for A/B measurements
+        const int last_mode = ctx->big_last_mode >= 0 ? ctx->big_last_mode : (!ctx->big_persist ? 0 : (ctx->big_rows_resident ? 2 : 1));
+        if (last_mode == 2 && (nb << LP) >= (size_t)ctx->num_cus * ctx->big_persist_min_units) {
             switch (L3) {
             case 7: rc = launch_rows_persist<T, 7>(ctx, b, tw, nb); break;
             case 8: rc = launch_rows_persist<T, 8>(ctx, b, tw, nb); break;
@@ -267,7 +270,7 @@ int fft_big_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t ba
             default: break;
             }
         }
-        if (rc == KOFFT_ERR_UNSUPPORTED) rc = launch_sub<T>(ctx, b, tw, L3, nb << LP);
+        if (rc == KOFFT_ERR_UNSUPPORTED) rc = launch_sub<T>(ctx, b, tw, L3, nb << LP, last_mode >= 1);
         if (rc) return rc;
     }
     return KOFFT_OK;

@@ -61,6 +61,7 @@ struct PlainTw {
 // FftImpl::fft (fft.rs:1054) / ifft (fft.rs:1134-1174: conj, fft, conj, *scale).
 template <typename T, bool INVERSE>
 struct ComplexIO : PlainTw {
+    static constexpr bool kSplitOk = true;  // fft_split.hip.h
     static constexpr bool kStreams = true;  // descriptor loads in the generic kernels
     static constexpr bool kPersist = true;  // eligible for the persistent prefetching kernel
     static constexpr bool kInvInLds = false;
@@ -134,6 +135,7 @@ struct ComplexIO : PlainTw {
 
 // stft.rs:91-103: frame f starts at start0 + f*hop; x = signal[start+i]*window[i] or 0.
 struct StftIO : PlainTw {
+    static constexpr bool kSplitOk = true;  // fft_split.hip.h
     static constexpr bool kStreams = true;
     static constexpr bool kPersist = true;
     static constexpr int kPersistMinLog2 = 6;

@@ -20,6 +20,7 @@
 
 #include "fft_big.hip.h"
 #include "fft_persist.hip.h"
+#include "fft_split.hip.h"
 #include "fft_wg.hip.h"
 #include "tables.h"
 
@@ -44,6 +45,8 @@ struct kofft_hip_ctx {
     int big_narrow_per_cu = 1; // KOFFT_HIP_BIG_NARROW_PER_CU: workgroups per CU the narrowing aims for
     bool big_persist = true;   // KOFFT_HIP_BIG_PERSIST=0: factors on the one-tile-per-workgroup kernel (A/B measurements)
     size_t big_persist_min_units = 32;  // KOFFT_HIP_BIG_PERSIST_MIN_UNITS: units (columns / rows) per CU from which the persistent factor kernels run
+    int big_first_persist = -1;  // KOFFT_HIP_BIG_FIRST_PERSIST=0/1: first factor one tile per workgroup / persistent (default: big_persist)
+    int big_last_mode = -1;      // KOFFT_HIP_BIG_LAST_MODE=0/1/2: last factor one tile per workgroup / generic persistent / rows resident
     bool big_rows_resident = true;  // KOFFT_HIP_BIG_ROWS_RESIDENT=0: last factor on the generic tile kernel (A/B measurements)
     int big_mid_nt = -1;       // KOFFT_HIP_BIG_MID_NT=0/1: force plain / streaming loads of the intermediate (default: by chunk size)
     bool blue_fused = true;    // KOFFT_HIP_BLUESTEIN_FUSED=0: pointwise steps as separate kernels at every size
@@ -54,6 +57,7 @@ struct kofft_hip_ctx {
     bool host_pipeline = true; // KOFFT_HIP_HOST_PIPELINE=0: host-pointer batches in one upload / kernel / download
     int host_chunks = 0;       // KOFFT_HIP_HOST_CHUNKS: pieces of a pipelined host batch (default 8)
     bool persist_small = true; // KOFFT_HIP_PERSIST_SMALL=0: n = 128, 256 on the generic kernels (A/B measurements)
+    bool use_split = true;     // KOFFT_HIP_SPLIT=0: n = 8192 on the block-synchronised persistent kernel instead of the wave-split one (A/B)
     std::string last_error;
     // planner caches: (kind, n) -> device table.  kind 0/1 = FftPlanner twiddles f32/f64,
     // 2/3 = RfftPlanner post-pass table f32/f64.
@@ -363,6 +367,28 @@ int launch_persist(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t ba
     return KOFFT_OK;
 }
 
+// The wave-split kernel (fft_split.hip.h): one workgroup per CU, one s_barrier per transform.
+template <typename T, int LA, int LB, class IO>
+int launch_split(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t batch)
+{
+    using Gm = SplitGeom<LA, LB>;
+    constexpr size_t lds = 2 * (size_t)Gm::N * sizeof(cpx<T>);
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = fft_split_persist_kernel<T, LA, LB, IO>;
+    {
+        static std::atomic<unsigned long long> attr_done{0};
+        const int arc = set_dyn_lds_once(ctx, attr_done, reinterpret_cast<const void *>(kern), lds);
+        if (arc) return arc;
+    }
+    size_t blocks = (size_t)ctx->num_cus;
+    if (ctx->persist_grid_pct > 0) blocks = blocks * (size_t)ctx->persist_grid_pct / 100;
+    if (blocks < 1) blocks = 1;
+    if (blocks > batch) blocks = batch;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Gm::TPT), lds, ctx->stream, io, tw, batch);
+    KOFFT_HIP_TRY(ctx, hipGetLastError());
+    return KOFFT_OK;
+}
+
 template <typename T, int N, int EPI, class IO>
 int launch_small(kofft_hip_ctx *ctx, const IO &io, size_t batch, const cpx<T> *tw = nullptr)
 {
@@ -423,6 +449,8 @@ int dispatch(kofft_hip_ctx *ctx, const IO &io, size_t n, size_t batch)
     if constexpr (sizeof(T) == 4 && IO::kPersist) if (ctx->use_persist) {
         // streaming sizes: enough transforms to give every resident workgroup several iterations
         if constexpr (EPI == EPI_STORE && IO::kPersistMaxLog2 >= 13) {
+            if constexpr (io_split_ok<IO>::value)
+                if (L == 13 && ctx->use_split && batch >= (size_t)ctx->num_cus * 4) return launch_split<T, 7, 6>(ctx, io, tw, batch);
             if (L == 13 && batch >= (size_t)ctx->num_cus * 4) return launch_persist<T, 13, EPI>(ctx, io, tw, batch);
             if (L == 12 && batch >= (size_t)ctx->num_cus * 4) return launch_persist<T, 12, EPI>(ctx, io, tw, batch);
         }

@@ -463,9 +463,12 @@ int kofft_hip_create(int device, kofft_hip_ctx **out)
     if (const char *e = getenv("KOFFT_HIP_SMALL32")) ctx->small32 = !(e[0] == '0');
     if (const char *e = getenv("KOFFT_HIP_BIG_PERSIST")) ctx->big_persist = !(e[0] == '0');
     if (const char *e = getenv("KOFFT_HIP_BIG_MID_NT")) ctx->big_mid_nt = atoi(e);
+    if (const char *e = getenv("KOFFT_HIP_BIG_FIRST_PERSIST")) ctx->big_first_persist = atoi(e);
+    if (const char *e = getenv("KOFFT_HIP_BIG_LAST_MODE")) ctx->big_last_mode = atoi(e);
     if (const char *e = getenv("KOFFT_HIP_BIG_PERSIST_MIN_UNITS")) ctx->big_persist_min_units = (size_t)atol(e);
     if (const char *e = getenv("KOFFT_HIP_BIG_ROWS_RESIDENT")) ctx->big_rows_resident = !(e[0] == '0');
     if (const char *e = getenv("KOFFT_HIP_PERSIST_SMALL")) ctx->persist_small = !(e[0] == '0');
+    if (const char *e = getenv("KOFFT_HIP_SPLIT")) ctx->use_split = !(e[0] == '0');
     if (const char *e = getenv("KOFFT_HIP_HOST_PIPELINE")) ctx->host_pipeline = !(e[0] == '0');
     if (const char *e = getenv("KOFFT_HIP_ZERO_COPY")) ctx->zero_copy = !(e[0] == '0');
     if (const char *e = getenv("KOFFT_HIP_ND_TRANSPOSE")) ctx->nd_transpose = !(e[0] == '0');

@@ -784,6 +784,36 @@ def test_n8192_streaming_paths(fft32, oracle, batch):
     w = oracle.hann(8192)
     frames = -(-sig.size // 2048)
     assert_parity(fft32.stft_into(sig, w, 2048, frames), oracle.stft(sig, w, 2048, frames), "streaming stft win=8192", REL_TOL_F32)
+    # the magnitude policy rides the same kernel (the running maximum is carried across the delayed stores)
+    mags, mx = fft32.stft_magnitudes(sig, 8192, 2048)
+    wm, wmx = oracle.stft_magnitudes(sig, 8192, 2048)
+    assert bits_equal(mags, wm) and mx == wmx
+
+
+@pytest.mark.parametrize("batch", [1024, 1025, 1279, 1281, 2048 + 3])
+def test_n8192_wave_split_kernel_around_the_grid(fft32, oracle, batch):
+    """fft_split_persist_kernel (n = 8192: one workgroup per CU, every wavefront owning 1024 points, one s_barrier per
+    transform, results stored one step late): batch sizes around multiples of the grid (256 workgroups), so that workgroups
+    with 4 and 5 transforms, odd and even counts (the two LDS buffers alternate) and the empty-descriptor prefetch all occur;
+    both settings of KOFFT_HIP_SPLIT agree bit for bit with the oracle."""
+    import os
+
+    import kofft_amd
+
+    rng = seeded(7100 + batch)
+    x = rand_c(rng, (batch, 8192))
+    want = oracle.fft(x)
+    for split in ("1", "0"):
+        os.environ["KOFFT_HIP_SPLIT"] = split
+        try:
+            f = kofft_amd.HipFftImpl(np.float32)
+        finally:
+            del os.environ["KOFFT_HIP_SPLIT"]
+        y = x.copy()
+        f.fft_batch(y)
+        assert bits_equal(y, want), f"KOFFT_HIP_SPLIT={split} batch={batch}"
+        f.fft_batch(y, inverse=True)
+        assert bits_equal(y, oracle.ifft(want)), f"inverse KOFFT_HIP_SPLIT={split} batch={batch}"
 
 
 def test_istft_stream_reconstructs_and_flushes(fft32, oracle):
