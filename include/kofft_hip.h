@@ -108,6 +108,20 @@ int kofft_hip_fft_c32_dev_oop(kofft_hip_ctx *ctx, const float *d_in, float *d_ou
 int kofft_hip_fft_c64_dev_oop(kofft_hip_ctx *ctx, const double *d_in, double *d_out, size_t n,
                               size_t batch, int inverse);
 
+/* ScalarFftImpl::fft_radix4 (fft.rs:1455-1548) byte for byte -- an OPT-IN compatibility arm.  kofft's
+ * fft_with_strategy(.., FftStrategy::Radix4) (fft.rs:1356) runs it for powers of four, and from n = 16 its output is NOT
+ * the DFT (its "bit-reversal for radix-4" loop, fft.rs:1462-1474, flips one bit per base-4 digit instead of reversing the
+ * digits); every other entry point here, and the host mirrors' fft_with_strategy by default, return the true transform.
+ * These four reproduce the reference's bytes for callers that depend on them (the mirrors call them when
+ * KOFFT_HIP_RADIX4_COMPAT=1 or their radix4_compat flag is set): the swap loop as a gather through its net permutation,
+ * butterfly4 in the reference's operation order, the three running-product twiddle sequences of every stage built on the
+ * host with Complex::mul.  n not a power of four -> fft() (fft.rs:1457-1460; n == 0 -> EMPTY_INPUT); n > 2^20 ->
+ * KOFFT_ERR_UNSUPPORTED.  Forward only, like the reference.  data: batch * n complex. */
+int kofft_hip_fft_radix4_c32(kofft_hip_ctx *ctx, float *data, size_t n, size_t batch);
+int kofft_hip_fft_radix4_c64(kofft_hip_ctx *ctx, double *data, size_t n, size_t batch);
+int kofft_hip_fft_radix4_c32_dev(kofft_hip_ctx *ctx, const float *d_in, float *d_out, size_t n, size_t batch);
+int kofft_hip_fft_radix4_c64_dev(kofft_hip_ctx *ctx, const double *d_in, double *d_out, size_t n, size_t batch);
+
 /* FftImpl::fft_strided / ifft_strided (fft.rs:1175-1199, 1236-1260), host pointers:
  * gathers n = scratch_len elements data[i*stride], transforms, scatters back.
  * stride == 0 -> KOFFT_ERR_INVALID_STRIDE; n == 0 -> KOFFT_OK;

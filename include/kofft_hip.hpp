@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <cstddef>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -96,6 +97,7 @@ template <> struct Abi<float> {
     static int twiddles(size_t n, float *o) { return kofft_hip_twiddles_f32(n, o); }
     static int rfft_table(size_t m, float *o) { return kofft_hip_rfft_table_f32(m, o); }
     static int fftnd(kofft_hip_ctx *c, float *d, size_t dp, size_t r, size_t cl, int inv) { return kofft_hip_fftnd_c32(c, d, dp, r, cl, inv); }
+    static int radix4(kofft_hip_ctx *c, float *d, size_t n, size_t b) { return kofft_hip_fft_radix4_c32(c, d, n, b); }
 };
 template <> struct Abi<double> {
     static int fft(kofft_hip_ctx *c, double *d, size_t n, size_t b, int inv) { return kofft_hip_fft_c64(c, d, n, b, inv); }
@@ -105,6 +107,7 @@ template <> struct Abi<double> {
     static int twiddles(size_t n, double *o) { return kofft_hip_twiddles_f64(n, o); }
     static int rfft_table(size_t m, double *o) { return kofft_hip_rfft_table_f64(m, o); }
     static int fftnd(kofft_hip_ctx *c, double *d, size_t dp, size_t r, size_t cl, int inv) { return kofft_hip_fftnd_c64(c, d, dp, r, cl, inv); }
+    static int radix4(kofft_hip_ctx *c, double *d, size_t n, size_t b) { return kofft_hip_fft_radix4_c64(c, d, n, b); }
 };
 }  // namespace detail
 
@@ -168,7 +171,12 @@ public:
     {
         int rc = kofft_hip_create(device, &ctx_);
         if (rc != 0) throw DeviceError(rc, "kofft_hip_create");
+        const char *e = std::getenv("KOFFT_HIP_RADIX4_COMPAT");
+        radix4_compat = e && e[0] == '1';
     }
+    // fft_with_strategy(.., Radix4) reproduces the reference's fft_radix4 bytes (NOT a DFT from n = 16) instead of the true
+    // transform.  Off unless KOFFT_HIP_RADIX4_COMPAT=1 or set here.
+    bool radix4_compat = false;
     static HipFftImpl default_() { return HipFftImpl(0); }
     ~HipFftImpl() override { if (ctx_) kofft_hip_destroy(ctx_); }
     HipFftImpl(const HipFftImpl &) = delete;
@@ -198,13 +206,17 @@ public:
         return oop_strided(input, in_stride, output, out_stride, true);
     }
     // fft.rs:1337-1363.  Every strategy runs the Stockham path.  Deliberate divergence: the reference's Radix4 arm
-    // (fft_radix4, fft.rs:1455-1548) is not a DFT from n = 16 (its digit-reversal loop is wrong).
-    Result fft_with_strategy(std::vector<C> &input, FftStrategy) const override
+    // (fft_radix4, fft.rs:1455-1548) is not a DFT from n = 16 (its digit-reversal loop is wrong);
+    // with radix4_compat the reference's bytes are reproduced instead (kofft_hip_fft_radix4_*).
+    Result fft_with_strategy(std::vector<C> &input, FftStrategy strategy) const override
     {
         if (input.empty()) return Result::Err(FftError::EmptyInput);
         if (input.size() == 1) return Result::Ok();
+        if (strategy == FftStrategy::Radix4 && radix4_compat) return fft_radix4(input);
         return fft(input);
     }
+    // ScalarFftImpl::fft_radix4 (fft.rs:1455-1548), the reference's bytes
+    Result fft_radix4(std::vector<C> &input) const { return st(detail::Abi<T>::radix4(ctx_, fp(input), input.size(), 1)); }
 
     // RealFftImpl<T> blanket methods (rfft.rs:780-833); checks in rfft_direct's order (rfft.rs:433-443)
     Result rfft_with_scratch(std::vector<T> &input, std::vector<C> &output, std::vector<C> &scratch) const

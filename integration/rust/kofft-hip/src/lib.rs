@@ -22,6 +22,8 @@ extern "C" {
     fn kofft_hip_last_error(ctx: *const KofftHipCtx) -> *const c_char;
     fn kofft_hip_fft_c32(ctx: *mut KofftHipCtx, data: *mut f32, n: usize, batch: usize, inverse: c_int) -> c_int;
     fn kofft_hip_fft_c64(ctx: *mut KofftHipCtx, data: *mut f64, n: usize, batch: usize, inverse: c_int) -> c_int;
+    fn kofft_hip_fft_radix4_c32(ctx: *mut KofftHipCtx, data: *mut f32, n: usize, batch: usize) -> c_int;
+    fn kofft_hip_fft_radix4_c64(ctx: *mut KofftHipCtx, data: *mut f64, n: usize, batch: usize) -> c_int;
     fn kofft_hip_fft_c32_strided(ctx: *mut KofftHipCtx, data: *mut f32, len: usize, stride: usize, n: usize, inverse: c_int) -> c_int;
     fn kofft_hip_fft_c64_strided(ctx: *mut KofftHipCtx, data: *mut f64, len: usize, stride: usize, n: usize, inverse: c_int) -> c_int;
     fn kofft_hip_rfft_f32(ctx: *mut KofftHipCtx, input: *const f32, out: *mut f32, window: *const f32, n: usize, batch: usize) -> c_int;
@@ -101,6 +103,9 @@ fn status(ctx: *const KofftHipCtx, rc: c_int) -> Result<(), FftError> {
 /// One device context per instance; `Send` but not `Sync`, like `ScalarFftImpl` (kofft fft.rs:589-605).
 pub struct HipFftImpl<T: Float> {
     ctx: *mut KofftHipCtx,
+    /// `fft_with_strategy(.., Radix4)` reproduces kofft's `fft_radix4` bytes (NOT a DFT from n = 16) instead of the true
+    /// transform.  Off unless `KOFFT_HIP_RADIX4_COMPAT=1` or set by the caller.
+    pub radix4_compat: bool,
     _t: PhantomData<T>,
 }
 
@@ -111,7 +116,8 @@ impl<T: Float> HipFftImpl<T> {
         let mut ctx = core::ptr::null_mut();
         let rc = unsafe { kofft_hip_create(device as c_int, &mut ctx) };
         assert!(rc == 0 && !ctx.is_null(), "kofft_hip_create failed: {rc}");
-        Self { ctx, _t: PhantomData }
+        let radix4_compat = std::env::var("KOFFT_HIP_RADIX4_COMPAT").map_or(false, |v| v == "1");
+        Self { ctx, radix4_compat, _t: PhantomData }
     }
 }
 
@@ -128,7 +134,7 @@ impl<T: Float> Drop for HipFftImpl<T> {
 }
 
 macro_rules! impl_fft {
-    ($t:ty, $cplx:ty, $fft:ident, $strided:ident) => {
+    ($t:ty, $cplx:ty, $fft:ident, $strided:ident, $radix4:ident) => {
         impl FftImpl<$t> for HipFftImpl<$t> {
             // Complex<T> is #[repr(C)] {re, im} (kofft num.rs:105-110, tests/complex_repr.rs): a slice of n
             // complex values is 2n scalars.
@@ -171,12 +177,21 @@ macro_rules! impl_fft {
                 for i in 0..n { output[i * out_stride] = scratch[i]; }
                 Ok(())
             }
-            fn fft_with_strategy(&self, input: &mut [$cplx], _strategy: FftStrategy) -> Result<(), FftError> {
+            fn fft_with_strategy(&self, input: &mut [$cplx], strategy: FftStrategy) -> Result<(), FftError> {
                 // kofft fft.rs:1337-1363: every strategy runs the Stockham path here.  (The crate's own Radix4 arm,
-                // fft_radix4, is not a DFT from n = 16: its digit-reversal loop is wrong; this shim returns the correct transform.)
+                // fft_radix4, is not a DFT from n = 16: its digit-reversal loop is wrong; this shim returns the correct
+                // transform unless `radix4_compat` asks for the crate's bytes.)
                 if input.is_empty() { return Err(FftError::EmptyInput); }
                 if input.len() == 1 { return Ok(()); }
+                if strategy == FftStrategy::Radix4 && self.radix4_compat { return self.fft_radix4(input); }
                 self.fft(input)
+            }
+        }
+
+        impl HipFftImpl<$t> {
+            /// `ScalarFftImpl::fft_radix4` (kofft fft.rs:1455-1548), byte for byte.
+            pub fn fft_radix4(&self, input: &mut [$cplx]) -> Result<(), FftError> {
+                status(self.ctx, unsafe { $radix4(self.ctx, input.as_mut_ptr() as *mut $t, input.len(), 1) })
             }
         }
 
@@ -191,8 +206,8 @@ macro_rules! impl_fft {
     };
 }
 
-impl_fft!(f32, Complex32, kofft_hip_fft_c32, kofft_hip_fft_c32_strided);
-impl_fft!(f64, Complex64, kofft_hip_fft_c64, kofft_hip_fft_c64_strided);
+impl_fft!(f32, Complex32, kofft_hip_fft_c32, kofft_hip_fft_c32_strided, kofft_hip_fft_radix4_c32);
+impl_fft!(f64, Complex64, kofft_hip_fft_c64, kofft_hip_fft_c64_strided, kofft_hip_fft_radix4_c64);
 
 macro_rules! impl_ndfft {
     ($t:ty, $cplx:ty, $nd:ident) => {

@@ -3,6 +3,7 @@
 #pragma once
 
 #include "host_common.hip.h"
+#include "fft_radix4.hip.h"
 
 namespace kofft {
 namespace host {
@@ -464,6 +465,82 @@ int fft_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t batch,
     return dispatch<T, EPI_STORE>(ctx, io, n, batch);
 }
 
+
+// ---------------------------------------------------------------------------------
+// ScalarFftImpl::fft_radix4 (fft.rs:1455-1548), the reference's bytes (opt-in: fft_radix4.hip.h)
+// ---------------------------------------------------------------------------------
+template <typename T>
+int fft_radix4_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t batch)
+{
+    if (batch == 0) return KOFFT_OK;
+    // fft.rs:1457-1460: anything but a power of four falls back to fft() (n == 0 -> EmptyInput there)
+    if (!is_pow2(n) || (ilog2(n) & 1)) return fft_dev<T>(ctx, d_in, d_out, n, batch, 0);
+    if (n > (size_t(1) << 20)) return KOFFT_ERR_UNSUPPORTED;  // (tables of n entries per context; the arm is a compatibility path)
+    if (!ctx || !d_in || !d_out) return KOFFT_ERR_NULL;
+    KOFFT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const cpx<T> *in = reinterpret_cast<const cpx<T> *>(d_in);
+    cpx<T> *out = reinterpret_cast<cpx<T> *>(d_out);
+    if (n == 1) {  // no swap, no stage
+        if (d_in != d_out) KOFFT_HIP_TRY(ctx, hipMemcpyAsync(d_out, d_in, batch * 2 * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
+        return KOFFT_OK;
+    }
+    // tables: (kind 9 / 10, n) = permutation, (11 / 12, n) = stage triples
+    const int kp = sizeof(T) == 4 ? 9 : 10, kw = sizeof(T) == 4 ? 11 : 12;
+    auto ip = ctx->tables.find(std::make_pair(kp, n));
+    auto iw = ctx->tables.find(std::make_pair(kw, n));
+    if (ip == ctx->tables.end() || iw == ctx->tables.end()) {
+        const size_t triples = kofft_tables::radix4_triples(n);
+        std::vector<unsigned> hp(n);
+        std::vector<T> hw(6 * (triples ? triples : 1));
+        if constexpr (sizeof(T) == 4) kofft_tables::radix4_f32(n, hp.data(), (float *)hw.data());
+        else kofft_tables::radix4_f64(n, hp.data(), (double *)hw.data());
+        void *dp = nullptr, *dw = nullptr;
+        hipError_t e = hipMalloc(&dp, hp.size() * sizeof(unsigned));
+        if (e == hipSuccess) e = hipMalloc(&dw, hw.size() * sizeof(T));
+        if (e == hipSuccess) e = hipMemcpy(dp, hp.data(), hp.size() * sizeof(unsigned), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(dw, hw.data(), hw.size() * sizeof(T), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            if (dp) (void)hipFree(dp);
+            if (dw) (void)hipFree(dw);
+            ctx->last_error = std::string("radix4 tables: ") + hipGetErrorString(e);
+            return KOFFT_ERR_HIP;
+        }
+        ctx->tables[std::make_pair(kp, n)] = dp;
+        ctx->tables[std::make_pair(kw, n)] = dw;
+        ip = ctx->tables.find(std::make_pair(kp, n));
+        iw = ctx->tables.find(std::make_pair(kw, n));
+    }
+    const unsigned *perm = static_cast<const unsigned *>(ip->second);
+    const cpx<T> *w = static_cast<const cpx<T> *>(iw->second);
+    auto grid = [](size_t quads) { return dim3((unsigned)((quads + 255) / 256)); };
+    if (n == 4) {  // the permutation is the identity and every thread owns its quad: in place is safe
+        const size_t quads = batch;
+        if (quads > 0x7fffffffULL * 256) return KOFFT_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(radix4_first_kernel<T>, grid(quads), dim3(256), 0, ctx->stream, in, out, perm, n, quads);
+        KOFFT_HIP_TRY(ctx, hipGetLastError());
+        return KOFFT_OK;
+    }
+    const size_t xf_bytes = n * sizeof(cpx<T>);
+    size_t chunk = (size_t(512) << 20) / xf_bytes;
+    if (chunk < 1) chunk = 1;
+    if (chunk > batch) chunk = batch;
+    const int prc = ensure_real_tmp(ctx, chunk * xf_bytes);
+    if (prc) return prc;
+    cpx<T> *tmp = static_cast<cpx<T> *>(ctx->real_tmp);
+    for (size_t b0 = 0; b0 < batch; b0 += chunk) {
+        const size_t nb = (batch - b0 < chunk) ? batch - b0 : chunk, quads = nb * (n / 4);
+        hipLaunchKernelGGL(radix4_first_kernel<T>, grid(quads), dim3(256), 0, ctx->stream, in + b0 * n, tmp, perm, n, quads);
+        KOFFT_HIP_TRY(ctx, hipGetLastError());
+        size_t off = 0;
+        for (size_t len = 16; len <= n; len <<= 2) {
+            cpx<T> *dst = (len == n) ? out + b0 * n : tmp;  // the last stage lands in the caller's buffer
+            hipLaunchKernelGGL(radix4_stage_kernel<T>, grid(quads), dim3(256), 0, ctx->stream, tmp, dst, w + 3 * off, len, n, quads);
+            KOFFT_HIP_TRY(ctx, hipGetLastError());
+            off += len / 4;
+        }
+    }
+    return KOFFT_OK;
+}
 
 }  // namespace host
 }  // namespace kofft

@@ -4,5 +4,6 @@
 namespace kofft {
 namespace host {
 template int fft_dev<float>(kofft_hip_ctx *, const float *, float *, size_t, size_t, int);
+template int fft_radix4_dev<float>(kofft_hip_ctx *, const float *, float *, size_t, size_t);
 }  // namespace host
 }  // namespace kofft

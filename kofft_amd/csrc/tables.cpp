@@ -83,9 +83,64 @@ void bluestein(size_t n, size_t m, T *chirp, T *b)
     }
 }
 
+// ScalarFftImpl::fft_radix4 (fft.rs:1455-1548), the parts that do not depend on the data:
+//   perm[i]  = index of the INPUT element that sits at position i after the reference's swap loop (fft.rs:1462-1474;
+//              it flips one bit per base-4 digit -- not a digit reversal, which is why the arm is not a DFT from n = 16);
+//   w        = for every stage len = 16, 64, .. n, the quarter = len/4 triples (w1, w2, w3)[j] the reference builds by
+//              starting at (1, 0) and multiplying (Complex::mul, un-fused) by entries 1, 2, 3 of get_twiddles(len) after
+//              every j (fft.rs:1490-1530; the sequence restarts for every block i, so one copy per stage serves all).
+//              Triples of consecutive stages follow each other (radix4_triples(n) in all).
+template <typename T>
+void radix4(size_t n, unsigned *perm, T *w)
+{
+    for (size_t i = 0; i < n; ++i) perm[i] = (unsigned)i;
+    size_t j = 0;
+    for (size_t i = 1; i < n; ++i) {
+        size_t bit = n >> 2;
+        while (j & bit) {
+            j ^= bit;
+            bit >>= 2;
+        }
+        j ^= bit;
+        if (i < j) {
+            const unsigned t = perm[i];
+            perm[i] = perm[j];
+            perm[j] = t;
+        }
+    }
+    T *tw = new T[n >= 16 ? n : 16];
+    size_t off = 0;  // triples written so far
+    for (size_t len = 16; len <= n; len <<= 2) {
+        twiddles<T>(len, tw);
+        const T s_re[3] = {tw[2], tw[4], tw[6]}, s_im[3] = {tw[3], tw[5], tw[7]};
+        T re[3] = {(T)1, (T)1, (T)1}, im[3] = {(T)0, (T)0, (T)0};
+        const size_t quarter = len / 4;
+        for (size_t q = 0; q < quarter; ++q) {
+            for (int k = 0; k < 3; ++k) {
+                w[2 * (3 * (off + q) + k)] = re[k];
+                w[2 * (3 * (off + q) + k) + 1] = im[k];
+                const T nre = re[k] * s_re[k] - im[k] * s_im[k];  // Complex::mul (num.rs:161-166), un-fused
+                const T nim = re[k] * s_im[k] + im[k] * s_re[k];
+                re[k] = nre;
+                im[k] = nim;
+            }
+        }
+        off += quarter;
+    }
+    delete[] tw;
+}
+
 }  // namespace
 
 namespace kofft_tables {
+size_t radix4_triples(size_t n)
+{
+    size_t t = 0;
+    for (size_t len = 16; len <= n; len <<= 2) t += len / 4;
+    return t;
+}
+void radix4_f32(size_t n, unsigned *perm, float *w) { radix4<float>(n, perm, w); }
+void radix4_f64(size_t n, unsigned *perm, double *w) { radix4<double>(n, perm, w); }
 void bluestein_f32(size_t n, size_t m, float *chirp, float *b) { bluestein<float>(n, m, chirp, b); }
 void bluestein_f64(size_t n, size_t m, double *chirp, double *b) { bluestein<double>(n, m, chirp, b); }
 void twiddles_f32(size_t n, float *out) { twiddles<float>(n, out); }

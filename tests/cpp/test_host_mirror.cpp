@@ -310,6 +310,15 @@ int main()
         auto want = oracle_fft(x64);
         FftPlan<float>(64, FftStrategy::Radix4, fft).fft(x64).unwrap();  // the correct transform
         CHECK(same_bits(x64, want));
+        // opt-in: the reference's own fft_radix4 bytes (fft.rs:1455-1548), which are not that transform
+        std::vector<Complex32> r4(64), r4want(64);
+        for (size_t i = 0; i < 64; ++i) r4[i] = r4want[i] = Complex32(std::sin(0.3f * (float)i), std::cos(1.1f * (float)i));
+        ko_fft_radix4_batch_f32(reinterpret_cast<float *>(r4want.data()), 64, 1);
+        HipFftImpl<float> compat;
+        compat.radix4_compat = true;
+        compat.fft_with_strategy(r4, FftStrategy::Radix4).unwrap();
+        CHECK(same_bits(r4, r4want));
+        CHECK(!same_bits(r4, want));
     }
     {   // multi-GPU STFT through the C++ mirror: one device here, same path as G devices
         std::vector<float> sig(3000), window = hann(256);

@@ -1100,3 +1100,62 @@ def test_large_n_batches_around_the_tile_width_steps(fft32, fft64, oracle, dtype
         y = x[:b].copy()
         fft.fft_batch(y)
         assert_parity(y, want[:b], f"{dtype} 2^{log2n} batch {b}", tol)
+
+
+# ---- FftStrategy::Radix4, the reference's bytes (opt-in compatibility arm) -----------------------------
+@pytest.mark.parametrize("n", [1, 4, 16, 64, 256, 1024, 4096, 65536, 8, 32, 12])
+def test_radix4_compat_reproduces_the_reference_arm(oracle, n):
+    """kofft_hip_fft_radix4_* = ScalarFftImpl::fft_radix4 (fft.rs:1455-1548) byte for byte, f32 and f64: powers of four run
+    the reference's swap loop, butterfly4 and running-product twiddles; other lengths fall back to fft() (fft.rs:1457-1460).
+    Default behaviour is unchanged: without the flag fft_with_strategy(.., Radix4) is the true transform."""
+    import kofft_amd as K
+
+    for dt, cdt in ((np.float32, np.complex64), (np.float64, np.complex128)):
+        rng = seeded(8800 + n)
+        x = rand_c(rng, (3, n), cdt)
+        want = oracle.fft_radix4(x)
+        compat = K.HipFftImpl(dt, radix4_compat=True)
+        y = x.copy()
+        compat.fft_radix4_batch(y)
+        assert bits_equal(y, want), f"fft_radix4 {cdt.__name__} n={n}"
+        z = x[0].copy()
+        compat.fft_with_strategy(z, K.FftStrategy.Radix4)
+        assert bits_equal(z, want[0])
+        z = x[1].copy()
+        K.FftPlan(n, K.FftStrategy.Radix4, compat).fft(z)  # FftPlan::fft goes through fft_with_strategy (fft.rs:2020-2030)
+        assert bits_equal(z, want[1])
+        plain = K.HipFftImpl(dt)
+        assert plain.radix4_compat is False
+        v = x[0].copy()
+        plain.fft_with_strategy(v, K.FftStrategy.Radix4)
+        assert bits_equal(v, oracle.fft(x[:1])[0])  # the correct transform
+        if n >= 16 and (n & (n - 1)) == 0 and (n.bit_length() - 1) % 2 == 0:
+            assert not bits_equal(want[0], oracle.fft(x[:1])[0])  # ... which the reference's arm is not
+
+
+def test_radix4_compat_env_and_device_pointers(oracle, monkeypatch):
+    import torch
+
+    import kofft_amd as K
+
+    monkeypatch.setenv("KOFFT_HIP_RADIX4_COMPAT", "1")
+    f = K.HipFftImpl(np.float32)
+    assert f.radix4_compat is True
+    monkeypatch.delenv("KOFFT_HIP_RADIX4_COMPAT")
+    x = rand_c(seeded(8899), (5, 1024))
+    want = oracle.fft_radix4(x)
+    d = torch.from_numpy(x.view(np.float32).reshape(5, 1024, 2)).to("cuda")
+    o = torch.empty_like(d)
+    lib = K.load_library()
+    assert lib.kofft_hip_fft_radix4_c32_dev(f._ctx, C_void(d.data_ptr()), C_void(o.data_ptr()), 1024, 5) == 0
+    assert lib.kofft_hip_fft_radix4_c32_dev(f._ctx, C_void(d.data_ptr()), C_void(d.data_ptr()), 1024, 5) == 0  # in place
+    f.synchronize() if hasattr(f, "synchronize") else lib.kofft_hip_synchronize(f._ctx)
+    assert bits_equal(o.cpu().numpy().view(np.complex64).reshape(5, 1024), want)
+    assert bits_equal(d.cpu().numpy().view(np.complex64).reshape(5, 1024), want)
+    assert lib.kofft_hip_fft_radix4_c32_dev(f._ctx, C_void(d.data_ptr()), C_void(o.data_ptr()), 1 << 22, 1) == -2  # UNSUPPORTED
+
+
+def C_void(p):
+    import ctypes
+
+    return ctypes.c_void_p(p)
