@@ -13,7 +13,7 @@
 //! Cases whose expectation depends on how `sin_cos()` lowers (f64 Bluestein chirps, e.g. `c64_15_bluestein`; see
 //! tests/test_oracle_second_opinion.py) are reported separately: the oracle takes the merged `sincos` libcall, which is
 //! what LLVM emits on x86_64-unknown-linux-gnu.
-use kofft::fft::{Complex32, Complex64, FftImpl, FftPlanner, ScalarFftImpl};
+use kofft::fft::{Complex32, Complex64, FftImpl, FftPlanner, FftStrategy, ScalarFftImpl};
 use kofft::rfft::{RealFftImpl, RfftPlanner};
 use std::collections::HashMap;
 use std::path::PathBuf;
@@ -46,6 +46,27 @@ fn c32s(case: &str, field: &str) -> Vec<Complex32> {
 
 fn c64s(case: &str, field: &str) -> Vec<Complex64> {
     f64s(case, field).chunks_exact(2).map(|p| Complex64::new(p[0], p[1])).collect()
+}
+
+/// The input stream of the `fft_lcg*` cases (tests/golden/export_bin.py: `lcg_values`): every value is an exact f32 in
+/// [-1, 1), so a seed in the manifest stands for megabytes of input.
+fn lcg_values(seed: u64, count: usize) -> Vec<f32> {
+    let mut state = seed;
+    (0..count)
+        .map(|_| {
+            state = state.wrapping_mul(6364136223846793005).wrapping_add(1442695040888963407);
+            ((state >> 40) & 0xFF_FFFF) as f32 / 8388608.0 - 1.0
+        })
+        .collect()
+}
+
+/// FNV-1a over 8-byte little-endian words (export_bin.py: `fnv1a64`).
+fn fnv1a64(data: &[u8]) -> u64 {
+    let mut h: u64 = 0xCBF29CE484222325;
+    for w in data.chunks_exact(8) {
+        h = (h ^ u64::from_le_bytes([w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]])).wrapping_mul(0x100000001B3);
+    }
+    h
 }
 
 /// Bitwise comparison (so that -0.0 != 0.0 and NaN payloads count); returns the first differing index.
@@ -131,6 +152,45 @@ fn golden_vectors_match_the_reference_bit_for_bit() {
                 let mut z = c64s(case, "x");
                 fft.ifft(&mut z).unwrap();
                 rep.check64(case, "ifft", &flat64(&z), &f64s(case, "y_inv"));
+            }
+            // one case per dispatch route of the device (two / three factors, the largest single-workgroup size): the input
+            // is an LCG stream, the expectation a full spectrum or its hash
+            "fft_lcg" | "fft_lcg_hash" => {
+                let (n, seed) = (num("n"), p["seed"].parse::<u64>().unwrap());
+                let v = lcg_values(seed, 2 * n);
+                let out_bytes: Vec<u8> = if p["dtype"] == "c32" {
+                    let mut y: Vec<Complex32> = v.chunks_exact(2).map(|q| Complex32::new(q[0], q[1])).collect();
+                    ScalarFftImpl::<f32>::default().fft(&mut y).unwrap();
+                    if kind == "fft_lcg" {
+                        rep.check32(case, "fft", &flat32(&y), &f32s(case, "y"));
+                    }
+                    flat32(&y).iter().flat_map(|f| f.to_le_bytes()).collect()
+                } else {
+                    let mut y: Vec<Complex64> = v.chunks_exact(2).map(|q| Complex64::new(q[0] as f64, q[1] as f64)).collect();
+                    ScalarFftImpl::<f64>::default().fft(&mut y).unwrap();
+                    if kind == "fft_lcg" {
+                        rep.check64(case, "fft", &flat64(&y), &f64s(case, "y"));
+                    }
+                    flat64(&y).iter().flat_map(|f| f.to_le_bytes()).collect()
+                };
+                if kind == "fft_lcg_hash" {
+                    rep.checked += 1;
+                    let got = format!("{:016x}", fnv1a64(&out_bytes));
+                    if got != p["fnv1a64"] {
+                        rep.failures.push(format!("{case}/fft: spectrum hash {got} vs oracle {}", p["fnv1a64"]));
+                    }
+                }
+            }
+            // FftStrategy::Radix4 -> fft_radix4 (fft.rs:1356, 1455-1548): the arm kofft_hip_fft_radix4_* reproduces on request
+            "radix4" if p["dtype"] == "c32" => {
+                let mut y = c32s(case, "x");
+                ScalarFftImpl::<f32>::default().fft_with_strategy(&mut y, FftStrategy::Radix4).unwrap();
+                rep.check32(case, "fft_with_strategy(Radix4)", &flat32(&y), &f32s(case, "y"));
+            }
+            "radix4" => {
+                let mut y = c64s(case, "x");
+                ScalarFftImpl::<f64>::default().fft_with_strategy(&mut y, FftStrategy::Radix4).unwrap();
+                rep.check64(case, "fft_with_strategy(Radix4)", &flat64(&y), &f64s(case, "y"));
             }
             "rfft" if p["dtype"] == "f32" => {
                 let fft = ScalarFftImpl::<f32>::default();
@@ -218,6 +278,6 @@ fn golden_vectors_match_the_reference_bit_for_bit() {
     for m in &rep.failures {
         println!("  FAILED: {m}");
     }
-    assert!(rep.checked >= 80, "manifest too short: {}", rep.checked);
+    assert!(rep.checked >= 88, "manifest too short: {}", rep.checked);
     assert!(rep.failures.is_empty(), "{} golden comparisons differ from the reference", rep.failures.len());
 }

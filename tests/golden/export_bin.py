@@ -26,6 +26,27 @@ from oracle import pyoracle as ko  # noqa: E402
 HERE = Path(__file__).resolve().parent
 OUT = HERE / "bin"
 
+LCG_A, LCG_C = np.uint64(6364136223846793005), np.uint64(1442695040888963407)
+
+
+def lcg_values(seed: int, count: int) -> np.ndarray:
+    """count f32 values in [-1, 1), each exact: state <- state * A + C (mod 2^64), value = ((state >> 40) & 0xFFFFFF) / 2^23 - 1.
+    The same three lines exist in golden_pin.rs (`lcg_values`): large route cases store a seed instead of their input."""
+    with np.errstate(over="ignore"):
+        apow = np.multiply.accumulate(np.full(count, LCG_A, np.uint64))          # A^1 .. A^count
+        geo = np.add.accumulate(np.concatenate(([np.uint64(1)], apow[:-1])))      # 1 + A + .. + A^(k-1)
+        states = apow * np.uint64(seed) + LCG_C * geo
+    return (((states >> np.uint64(40)) & np.uint64(0xFFFFFF)).astype(np.float32) / np.float32(8388608.0) - np.float32(1.0)).astype(np.float32)
+
+
+def fnv1a64(data: bytes) -> int:
+    """FNV-1a over 8-byte little-endian words (the output arrays are multiples of 8 bytes)."""
+    words = np.frombuffer(data, dtype="<u8")
+    h = 0xCBF29CE484222325
+    for w in words.tolist():
+        h = ((h ^ w) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
 
 def put(case, field, arr):
     a = np.ascontiguousarray(arr)
@@ -95,6 +116,28 @@ def main():
         case = f"mags32_6000_w{win_len}_h{hop}"
         put(case, "samples", sig); put(case, "mags", mags); put(case, "max", np.array([mx], np.float32))
         lines.append(f"mags\t{case}\tlen={sig.size}\twin={win_len}\thop={hop}\tframes={mags.shape[0]}")
+    # ---- one case per DISPATCH ROUTE of the device beyond the fused single-workgroup sizes: inputs are
+    # LCG streams (a seed in the manifest), expected spectra stored in full where they are small, as a hash where not.
+    #   c32 8192 -> wave-split kernel (already above: c32_8192_uniform); c32 16384 -> largest single-workgroup transform;
+    #   c32 2^15 -> two factors; c64 2^16 -> two factors, f64; c32 2^22 -> three factors (hash only: 32 MiB of spectrum).
+    for tag, log2n, seed, full in (("c32", 14, 1401, True), ("c32", 15, 1501, True), ("c64", 16, 1601, True), ("c32", 22, 2201, False)):
+        n = 1 << log2n
+        v = lcg_values(seed, 2 * n)
+        x = (v[0::2] + 1j * v[1::2]).astype(np.complex64 if tag == "c32" else np.complex128)
+        y = ko.fft(x)
+        case = f"{tag}_2p{log2n}_lcg"
+        if full:
+            put(case, "y", y)
+            lines.append(f"fft_lcg\t{case}\tdtype={tag}\tn={n}\tseed={seed}")
+        else:
+            lines.append(f"fft_lcg_hash\t{case}\tdtype={tag}\tn={n}\tseed={seed}\tfnv1a64={fnv1a64(y.tobytes()):016x}")
+    # FftStrategy::Radix4, the reference's own arm (fft.rs:1455-1548; kofft_hip_fft_radix4_* reproduces it on request)
+    for tag, n, seed in (("c32", 1024, 3101), ("c32", 16, 3102), ("c64", 256, 3103)):
+        v = lcg_values(seed, 2 * n)
+        x = (v[0::2] + 1j * v[1::2]).astype(np.complex64 if tag == "c32" else np.complex128)
+        case = f"{tag}_{n}_radix4"
+        put(case, "x", x); put(case, "y", ko.fft_radix4(x))
+        lines.append(f"radix4\t{case}\tdtype={tag}\tn={n}")
     (OUT / "manifest.tsv").write_text("\n".join(lines) + "\n")
     total = sum(f.stat().st_size for f in OUT.glob("*.bin"))
     print(f"{len(lines)} cases, {total / 1024:.0f} KiB in {OUT}")

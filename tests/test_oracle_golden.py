@@ -133,6 +133,43 @@ def test_bin_export_matches_the_oracle(oracle):
             assert bits_equal(oracle.rfft_table(int(p["m"]), dt), rd(case, "table", np.complex64 if dt == np.float32 else np.complex128)), case
         elif kind == "hann":
             assert bits_equal(oracle.hann(int(p["len"])), rd(case, "table", np.float32)), case
+        elif kind in ("fft_lcg", "fft_lcg_hash"):
+            import importlib.util
+
+            spec = importlib.util.spec_from_file_location("export_bin", GOLDEN / "export_bin.py")
+            eb = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(eb)
+            cdt = np.complex64 if p["dtype"] == "c32" else np.complex128
+            v = eb.lcg_values(int(p["seed"]), 2 * int(p["n"]))
+            assert v.dtype == np.float32 and np.all(v >= -1) and np.all(v < 1)
+            x = (v[0::2] + 1j * v[1::2]).astype(cdt)
+            y = oracle.fft(x)
+            if kind == "fft_lcg":
+                assert bits_equal(y, rd(case, "y", cdt)), case
+            else:
+                assert f"{eb.fnv1a64(y.tobytes()):016x}" == p["fnv1a64"], case
+        elif kind == "radix4":
+            cdt = np.complex64 if p["dtype"] == "c32" else np.complex128
+            assert bits_equal(oracle.fft_radix4(rd(case, "x", cdt)), rd(case, "y", cdt)), case
         else:
             raise AssertionError(kind)
-    assert kinds == {"fft", "rfft", "stft", "istft", "mags", "twiddles", "rffttab", "hann"}
+    assert kinds == {"fft", "rfft", "stft", "istft", "mags", "twiddles", "rffttab", "hann", "fft_lcg", "fft_lcg_hash", "radix4"}
+
+
+def test_lcg_stream_is_what_the_rust_harness_generates():
+    """The three-line generator of export_bin.py / golden_pin.rs, restated with plain Python integers."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("export_bin", GOLDEN / "export_bin.py")
+    eb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(eb)
+    state, want = 1401, []
+    for _ in range(64):
+        state = (state * 6364136223846793005 + 1442695040888963407) % (1 << 64)
+        want.append(np.float32(((state >> 40) & 0xFFFFFF)) / np.float32(8388608.0) - np.float32(1.0))
+    assert bits_equal(eb.lcg_values(1401, 64), np.array(want, np.float32))
+    assert eb.fnv1a64(bytes(range(16))) == 0x2B4A9E4A1B0F9B3D or True  # (value pinned below)
+    h = 0xCBF29CE484222325
+    for w in (int.from_bytes(bytes(range(8)), "little"), int.from_bytes(bytes(range(8, 16)), "little")):
+        h = ((h ^ w) * 0x100000001B3) % (1 << 64)
+    assert eb.fnv1a64(bytes(range(16))) == h
