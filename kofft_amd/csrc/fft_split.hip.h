@@ -387,4 +387,207 @@ __global__ __launch_bounds__((SplitGeom<LA, LB>::TPT), (SplitGeom<LA, LB>::TPT /
     if constexpr (io_has_acc<IO>::value) io.acc_finish(acc);
 }
 
+// ---- n = 2^14 (f32): the same decomposition with ONE buffer --------------------------------------------------------------
+// 16384 points are 128 KiB: one buffer fills the CU's LDS, and 1024 threads (16 wavefronts, 4 per SIMD) leave 128 registers
+// per thread.  Against the kernel above:
+//   * one LDS buffer, two s_barriers per transform: before a wavefront's first LDS write of phase A (every wave has left the
+//     previous transform's phase B reads) and between the phases; sixteen wavefronts hide each other's waits instead;
+//   * the table entries of passes A1 (16 x (2^QA1 - 1): they depend on the position k only) and B0 (2^LA rows x 15: they
+//     depend on the row K only) live in LDS beside the buffer, built once per workgroup; pass B1's entries depend on
+//     both and are re-read from the table in global memory (L2) at the start of every phase B -- kept in registers across
+//     the transform they put the kernel 10..20 registers over its 128 (scratch);
+//   * results are stored as each group of pass B1 completes (no second result set); the next transform's loads are issued
+//     into the input registers right after `finish` has consumed them.
+template <typename T, int LA, int LB, class IO>
+struct Split1State {
+    using Gm = SplitGeom<LA, LB>;
+    typename IO::Inv inv[16];
+    int cA, gA1, cB, gB1;
+    int tauA, tauB;
+    int twA1_off, twB0_off;  // LDS byte offsets of this thread's first table entries
+};
+
+// Q stages on 2^Q values with the entries read from LDS (entry (1 << t) - 1 + h at table + 8 * that).
+template <typename T, int Q, class Lds, bool STAGED = false>
+__device__ __forceinline__ void reg_pass_lds(cpx<T> *v, const int table_bytes)
+{
+#pragma unroll
+    for (int t = 0; t < Q; ++t) {
+        const int pos = Q - 1 - t;
+        if (STAGED) split_pin();  // one stage's entries at a time (at most 2^(Q-1) live): the scheduler would hoist all 2^Q - 1
+#pragma unroll
+        for (int h = 0; h < (1 << t); ++h) {
+            const cpx<T> w = Lds::ld(table_bytes + ((1 << t) - 1 + h) * (int)sizeof(cpx<T>));
+#pragma unroll
+            for (int lo = 0; lo < (1 << pos); ++lo) {
+                const int c = (h << (pos + 1)) | lo;
+                bfly(v[c], v[c | (1 << pos)], w);
+            }
+        }
+    }
+}
+
+template <typename T, int LA, int LB, class IO>
+__global__ __launch_bounds__((SplitGeom<LA, LB>::TPT)) void fft_split1_persist_kernel(const IO io, const cpx<T> *__restrict__ tw, const size_t batch)
+{
+    using Gm = SplitGeom<LA, LB>;
+    using Lds = SplitLds<T, LA, LB, IO>;
+    constexpr int R = 16;
+    constexpr int EA = (1 << Gm::QA1) - 1, EB1 = (1 << Gm::QB1) - 1;
+    constexpr int TABLE_A = Gm::N * (int)sizeof(cpx<T>);              // [k < 16][EA]
+    constexpr int TABLE_B = TABLE_A + 16 * EA * (int)sizeof(cpx<T>);  // [K < 2^LA][15]
+    static_assert(sizeof(cpx<T>) == 8, "8-byte cells");
+    using Raw = typename IO::Raw;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    if ((unsigned)(size_t)(__attribute__((address_space(3))) char *)smem_raw != 0u) __builtin_trap();  // SplitLds's addressing
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int ja = lane / Gm::CA, x = lane % Gm::CA;
+    const int jb = lane / Gm::RB, y = lane % Gm::RB;
+    const int col = w * Gm::CA + x, K = w * Gm::RB + y;
+
+    // ---- tables in LDS, built once: the same indices the register version above loads (TwSubFirst / TwSub)
+    for (int e = tid; e < 16 * EA; e += Gm::TPT) {
+        const int k = e / EA, i = e % EA;
+        int t = 0;
+        while (((2 << t) - 1) <= i) ++t;  // i = (1 << t) - 1 + h
+        const int h = i - ((1 << t) - 1);
+        int hr = 0;
+        for (int b = 0; b < t; ++b) hr |= ((h >> b) & 1) << (t - 1 - b);
+        Lds::st(TABLE_A + e * (int)sizeof(cpx<T>), tw[((k << (LA - 1 - 4 - t)) + (hr << (LA - 1 - t))) << LB]);
+    }
+    for (int e = tid; e < (1 << LA) * 15; e += Gm::TPT) {
+        const int row = e / 15, i = e % 15;
+        int t = 0;
+        while (((2 << t) - 1) <= i) ++t;
+        const int h = i - ((1 << t) - 1);
+        int hr = 0;
+        for (int b = 0; b < t; ++b) hr |= ((h >> b) & 1) << (t - 1 - b);
+        Lds::st(TABLE_B + e * (int)sizeof(cpx<T>), tw[((hr << (LB - 1 - t)) << LA) + (row << (LB - 1 - t))]);
+    }
+
+    Split1State<T, LA, LB, IO> st;
+    st.tauA = (ja << LB) | col;
+    st.tauB = (jb << LA) | K;
+    st.cA = Gm::cell_bytes(ja, col);
+    st.gA1 = Gm::cell_bytes(ja << Gm::QA1, col);
+    st.cB = Gm::cell_bytes(K, jb);
+    st.gB1 = Gm::cell_bytes(K, jb << Gm::QB1);
+    st.twA1_off = TABLE_A + ja * EA * (int)sizeof(cpx<T>);  // group g: + g * TA * EA entries
+    st.twB0_off = TABLE_B + K * 15 * (int)sizeof(cpx<T>);
+    // pass B1's entries: T[(tauB << (LB-5-t)) + ((g*TB) << (L-5-t)) + (rev_t(h) << (L-1-t))] -- one per-thread byte offset per
+    // stage t, the rest a constant that rides in the instruction's scalar offset
+    const rsrc_t twd = make_rsrc(tw, (unsigned)(Gm::N / 2) * (unsigned)sizeof(cpx<T>));
+#pragma unroll
+    for (int u = 0; u < R; ++u) st.inv[u] = io.invariant(u * Gm::TPT + st.tauA);
+    __syncthreads();  // tables complete
+
+    const size_t step = gridDim.x;
+    size_t base = blockIdx.x;
+    if (base >= batch) return;
+
+    Raw raw[R];
+    const int in_lane_bytes = st.tauA * IO::kRawBytes;
+    const int out_lane_bytes = st.tauB * (int)sizeof(cpx<T>);
+    typename persist_acc<IO>::type acc{};
+    if constexpr (io_has_acc<IO>::value) acc = io.acc_init();
+    auto loads = [&](const rsrc_t d, const int chunk) {
+#pragma unroll
+        for (int u = 4 * chunk; u < 4 * chunk + 4; ++u) raw[u] = io.fetch_d(d, in_lane_bytes, u * Gm::TPT, 0);
+    };
+    {
+        const rsrc_t d0 = io.in_desc_n(base, 1);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) loads(d0, c);
+    }
+    for (;;) {
+        const size_t nbase = base + step;
+        const bool more = nbase < batch;  // workgroup-uniform
+        const rsrc_t nd = io.in_desc_n(nbase, more ? 1 : 0);
+        const size_t xf = base;
+        int cA = st.cA, gA1 = st.gA1, cB = st.cB, gB1 = st.gB1, tA = st.twA1_off, tB = st.twB0_off;
+        asm volatile("" : "+v"(cA), "+v"(gA1), "+v"(cB), "+v"(gB1), "+v"(tA), "+v"(tB));  // (no hoisting of 96 addresses: see above)
+        cpx<T> cur[R];
+        KOFFT_SPLIT_STAMP(0)
+        if (io.inside(xf)) {
+#pragma unroll
+            for (int u = 0; u < R; ++u) cur[u] = io.finish_in(raw[u], st.inv[u]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < R; ++u) cur[u] = io.finish(xf, u * Gm::TPT + st.tauA, raw[u], st.inv[u]);
+        }
+        split_pin(); loads(nd, 0); loads(nd, 1); split_pin();
+        KOFFT_SPLIT_STAMP(1)
+        reg_pass<T, LA, 0, 4, true>(cur, 0, tw, TwSubFirst{LB});
+        split_pin(); loads(nd, 2); loads(nd, 3); split_pin();
+        KOFFT_SPLIT_STAMP(2)
+        __syncthreads();  // every wavefront has read the previous transform out of the buffer
+        KOFFT_SPLIT_STAMP(3)
+#pragma unroll
+        for (int u = 0; u < R; ++u) Lds::st(cA ^ Gm::a0_out_reg(u), cur[u]);
+        exchange_sync<true>();
+#pragma unroll
+        for (int u = 0; u < R; ++u) cur[u] = Lds::ld(gA1 ^ Gm::a1_in_reg(u));
+        KOFFT_SPLIT_STAMP(4)
+#pragma unroll
+        for (int g = 0; g < (16 >> Gm::QA1); ++g)
+            reg_pass_lds<T, Gm::QA1, Lds>(cur + g * (1 << Gm::QA1), tA + g * Gm::TA * EA * (int)sizeof(cpx<T>));
+        KOFFT_SPLIT_STAMP(5)
+        exchange_sync<true>();
+#pragma unroll
+        for (int u = 0; u < R; ++u) Lds::st(cA ^ Gm::a1_out_reg(u), cur[u]);
+        KOFFT_SPLIT_STAMP(6)
+        __syncthreads();  // the block-wide exchange
+        KOFFT_SPLIT_STAMP(7)
+        // pass B1's entries are requested HERE, while the memory pipeline holds nothing but the next transform's (long issued)
+        // loads: requested after pass B0 they queued behind the older wavefronts' result stores -- 128 KiB draining at HBM's
+        // rate -- and the younger wavefronts sat 9 000 .. 18 000 clocks in that exchange (s_memtime stamps).
+        cpx<T> twb[(16 >> Gm::QB1) * EB1];
+        auto load_twb = [&](const int g) {
+#pragma unroll
+            for (int t = 0; t < Gm::QB1; ++t)
+#pragma unroll
+                for (int h = 0; h < (1 << t); ++h)
+                    twb[g * EB1 + (1 << t) - 1 + h] = buf_load_cpx<T, AUX_DEFAULT>(
+                        twd, (st.tauB << (LB - 5 - t)) * (int)sizeof(cpx<T>),
+                        (((g * Gm::TB) << (Gm::L - 5 - t)) + (bitrev(h, t) << (Gm::L - 1 - t))) * (int)sizeof(cpx<T>));
+        };
+        load_twb(0);  // (the other groups after pass B0: all 14 entries beside B0's own put the kernel 10 registers into scratch)
+        split_pin();
+#pragma unroll
+        for (int u = 0; u < R; ++u) cur[u] = Lds::ld(cB ^ Gm::b0_in_reg(u));
+        KOFFT_SPLIT_STAMP(8)
+        reg_pass_lds<T, 4, Lds, true>(cur, tB);  // staged: one stage's entries at a time
+        KOFFT_SPLIT_STAMP(9)
+        split_pin();
+#pragma unroll
+        for (int g = 1; g < (16 >> Gm::QB1); ++g) load_twb(g);
+        split_pin();
+        exchange_sync<true>();
+#pragma unroll
+        for (int u = 0; u < R; ++u) Lds::st(cB ^ Gm::b0_out_reg(u), cur[u]);
+        exchange_sync<true>();
+#pragma unroll
+        for (int u = 0; u < R; ++u) cur[u] = Lds::ld(gB1 ^ Gm::b1_in_reg(u));
+        KOFFT_SPLIT_STAMP(10)
+        const rsrc_t od = io.out_desc_n(xf, 1);
+#pragma unroll
+        for (int g = 0; g < (16 >> Gm::QB1); ++g) {
+            reg_pass_r<T, Gm::QB1>(cur + g * (1 << Gm::QB1), twb + g * EB1);
+            split_pin();
+#pragma unroll
+            for (int u = g << Gm::QB1; u < ((g + 1) << Gm::QB1); ++u) {
+                if constexpr (io_has_acc<IO>::value) io.store_d_acc(od, out_lane_bytes, Gm::out_reg(u), cur[u], 0, acc);
+                else io.store_d(od, out_lane_bytes, Gm::out_reg(u), cur[u], 0);
+            }
+            split_pin();
+        }
+        KOFFT_SPLIT_STAMP(11)
+        if (!more) break;
+        base = nbase;
+    }
+    if constexpr (io_has_acc<IO>::value) io.acc_finish(acc);
+}
+
 }  // namespace kofft

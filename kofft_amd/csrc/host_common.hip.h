@@ -389,6 +389,28 @@ int launch_split(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t batc
     return KOFFT_OK;
 }
 
+// n = 2^14: the single-buffer, 16-wavefront form of the same kernel (tables for passes A1 / B0 beside the buffer)
+template <typename T, int LA, int LB, class IO>
+int launch_split1(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t batch)
+{
+    using Gm = SplitGeom<LA, LB>;
+    constexpr size_t lds = ((size_t)Gm::N + 16 * ((1 << Gm::QA1) - 1) + (size_t(1) << LA) * 15) * sizeof(cpx<T>);
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = fft_split1_persist_kernel<T, LA, LB, IO>;
+    {
+        static std::atomic<unsigned long long> attr_done{0};
+        const int arc = set_dyn_lds_once(ctx, attr_done, reinterpret_cast<const void *>(kern), lds);
+        if (arc) return arc;
+    }
+    size_t blocks = (size_t)ctx->num_cus;
+    if (ctx->persist_grid_pct > 0) blocks = blocks * (size_t)ctx->persist_grid_pct / 100;
+    if (blocks < 1) blocks = 1;
+    if (blocks > batch) blocks = batch;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Gm::TPT), lds, ctx->stream, io, tw, batch);
+    KOFFT_HIP_TRY(ctx, hipGetLastError());
+    return KOFFT_OK;
+}
+
 template <typename T, int N, int EPI, class IO>
 int launch_small(kofft_hip_ctx *ctx, const IO &io, size_t batch, const cpx<T> *tw = nullptr)
 {
@@ -448,6 +470,8 @@ int dispatch(kofft_hip_ctx *ctx, const IO &io, size_t n, size_t batch)
     if constexpr (sizeof(T) == 4 && !IO::kSlotMinor) if (L == 5 && ctx->small32) return launch_small<T, 32, EPI>(ctx, io, batch, tw);
     if constexpr (sizeof(T) == 4 && IO::kPersist) if (ctx->use_persist) {
         // streaming sizes: enough transforms to give every resident workgroup several iterations
+        if constexpr (EPI == EPI_STORE && io_split_ok<IO>::value)
+            if (L == 14 && ctx->use_split && batch >= (size_t)ctx->num_cus * 4) return launch_split1<T, 7, 7>(ctx, io, tw, batch);
         if constexpr (EPI == EPI_STORE && IO::kPersistMaxLog2 >= 13) {
             if constexpr (io_split_ok<IO>::value)
                 if (L == 13 && ctx->use_split && batch >= (size_t)ctx->num_cus * 4) return launch_split<T, 7, 6>(ctx, io, tw, batch);
