@@ -428,7 +428,7 @@ __device__ __forceinline__ void reg_pass_lds(cpx<T> *v, const int table_bytes)
 }
 
 template <typename T, int LA, int LB, class IO>
-__global__ __launch_bounds__((SplitGeom<LA, LB>::TPT)) void fft_split1_persist_kernel(const IO io, const cpx<T> *__restrict__ tw, const size_t batch)
+__global__ __launch_bounds__((SplitGeom<LA, LB>::TPT), 4) void fft_split1_persist_kernel(const IO io, const cpx<T> *__restrict__ tw, const size_t batch)
 {
     using Gm = SplitGeom<LA, LB>;
     using Lds = SplitLds<T, LA, LB, IO>;

@@ -57,6 +57,8 @@ struct kofft_hip_ctx {
     bool host_pipeline = true; // KOFFT_HIP_HOST_PIPELINE=0: host-pointer batches in one upload / kernel / download
     int host_chunks = 0;       // KOFFT_HIP_HOST_CHUNKS: pieces of a pipelined host batch (default 8)
     bool persist_small = true; // KOFFT_HIP_PERSIST_SMALL=0: n = 128, 256 on the generic kernels (A/B measurements)
+    int split13 = 1;           // KOFFT_HIP_SPLIT13=2: n = 8192 as TWO independent single-buffer workgroups per CU (fft_split1) instead of one
+                               // double-buffered one (measured, same box: c32 0.52-0.53 against 0.61-0.63, STFT 0.41 against 0.43)
     bool use_split = true;     // KOFFT_HIP_SPLIT=0: n = 8192 on the block-synchronised persistent kernel instead of the wave-split one (A/B)
     std::string last_error;
     // planner caches: (kind, n) -> device table.  kind 0/1 = FftPlanner twiddles f32/f64,
@@ -402,7 +404,8 @@ int launch_split1(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t bat
         const int arc = set_dyn_lds_once(ctx, attr_done, reinterpret_cast<const void *>(kern), lds);
         if (arc) return arc;
     }
-    size_t blocks = (size_t)ctx->num_cus;
+    // 16 wavefronts per CU either way: one 1024-thread workgroup (n = 16384) or two INDEPENDENT 512-thread ones (n = 8192)
+    size_t blocks = (size_t)ctx->num_cus * (1024 / Gm::TPT);
     if (ctx->persist_grid_pct > 0) blocks = blocks * (size_t)ctx->persist_grid_pct / 100;
     if (blocks < 1) blocks = 1;
     if (blocks > batch) blocks = batch;
@@ -473,8 +476,10 @@ int dispatch(kofft_hip_ctx *ctx, const IO &io, size_t n, size_t batch)
         if constexpr (EPI == EPI_STORE && io_split_ok<IO>::value)
             if (L == 14 && ctx->use_split && batch >= (size_t)ctx->num_cus * 4) return launch_split1<T, 7, 7>(ctx, io, tw, batch);
         if constexpr (EPI == EPI_STORE && IO::kPersistMaxLog2 >= 13) {
-            if constexpr (io_split_ok<IO>::value)
+            if constexpr (io_split_ok<IO>::value) {
+                if (L == 13 && ctx->use_split && ctx->split13 == 2 && batch >= (size_t)ctx->num_cus * 8) return launch_split1<T, 7, 6>(ctx, io, tw, batch);
                 if (L == 13 && ctx->use_split && batch >= (size_t)ctx->num_cus * 4) return launch_split<T, 7, 6>(ctx, io, tw, batch);
+            }
             if (L == 13 && batch >= (size_t)ctx->num_cus * 4) return launch_persist<T, 13, EPI>(ctx, io, tw, batch);
             if (L == 12 && batch >= (size_t)ctx->num_cus * 4) return launch_persist<T, 12, EPI>(ctx, io, tw, batch);
         }
