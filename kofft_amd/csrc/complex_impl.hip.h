@@ -99,14 +99,14 @@ int launch_rows_persist(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size
 // every CU has a workgroup; segments get narrower, but such a transform lives in the L2 / Infinity Cache anyway.
 template <class IO>
 inline void narrow_tile_adjust(IO &, size_t) {}
-template <typename T, bool INVERSE>
-inline void narrow_tile_adjust(BigRowsIO<T, INVERSE> &io, size_t segment_bytes)
+template <typename T, bool INVERSE, int POST>
+inline void narrow_tile_adjust(BigRowsIO<T, INVERSE, POST> &io, size_t segment_bytes)
 {
     if (segment_bytes < 64) io.nt = false;  // streaming stores only for segments of at least half a line (as in fft_big_dev)
     io.nt_load = false;                     // (a single transform's intermediate sits in the caches anyway)
 }
-template <typename T, bool INVERSE>
-inline void narrow_tile_adjust(BigColsIO<T, INVERSE> &io, size_t segment_bytes)
+template <typename T, bool INVERSE, int PRE>
+inline void narrow_tile_adjust(BigColsIO<T, INVERSE, PRE> &io, size_t segment_bytes)
 {
     if (segment_bytes < 64) io.nt_in_pieces = false;  // pieces of less than half a line: the neighbours want the rest
 }
@@ -194,8 +194,12 @@ int launch_mid(kofft_hip_ctx *ctx, const BigMidIO<T> &io, const cpx<T> *tw, int 
 template <typename T>
 inline int big_rows_per_wg(int LB) { return LB <= 9 ? KOFFT_BIG_XPB(T) : LB == 10 ? 8 : LB == 11 ? 4 : LB == 12 ? 2 : 1; }
 
-template <typename T, bool INVERSE>
-int fft_big_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t batch)
+// The factor path with the policies of its first and last factor as parameters (round 3): ColsIO / RowsIO are BigColsIO /
+// BigRowsIO instances, possibly with a folded pointwise factor (PRE / POST) whose extra fields fix_cols / fix_rows fill in;
+// such policies may read input rows of in_row values and write output rows of out_row values (the transform itself is n).
+template <typename T, class ColsIO, class RowsIO, class FixCols, class FixRows>
+int fft_big_core(kofft_hip_ctx *ctx, const cpx<T> *in_base, size_t in_row, cpx<T> *out_base, size_t out_row, size_t n, size_t batch,
+                 FixCols fix_cols, FixRows fix_rows)
 {
     const int L = ilog2(n);
     // Two factors while both stay <= 2^10 points (tiles of 8 adjacent columns / rows, 64..128-byte segments); from 2^22
@@ -234,10 +238,11 @@ int fft_big_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t ba
     const T scale = (T)1 / (T)(float)n;
     for (size_t b0 = 0; b0 < batch; b0 += chunk) {
         const size_t nb = (batch - b0 < chunk) ? batch - b0 : chunk;
-        const cpx<T> *src = reinterpret_cast<const cpx<T> *>(d_in) + b0 * n;
-        cpx<T> *dst = reinterpret_cast<cpx<T> *>(d_out) + b0 * n;
+        const cpx<T> *src = in_base + b0 * in_row;
+        cpx<T> *dst = out_base + b0 * out_row;
         // first factor: stages 0 .. L1-1 down the columns of a 2^L1 x 2^(L-L1) matrix
-        BigColsIO<T, INVERSE> a{src, mid, L - L1, L - L1, n};
+        ColsIO a{src, mid, L - L1, L - L1, n};
+        fix_cols(a);
         rc = launch_sub<T>(ctx, a, tw, L1, nb << (L - L1), ctx->big_first_persist >= 0 ? ctx->big_first_persist != 0 : ctx->big_persist);
         if (rc) return rc;
         const cpx<T> *last_in = mid;
@@ -249,7 +254,8 @@ int fft_big_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t ba
         }
         // last factor: the remaining L3 stages along contiguous rows, prefix K of L - L3 bits, output transposed
         const int LP = L - L3;
-        BigRowsIO<T, INVERSE> b{last_in, dst, LP, L3, L - L3, L - 1 - LP, n, scale, big_rows_per_wg<T>(L3) * sizeof(cpx<T>) >= 64};
+        RowsIO b{last_in, dst, LP, L3, L - L3, L - 1 - LP, n, scale, big_rows_per_wg<T>(L3) * sizeof(cpx<T>) >= 64};
+        fix_rows(b);
         // an intermediate small enough to stay in the 256 MiB Infinity Cache is read with plain loads (measured on a
         // copy model, tools/ubench_mall: streaming hints on the caller's buffers only, 3.1 -> 2.5 ms per 2 x 4 GiB)
         // ... and only where a wavefront's load instruction covers at least half a line per row: with 16-row c32 tiles (rows up
@@ -275,6 +281,26 @@ int fft_big_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t ba
         if (rc) return rc;
     }
     return KOFFT_OK;
+}
+
+template <typename T, bool INVERSE>
+int fft_big_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t batch)
+{
+    return fft_big_core<T, BigColsIO<T, INVERSE>, BigRowsIO<T, INVERSE>>(
+        ctx, reinterpret_cast<const cpx<T> *>(d_in), n, reinterpret_cast<cpx<T> *>(d_out), n, n, batch, [](BigColsIO<T, INVERSE> &) {},
+        [](BigRowsIO<T, INVERSE> &) {});
+}
+
+// The m-point transform of rfft_direct's packed row z[i] = (x[2i], x[2i+1]) (rfft.rs:444-447) with the row window of the
+// batched entry folded into the first factor's load (PRE_WINDOW): m a power of two beyond the single-workgroup sizes.
+template <typename T>
+int fft_big_windowed_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, const T *d_window, size_t m, size_t batch)
+{
+    using Cols = BigColsIO<T, false, PRE_WINDOW>;
+    using Rows = BigRowsIO<T, false>;
+    return fft_big_core<T, Cols, Rows>(
+        ctx, reinterpret_cast<const cpx<T> *>(d_in), m, reinterpret_cast<cpx<T> *>(d_out), m, m, batch,
+        [&](Cols &c) { c.pre_tab = reinterpret_cast<const cpx<T> *>(d_window); }, [](Rows &) {});
 }
 
 // ---------------------------------------------------------------------------------
@@ -415,6 +441,26 @@ int fft_bluestein_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, siz
             if (rc) return rc;
             BlueSecondIO<T, INVERSE> io2{{}, a, dst, chirp, (int)n, (int)m, scale_m, scale_n};
             rc = dispatch<T, EPI_STORE>(ctx, io2, m, nb);
+            if (rc) return rc;
+            continue;
+        }
+        if (ctx->blue_fused && is_pow2(m) && m > (size_t(1) << max_log2<T>())) {
+            // m beyond one workgroup's transform (round 3): the three pointwise steps ride on the factor kernels -- x * chirp and
+            // the zero padding on the first factor's load, * fft(b) + conj on the first transform's last store, conj * 1/m * chirp
+            // on the second one's (BigColsIO PRE_CHIRP, BigRowsIO POST_BLUE_MID / POST_BLUE_OUT): 4 passes over the padded
+            // buffer instead of 7.  Same expressions per element as the three kernels below.
+            using Cols1 = BigColsIO<T, INVERSE, PRE_CHIRP>;
+            using Rows1 = BigRowsIO<T, false, POST_BLUE_MID>;
+            rc = fft_big_core<T, Cols1, Rows1>(
+                ctx, src, n, a, m, m, nb,
+                [&](Cols1 &c) { c.pre_tab = chirp; c.n_in = (unsigned)n; },
+                [&](Rows1 &r) { r.post_tab = bfft; });
+            if (rc) return rc;
+            using Cols2 = BigColsIO<T, false, PRE_NONE>;
+            using Rows2 = BigRowsIO<T, INVERSE, POST_BLUE_OUT>;
+            rc = fft_big_core<T, Cols2, Rows2>(
+                ctx, a, m, dst, n, m, nb, [](Cols2 &) {},
+                [&](Rows2 &r) { r.post_tab = chirp; r.n_out = (unsigned)n; r.scale = scale_m; r.scale_out = scale_n; });
             if (rc) return rc;
             continue;
         }

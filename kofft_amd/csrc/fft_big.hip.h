@@ -32,7 +32,17 @@ namespace kofft {
 
 // factor A: unit xf = (b, j) with j in [0, 2^LB): column j of transform b.  Adjacent units are adjacent columns,
 // so lanes run over units first (kSlotMinor) and a wave touches whole 128-byte lines.
-template <typename T, bool INVERSE>
+//
+// PRE (round 3): a pointwise factor folded into the first factor's LOAD, so that transforms composed around the factor path
+// need no separate pass over HBM for it (fft.rs:1088-1132, rfft.rs:444-447 with stft.rs:96's product):
+//   PRE_NONE   the plain transform;
+//   PRE_CHIRP  Bluestein's a = x * chirp, zero-padded: the input rows are n_in values long (stride n_in), element i >= n_in is
+//              exactly (0, 0) (the descriptor's bounds check supplies the zero, the select keeps its sign), INVERSE = ifft's
+//              conj on the way in, BEFORE the product -- the expressions of BlueFirstIO / bluestein_pre_kernel;
+//   PRE_WINDOW the real transform's pack: the row read as m complex values z[i] = (x[2i], x[2i+1]), each part times its own
+//              window sample (pre_tab read as pairs): real_window_kernel's product.
+enum : int { PRE_NONE = 0, PRE_CHIRP = 1, PRE_WINDOW = 2 };
+template <typename T, bool INVERSE, int PRE = PRE_NONE>
 struct BigColsIO {
     static constexpr bool kStreams = false;
     static constexpr bool kPersist = false;
@@ -40,12 +50,15 @@ struct BigColsIO {
     static constexpr bool kPairXcd = true;
     static constexpr bool kSplitLds = sizeof(T) == 8;  // c64: 8-byte exchange elements (re / im in two rounds), 8-column tiles fit twice per CU
     static constexpr int kMinWaves = sizeof(T) == 8 ? 4 : 1;  // two 512-thread workgroups per CU need <= 128 VGPRs
+    static constexpr int kPre = PRE;
     const cpx<T> *__restrict__ in;
     cpx<T> *__restrict__ out;
     int LB;     // log2 of the column count
     int shift;  // L - LA
     size_t n;   // full transform length
     bool nt_in_pieces = true;  // streaming loads: off for tiles narrower than half a line (narrow tiles of a single transform)
+    const cpx<T> *__restrict__ pre_tab = nullptr;  // PRE_CHIRP: chirp (n_in entries); PRE_WINDOW: the window as n pairs
+    unsigned n_in = 0;                             // PRE_CHIRP: values per input row (= its stride)
     static constexpr bool nt = false;  // the intermediate is read back by the next factor: plain stores
     __device__ __forceinline__ TwSubFirst tw_map(size_t) const { return TwSubFirst{shift}; }
     // tile forms (fft_tile_persist_kernel): local index i of unit xf lives at  transform(xf) * n + off(xf) + (i << sl)
@@ -53,6 +66,23 @@ struct BigColsIO {
     static constexpr bool kTileInvariantTw = true;  // no frequency prefix yet: every tile uses the same 2^(L_sub-1) table entries
     __device__ __forceinline__ bool nt_in() const { return nt_in_pieces; }
     __device__ __forceinline__ T out_scale() const { return T(1); }
+    __device__ __forceinline__ size_t in_row() const { return PRE == PRE_CHIRP ? (size_t)n_in : n; }     // input row stride = valid values
+    __device__ __forceinline__ size_t out_row() const { return n; }
+    __device__ __forceinline__ size_t out_valid() const { return n; }
+    // the value the transform sees for element `elem` of its row, from the loaded (and, for ifft, conjugated) value
+    __device__ __forceinline__ cpx<T> pre(cpx<T> v, unsigned elem) const
+    {
+        if constexpr (PRE == PRE_CHIRP) {
+            const unsigned ec = elem < n_in ? elem : n_in - 1;  // branch-free: clamp the address, select the value
+            const cpx<T> a = cmul(v, pre_tab[ec]);
+            return elem < n_in ? a : mk<T>(T(0), T(0));
+        } else if constexpr (PRE == PRE_WINDOW) {
+            const cpx<T> w = pre_tab[elem];
+            return mk<T>(v.re * w.re, v.im * w.im);
+        } else {
+            return v;
+        }
+    }
     __device__ __forceinline__ size_t xf_transform(size_t xf) const { return xf >> LB; }
     __device__ __forceinline__ unsigned in_off(size_t xf) const { return (unsigned)(xf & ((size_t(1) << LB) - 1)); }
     __device__ __forceinline__ int in_sl() const { return LB; }
@@ -61,10 +91,13 @@ struct BigColsIO {
     __device__ __forceinline__ cpx<T> load(size_t xf, int c) const
     {
         const size_t b = xf >> LB, j = xf & ((size_t(1) << LB) - 1);
-        const cpx<T> *p = in + b * n + ((size_t)c << LB) + j;
+        const size_t elem = ((size_t)c << LB) + j;
+        size_t ec = elem;
+        if constexpr (PRE == PRE_CHIRP) ec = elem < n_in ? elem : n_in - 1;
+        const cpx<T> *p = in + b * in_row() + ec;
         cpx<T> v = nt_in_pieces ? ld_stream(p) : *p;  // read once
         if (INVERSE) v.im = -v.im;  // ifft: conj on the way in (fft.rs:1163-1165)
-        return v;
+        return pre(v, (unsigned)elem);
     }
     __device__ __forceinline__ void store(size_t xf, int q, cpx<T> v) const
     {
@@ -74,7 +107,14 @@ struct BigColsIO {
 };
 
 // factor B: unit xf = (b, K) with K in [0, 2^LA): row K of transform b (contiguous), output transposed.
-template <typename T, bool INVERSE>
+//
+// POST (round 3): a pointwise factor folded into the last factor's STORE:
+//   POST_NONE      the plain transform (INVERSE: ifft's conj, * 1/n);
+//   POST_BLUE_MID  Bluestein's a *= fft(b), then ifft's conj on the way in (fft.rs:1119-1121, 1163-1165): BlueFirstIO::store;
+//   POST_BLUE_OUT  Bluestein's way out: conj, * 1/m, * chirp, INVERSE: conj, * 1/n_out; only the first n_out outputs exist,
+//                  in rows of n_out values (the descriptor's bounds check drops the rest): BlueSecondIO::store.
+enum : int { POST_NONE = 0, POST_BLUE_MID = 1, POST_BLUE_OUT = 2 };
+template <typename T, bool INVERSE, int POST = POST_NONE>
 struct BigRowsIO {
     static constexpr bool kStreams = false;
     static constexpr bool kPersist = false;
@@ -82,20 +122,47 @@ struct BigRowsIO {
     static constexpr bool kPairXcd = true;
     static constexpr bool kSplitLds = sizeof(T) == 8;
     static constexpr int kMinWaves = sizeof(T) == 8 ? 4 : 1;
+    static constexpr int kPost = POST;
     const cpx<T> *__restrict__ in;
     cpx<T> *__restrict__ out;
     int LA, LB;
     int shift;  // L - LB
     int kbase;  // L - 1 - LA
     size_t n;
-    T scale;    // 1 / (n as f32 as T), fft.rs:1167
+    T scale;    // 1 / (n as f32 as T), fft.rs:1167 (POST_BLUE_OUT: 1 / (m as f32 as T))
     bool nt;    // non-temporal stores: only when a workgroup's adjacent rows fill at least 64-byte segments
     bool nt_load = true;  // the intermediate is read once: streaming hint, unless it is meant to be served by the Infinity Cache
+    const cpx<T> *__restrict__ post_tab = nullptr;  // POST_BLUE_MID: fft(b) (n entries); POST_BLUE_OUT: chirp (n_out entries)
+    unsigned n_out = 0;                              // POST_BLUE_OUT: values per output row (= its stride)
+    T scale_out = T(1);                              // POST_BLUE_OUT, INVERSE: 1 / (n_out as f32 as T)
     __device__ __forceinline__ TwSub tw_map(size_t xf) const { return TwSub{shift, (int)(xf & ((size_t(1) << LA) - 1)), kbase}; }
-    static constexpr bool kConjIn = false, kConjScaleOut = INVERSE, kNtOut = true;
+    static constexpr bool kConjIn = false, kConjScaleOut = INVERSE && POST == POST_NONE, kNtOut = true;
     static constexpr bool kTileInvariantTw = false;  // the table index carries the row's prefix K
     __device__ __forceinline__ bool nt_in() const { return nt_load; }
     __device__ __forceinline__ T out_scale() const { return scale; }
+    __device__ __forceinline__ size_t in_row() const { return n; }
+    __device__ __forceinline__ size_t out_row() const { return POST == POST_BLUE_OUT ? (size_t)n_out : n; }
+    __device__ __forceinline__ size_t out_valid() const { return out_row(); }
+    // the value stored at output index o (after the plain transform's own conj / scale, which POST modes do not use)
+    __device__ __forceinline__ cpx<T> post(cpx<T> v, unsigned o) const
+    {
+        if constexpr (POST == POST_BLUE_MID) {
+            cpx<T> w = cmul(v, post_tab[o]);
+            w.im = -w.im;
+            return w;
+        } else if constexpr (POST == POST_BLUE_OUT) {
+            v.im = -v.im;  // ifft: conj, * 1/m (fft.rs:1168-1172)
+            v = mk<T>(v.re * scale, v.im * scale);
+            cpx<T> r = cmul(v, post_tab[o < n_out ? o : n_out - 1]);
+            if (INVERSE) {
+                const T im = -r.im;
+                r = mk<T>(r.re * scale_out, im * scale_out);
+            }
+            return r;
+        } else {
+            return v;
+        }
+    }
     __device__ __forceinline__ size_t xf_transform(size_t xf) const { return xf >> LA; }
     __device__ __forceinline__ unsigned in_off(size_t xf) const { return (unsigned)((xf & ((size_t(1) << LA) - 1)) << LB); }
     __device__ __forceinline__ int in_sl() const { return 0; }
@@ -110,12 +177,17 @@ struct BigRowsIO {
     __device__ __forceinline__ void store(size_t xf, int q, cpx<T> v) const
     {
         const size_t b = xf >> LA, K = xf & ((size_t(1) << LA) - 1);
-        if (INVERSE) {  // conj, then scale (fft.rs:1168-1172)
+        const size_t o = ((size_t)q << LA) + K;
+        if (kConjScaleOut) {  // conj, then scale (fft.rs:1168-1172)
             const T im = -v.im;
             v = mk<T>(v.re * scale, im * scale);
         }
-        if (nt) st_stream(out + b * n + ((size_t)q << LA) + K, v);
-        else out[b * n + ((size_t)q << LA) + K] = v;
+        if constexpr (POST == POST_BLUE_OUT) {
+            if (o >= n_out) return;
+        }
+        v = post(v, (unsigned)o);
+        if (nt) st_stream(out + b * out_row() + o, v);
+        else out[b * out_row() + o] = v;
     }
 };
 
@@ -278,6 +350,15 @@ struct TileExchange {
 };
 
 template <class IO, class = void>
+struct io_pre { static constexpr int value = 0; };
+template <class IO>
+struct io_pre<IO, decltype((void)IO::kPre)> { static constexpr int value = IO::kPre; };
+template <class IO, class = void>
+struct io_post { static constexpr int value = 0; };
+template <class IO>
+struct io_post<IO, decltype((void)IO::kPost)> { static constexpr int value = IO::kPost; };
+
+template <class IO, class = void>
 struct io_tile_group_tw { static constexpr bool value = false; };
 template <class IO>
 struct io_tile_group_tw<IO, decltype((void)IO::kTileGroupTw)> { static constexpr bool value = IO::kTileGroupTw; };
@@ -362,12 +443,23 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 1024 ? 4 : 2)) void fft_tile_persi
     };
     const int in_sl = io.in_sl(), out_sl = io.out_sl();
     const unsigned xf_bytes = (unsigned)(io.n * sizeof(cpx<T>));  // n <= 2^26 points: below 4 GiB
+    // policies with a folded pointwise factor (PRE / POST) may read or write rows of another length than the transform's
+    size_t in_row = io.n, out_row = io.n;
+    unsigned in_bytes = xf_bytes, out_bytes = xf_bytes;
+    if constexpr (io_pre<IO>::value != 0) {
+        in_row = io.in_row();
+        in_bytes = (unsigned)(in_row * sizeof(cpx<T>));
+    }
+    if constexpr (io_post<IO>::value != 0) {
+        out_row = io.out_row();
+        out_bytes = (unsigned)(io.out_valid() * sizeof(cpx<T>));
+    }
 
     auto issue_loads = [&](cpx<T> *dst, const size_t t, const bool valid) {
         // an EMPTY descriptor when there is no next tile: the loads return zeros without touching memory, and no branch
         // sits between them (see fft_persist.hip.h)
         const size_t xf0 = (valid ? t : 0) * XPB;
-        const rsrc_t d = make_rsrc(io.in + io.xf_transform(xf0) * io.n, valid ? xf_bytes : 0u);
+        const rsrc_t d = make_rsrc(io.in + io.xf_transform(xf0) * in_row, valid ? in_bytes : 0u);
         const int lane = (int)((io.in_off(xf0 + slot) + ((unsigned)tau << in_sl)) * (unsigned)ES);
         if (io.nt_in()) {
 #pragma unroll
@@ -392,13 +484,18 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 1024 ? 4 : 2)) void fft_tile_persi
 #pragma unroll
             for (int u = 0; u < R; ++u) cur[u].im = -cur[u].im;  // ifft: conj on the way in (fft.rs:1163-1165)
         }
+        if constexpr (io_pre<IO>::value != 0) {
+            const unsigned e0 = io.in_off(xf) + ((unsigned)tau << in_sl);
+#pragma unroll
+            for (int u = 0; u < R; ++u) cur[u] = io.pre(cur[u], e0 + ((unsigned)G0::in_index(0, u) << in_sl));
+        }
         compute(std::integral_constant<int, 0>{}, cur, xf);
         if constexpr (NP > 1) { TileExchange<T, L, RL, XPB, SPLIT>::template run<0>(cur, smem_raw, tau, slot); compute(std::integral_constant<int, 1>{}, cur, xf); }
         if constexpr (NP > 2) { TileExchange<T, L, RL, XPB, SPLIT>::template run<1>(cur, smem_raw, tau, slot); compute(std::integral_constant<int, 2>{}, cur, xf); }
         if constexpr (NP > 3) { TileExchange<T, L, RL, XPB, SPLIT>::template run<2>(cur, smem_raw, tau, slot); compute(std::integral_constant<int, 3>{}, cur, xf); }
         if constexpr (NP > 4) { TileExchange<T, L, RL, XPB, SPLIT>::template run<3>(cur, smem_raw, tau, slot); compute(std::integral_constant<int, 4>{}, cur, xf); }
         const size_t xf0 = t * XPB;
-        const rsrc_t d = make_rsrc(io.out + io.xf_transform(xf0) * io.n, xf_bytes);
+        const rsrc_t d = make_rsrc(io.out + io.xf_transform(xf0) * out_row, out_bytes);
         const int lane = (int)((io.out_off(xf) + ((unsigned)tau << out_sl)) * (unsigned)ES);
         const T scale = io.out_scale();
         // 16-byte stores: the register offset goes into the VGPR offset, NOT into the SGPR offset field.  hipcc pads the
@@ -415,6 +512,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 1024 ? 4 : 2)) void fft_tile_persi
                 v = mk<T>(v.re * scale, im * scale);
             }
             const int off = lane + (GL::out_index(0, u) << out_sl) * ES;
+            if constexpr (io_post<IO>::value != 0) v = io.post(v, (unsigned)off / (unsigned)ES);
             if (nt_out) buf_store_cpx_aux<T, AUX_NT>(v, d, off, 0);
             else buf_store_cpx_aux<T, AUX_DEFAULT>(v, d, off, 0);
         }
@@ -545,6 +643,12 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 1024 ? 4 : 2)) void fft_rows_persi
     unsigned b = b_first;
 
     const unsigned xf_bytes = (unsigned)(io.n * sizeof(cpx<T>));
+    size_t out_row = io.n;
+    unsigned out_bytes = xf_bytes;
+    if constexpr (io_post<IO>::value != 0) {  // a folded pointwise factor may write rows of another length
+        out_row = io.out_row();
+        out_bytes = (unsigned)(io.out_valid() * sizeof(cpx<T>));
+    }
     const int out_sl = io.LA;
     auto issue_loads = [&](cpx<T> *dst, const unsigned tkt, const unsigned tb, const bool valid) {
         // (walking the transforms last to first, so that the most recently written part of the intermediate is read first,
@@ -616,7 +720,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 1024 ? 4 : 2)) void fft_rows_persi
         TileExchange<T, L, RL, XPB, SPLIT>::template run<NP - 2>(cur, smem_raw, tau, slot);
 #pragma unroll
         for (int g = 0; g < GRP; ++g) reg_pass_r<T, QL>(cur + g * (1 << QL), twl + g * ((1 << QL) - 1));
-        const rsrc_t d = make_rsrc(io.out + (size_t)tb * io.n, xf_bytes);
+        const rsrc_t d = make_rsrc(io.out + (size_t)tb * out_row, out_bytes);
         const int lane = (int)((tkt * XPB + slot + ((unsigned)tau << out_sl)) * (unsigned)ES);
         const T scale = io.out_scale();
         if (!do_store) return;
@@ -628,7 +732,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 1024 ? 4 : 2)) void fft_rows_persi
                 const T im = -v.im;
                 v = mk<T>(v.re * scale, im * scale);
             }
-            buf_store_cpx_aux<T, AUX_NT>(v, d, lane + (GL::out_index(0, u) << out_sl) * ES, 0);
+            const int off = lane + (GL::out_index(0, u) << out_sl) * ES;
+            if constexpr (io_post<IO>::value != 0) v = io.post(v, (unsigned)off / (unsigned)ES);
+            buf_store_cpx_aux<T, AUX_NT>(v, d, off, 0);
         }
     };
 

@@ -540,6 +540,8 @@ inline int ensure_real_tmp(kofft_hip_ctx *ctx, size_t bytes)
 template <typename T>
 int fft_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t batch, int inverse);  // k_complex_f32/f64.hip
 template <typename T>
+int fft_big_windowed_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, const T *d_window, size_t m, size_t batch);  // factor path, window in the first load
+template <typename T>
 int fft_radix4_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t batch);  // fft.rs:1455-1548, the reference's bytes (opt-in)
 template <typename T>
 int rfft_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, const T *d_window, size_t n, size_t batch);  // k_real_f32/f64.hip

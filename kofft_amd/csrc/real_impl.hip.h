@@ -79,8 +79,11 @@ int rfft_composed_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, const T *d_wi
     if (chunk < 1) chunk = 1;
     if (chunk > batch) chunk = batch;
     if ((chunk * (m + 1) + 255) / 256 > 0x7fffffffULL) return KOFFT_ERR_UNSUPPORTED;
-    // scratch: [windowed input (only with a window)] [Y]
-    const size_t zbytes = d_window ? chunk * n * sizeof(T) : 0, ybytes = chunk * m * sizeof(cpx<T>);
+    // Powers of two beyond the single-workgroup sizes (round 3): the window product rides on the factor path's first load
+    // (BigColsIO PRE_WINDOW) -- one pass over the input less.  Other lengths (Bluestein's inner transform) keep the kernel.
+    const bool fuse_window = d_window && is_pow2(m) && m > (size_t(1) << max_log2<T>()) && ctx->blue_fused;
+    // scratch: [windowed input (only with an unfused window)] [Y]
+    const size_t zbytes = (d_window && !fuse_window) ? chunk * n * sizeof(T) : 0, ybytes = chunk * m * sizeof(cpx<T>);
     rc = ensure_real_tmp(ctx, zbytes + ybytes);
     if (rc) return rc;
     T *z = static_cast<T *>(ctx->real_tmp);
@@ -88,14 +91,19 @@ int rfft_composed_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, const T *d_wi
     for (size_t b0 = 0; b0 < batch; b0 += chunk) {
         const size_t nb = (batch - b0 < chunk) ? batch - b0 : chunk;
         const T *src = d_in + b0 * n;
-        if (d_window) {
+        if (fuse_window) {
+            rc = fft_big_windowed_dev<T>(ctx, src, y, d_window, m, nb);
+            if (rc) return rc;
+        } else if (d_window) {
             hipLaunchKernelGGL(real_window_kernel<T>, dim3(blocks_for(nb * n)), dim3(256), 0, ctx->stream, src, d_window, z, n, nb * n);
             KOFFT_HIP_TRY(ctx, hipGetLastError());
             src = z;
         }
         // z[i] = (x[2i], x[2i+1]) (rfft.rs:444-446) is the row itself read as m complex values
-        rc = fft_dev<T>(ctx, src, y, m, nb, 0);
-        if (rc) return rc;
+        if (!fuse_window) {
+            rc = fft_dev<T>(ctx, src, y, m, nb, 0);
+            if (rc) return rc;
+        }
         hipLaunchKernelGGL(rfft_post_kernel<T>, dim3(blocks_for(nb * (m + 1))), dim3(256), 0, ctx->stream,
                            reinterpret_cast<const cpx<T> *>(y), rtab, reinterpret_cast<cpx<T> *>(d_out) + b0 * (m + 1), m, nb * (m + 1));
         KOFFT_HIP_TRY(ctx, hipGetLastError());

@@ -452,6 +452,48 @@ def test_rfft_irfft_any_length_f32(fft32, oracle, n, batch):
     assert_parity(fft32.irfft_batch(spec, n), oracle.irfft(spec, n), f"composed irfft n={n}", REL_TOL_F32)
 
 
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_pointwise_factors_folded_into_the_factor_kernels(oracle, fused):
+    """Round 3: for inner lengths beyond one workgroup's transform the Bluestein products ride on the factor
+    kernels' first load / last stores (BigColsIO PRE_CHIRP, BigRowsIO POST_BLUE_MID / POST_BLUE_OUT) and the row window of the
+    real transform on the first load (PRE_WINDOW).  Batches large enough for the PERSISTENT factor kernels (the small-batch
+    tests above take the one-tile kernels' load() / store() forms), forward and inverse, f32 and f64, against the oracle; the
+    separate pointwise kernels (KOFFT_HIP_BLUESTEIN_FUSED=0) give the same bits."""
+    import os
+
+    import kofft_amd
+
+    os.environ["KOFFT_HIP_BLUESTEIN_FUSED"] = fused
+    try:
+        f32, f64 = kofft_amd.HipFftImpl(np.float32), kofft_amd.HipFftImpl(np.float64)
+    finally:
+        del os.environ["KOFFT_HIP_BLUESTEIN_FUSED"]
+    rng = seeded(6100)
+    x = rand_c(rng, (160, 20000))            # m = 65536: two factors, 160 * 256 columns
+    pick = [0, 1, 77, 159]
+    y = x.copy()
+    f32.fft_batch(y)
+    assert bits_equal(y[pick], oracle.fft(x[pick]))
+    y = x.copy()
+    f32.fft_batch(y, inverse=True)
+    assert bits_equal(y[pick], oracle.ifft(x[pick]))
+    xd = rand_c(rng, (96, 9001), np.complex128)   # m = 32768 in f64
+    yd = xd.copy()
+    f64.fft_batch(yd)
+    assert bits_equal(yd[[0, 50, 95]], oracle.fft(xd[[0, 50, 95]]))
+    yd = xd.copy()
+    f64.fft_batch(yd, inverse=True)
+    assert bits_equal(yd[[0, 50, 95]], oracle.ifft(xd[[0, 50, 95]]))
+    r = rng.uniform(-1, 1, (80, 65536)).astype(np.float32)   # rfft: m = 32768 complex, window folded into the first factor
+    win = rng.uniform(0, 1, 65536).astype(np.float32)
+    got = f32.rfft_batch(r, win)
+    assert bits_equal(got[[0, 41, 79]], oracle.rfft(r[[0, 41, 79]], win))
+    rd = rng.uniform(-1, 1, (70, 32768))                        # f64: m = 16384
+    wd = rng.uniform(0, 1, 32768)
+    gd = f64.rfft_batch(rd, wd)
+    assert bits_equal(gd[[0, 69]], oracle.rfft(rd[[0, 69]], wd))
+
+
 @pytest.mark.parametrize("n,batch", [(12, 5), (1000, 4), (65536, 2), (34, 3)])
 def test_rfft_irfft_any_length_f64(fft64, oracle, n, batch):
     rng = seeded(3100 + n % 977)
