@@ -113,6 +113,49 @@ struct SplitState {
     bool young;  // the second wavefront on its SIMD (wave-uniform)
 };
 
+// KOFFT_SPLIT_FINE: memory instructions two at a time between the STAGES of the passes (8 slots per phase) instead of four
+// at a time between the passes (4 slots).
+#ifndef KOFFT_SPLIT_FINE
+#define KOFFT_SPLIT_FINE 0
+#endif
+// reg_pass (pass A0: compile-time table indices) with a callback after every stage
+template <typename T, int L, int Q, class TwMap, class Cb>
+__device__ __forceinline__ void split_pass0_cb(cpx<T> *v, const cpx<T> *__restrict__ tw, const TwMap map, const Cb &cb)
+{
+#pragma unroll
+    for (int t = 0; t < Q; ++t) {
+        const int pos = Q - 1 - t;
+#pragma unroll
+        for (int b = 0; b < (1 << (Q - 1)); ++b) {  // butterfly b of the stage: group h, position lo
+            const int h = b >> pos, lo = b & ((1 << pos) - 1);
+            const int idx = bitrev(h, t) << (L - 1 - t);
+            const cpx<T> w = tw[map(idx, t)];
+            const int c = (h << (pos + 1)) | lo;
+            bfly<T, true>(v[c], v[c | (1 << pos)], w);
+            if (KOFFT_SPLIT_FINE >= 2 && b == (1 << (Q - 2)) - 1) cb(t);  // half way through the stage
+        }
+        cb(t);
+    }
+}
+// reg_pass_r over G groups, stage by stage across the groups, with a callback after every stage
+template <typename T, int Q, class Cb>
+__device__ __forceinline__ void split_compute_cb(cpx<T> *v, const cpx<T> *twr, const Cb &cb)
+{
+#pragma unroll
+    for (int t = 0; t < Q; ++t) {
+        const int pos = Q - 1 - t;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {  // the stage's 8 butterflies: group g, twiddle h, position lo
+            const int g = b >> (Q - 1), r = b & ((1 << (Q - 1)) - 1), h = r >> pos, lo = r & ((1 << pos) - 1);
+            const cpx<T> w = twr[g * ((1 << Q) - 1) + (1 << t) - 1 + h];
+            const int c = (g << Q) | (h << (pos + 1)) | lo;
+            bfly(v[c], v[c | (1 << pos)], w);
+            if (KOFFT_SPLIT_FINE >= 2 && b == 3) cb(t);
+        }
+        cb(t);
+    }
+}
+
 template <typename T, int Q>
 __device__ __forceinline__ void split_compute(cpx<T> *v, const cpx<T> *twr)
 {
@@ -163,9 +206,13 @@ __device__ __forceinline__ void split_pin()  // keeps a chunk of memory instruct
 }
 
 // Phase A of transform xf (inputs in raw[]): stages 0 .. LA-1, results scattered to cells (K, j) of buffer BUF.
-template <typename T, int LA, int LB, int BUF, class IO, class LoadChunk>
+struct SplitNoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+template <typename T, int LA, int LB, int BUF, class IO, class LoadChunk, class BeforeLds = SplitNoHook, class AfterScatter = SplitNoHook>
 __device__ __forceinline__ void split_phase_a(const typename IO::Raw *raw, const SplitState<T, LA, LB, IO> &st, const IO &io,
-                                              const cpx<T> *__restrict__ tw, const size_t xf, const LoadChunk &load_chunk)
+                                              const cpx<T> *__restrict__ tw, const size_t xf, const LoadChunk &load_chunk,
+                                              const BeforeLds &before_lds = BeforeLds{}, const AfterScatter &after_scatter = AfterScatter{})
 {
     using Gm = SplitGeom<LA, LB>;
     using Lds = SplitLds<T, LA, LB, IO>;
@@ -186,11 +233,22 @@ __device__ __forceinline__ void split_phase_a(const typename IO::Raw *raw, const
         for (int u = 0; u < R; ++u) cur[u] = io.finish(xf, u * Gm::TPT + st.tauA, raw[u], st.inv[u]);
     }
     KOFFT_SPLIT_STAMP(1)
+#if KOFFT_SPLIT_FINE
+    // slots: after finish, after stages 0..3 of A0, after the gather, after stages 0..1 of A1 = 8 slots x 2 loads
+    int slot = 0;
+    constexpr int NSLOT = KOFFT_SPLIT_FINE >= 2 ? 16 : 8;  // load_chunk(100 + i): loads 2i, 2i+1; load_chunk(200 + i): load i
+    auto half_chunk = [&] { if (slot < NSLOT) { split_pin(); load_chunk((NSLOT == 16 ? 200 : 100) + slot); ++slot; split_pin(); } };
+    half_chunk();
+    split_pass0_cb<T, LA, 4>(cur, tw, TwSubFirst{LB}, [&](int) { half_chunk(); });
+    KOFFT_SPLIT_STAMP(2)
+#else
     split_pin(); load_chunk(0); split_pin();
     // stages 0 .. 3 (k = 0: table indices are compile-time constants -> scalar loads) ...
     reg_pass<T, LA, 0, 4, true>(cur, 0, tw, TwSubFirst{LB});
     KOFFT_SPLIT_STAMP(2)
     split_pin(); load_chunk(1); split_pin();
+#endif
+    before_lds();  // (counter mode: every wavefront has left the reads of the transform that used this buffer last)
     // ... wave-local exchange (this wavefront's columns only) ...
 #pragma unroll
     for (int u = 0; u < R; ++u) Lds::st(cA ^ (Gm::a0_out_reg(u) ^ BOFF), cur[u]);
@@ -198,20 +256,30 @@ __device__ __forceinline__ void split_phase_a(const typename IO::Raw *raw, const
 #pragma unroll
     for (int u = 0; u < R; ++u) cur[u] = Lds::ld(gA1 ^ (Gm::a1_in_reg(u) ^ BOFF));
     KOFFT_SPLIT_STAMP(3)
+#if KOFFT_SPLIT_FINE
+    half_chunk();
+    split_compute_cb<T, Gm::QA1>(cur, st.twA1, [&](int) { half_chunk(); });
+#pragma unroll
+    for (int i = 0; i < 16; ++i) half_chunk();  // whatever is left
+    KOFFT_SPLIT_STAMP(4)
+#else
     split_pin(); load_chunk(2); split_pin();
     // ... stages 4 .. LA-1
     split_compute<T, Gm::QA1>(cur, st.twA1);
     KOFFT_SPLIT_STAMP(4)
     split_pin(); load_chunk(3); split_pin();
+#endif
     exchange_sync<true>();  // the gathers above are done before the cells are overwritten (same wavefront: order only)
 #pragma unroll
     for (int u = 0; u < R; ++u) Lds::st(cA ^ (Gm::a1_out_reg(u) ^ BOFF), cur[u]);
+    after_scatter();
     KOFFT_SPLIT_STAMP(5)
 }
 
 // Phase B (after the block-wide barrier): stages LA .. L-1 of this thread's row K out of buffer BUF; results left in cur[].
-template <typename T, int LA, int LB, int BUF, class IO, class StoreChunk>
-__device__ __forceinline__ void split_phase_b(cpx<T> *cur, const SplitState<T, LA, LB, IO> &st, const size_t xf, const StoreChunk &store_chunk)
+template <typename T, int LA, int LB, int BUF, class IO, class StoreChunk, class AfterGathers = SplitNoHook>
+__device__ __forceinline__ void split_phase_b(cpx<T> *cur, const SplitState<T, LA, LB, IO> &st, const size_t xf, const StoreChunk &store_chunk,
+                                              const AfterGathers &after_gathers = AfterGathers{})
 {
     using Gm = SplitGeom<LA, LB>;
     using Lds = SplitLds<T, LA, LB, IO>;
@@ -224,23 +292,41 @@ __device__ __forceinline__ void split_phase_b(cpx<T> *cur, const SplitState<T, L
 #pragma unroll
     for (int u = 0; u < R; ++u) cur[u] = Lds::ld(cB ^ (Gm::b0_in_reg(u) ^ BOFF));
     KOFFT_SPLIT_STAMP(7)
+#if KOFFT_SPLIT_FINE
+    int slot = 0;
+    constexpr int NSLOT = KOFFT_SPLIT_FINE >= 2 ? 16 : 8;
+    auto half_chunk = [&] { if (slot < NSLOT) { split_pin(); store_chunk((NSLOT == 16 ? 200 : 100) + slot); ++slot; split_pin(); } };
+    half_chunk();
+    split_compute_cb<T, 4>(cur, st.twB0, [&](int) { half_chunk(); });
+    KOFFT_SPLIT_STAMP(8)
+#else
     split_pin(); store_chunk(0); split_pin();
     // stages LA .. LA+3 of row K ...
     reg_pass_r<T, 4>(cur, st.twB0);
     KOFFT_SPLIT_STAMP(8)
     split_pin(); store_chunk(1); split_pin();
+#endif
     exchange_sync<true>();
 #pragma unroll
     for (int u = 0; u < R; ++u) Lds::st(cB ^ (Gm::b0_out_reg(u) ^ BOFF), cur[u]);
     exchange_sync<true>();
 #pragma unroll
     for (int u = 0; u < R; ++u) cur[u] = Lds::ld(gB1 ^ (Gm::b1_in_reg(u) ^ BOFF));
+    after_gathers();
     KOFFT_SPLIT_STAMP(9)
+#if KOFFT_SPLIT_FINE
+    half_chunk();
+    split_compute_cb<T, Gm::QB1>(cur, st.twB1, [&](int) { half_chunk(); });
+#pragma unroll
+    for (int i = 0; i < 16; ++i) half_chunk();  // whatever is left
+    KOFFT_SPLIT_STAMP(10)
+#else
     split_pin(); store_chunk(2); split_pin();
     // ... and the rest
     split_compute<T, Gm::QB1>(cur, st.twB1);
     KOFFT_SPLIT_STAMP(10)
     split_pin(); store_chunk(3); split_pin();
+#endif
     KOFFT_SPLIT_STAMP(11)
 }
 
@@ -258,6 +344,30 @@ __device__ __forceinline__ void split_phase_b(cpx<T> *cur, const SplitState<T, L
 #ifndef KOFFT_SPLIT_ALTERNATE
 #define KOFFT_SPLIT_ALTERNATE 0
 #endif
+// KOFFT_SPLIT_COUNTERS: the s_barrier replaced by two LDS counters (a split barrier): `arrived` counts phase-A scatters,
+// `done` counts phase-B gathers.  Every wavefront runs A(t+1) BEFORE B(t), so between its own arrival for transform t and
+// its wait for everyone's there is a whole phase of work: a wavefront only ever stops when another one is more than a
+// phase behind, and the waves drift apart instead of hitting the LDS pipe and the memory queue together after every
+// barrier.  LDS operations of one wavefront execute in order, so the counter update is behind the accesses it publishes.
+#ifndef KOFFT_SPLIT_COUNTERS
+#define KOFFT_SPLIT_COUNTERS 0
+#endif
+typedef __attribute__((address_space(3))) unsigned split_lds_u32;
+__device__ __forceinline__ void split_signal(const int counter_bytes)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add((split_lds_u32 *)(size_t)(unsigned)counter_bytes, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void split_wait(const int counter_bytes, const unsigned target)
+{
+    for (;;) {
+        const unsigned v = __builtin_amdgcn_readfirstlane(
+            __hip_atomic_load((split_lds_u32 *)(size_t)(unsigned)counter_bytes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if ((int)(v - target) >= 0) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 template <typename T, int LA, int LB, class IO>
 __global__ __launch_bounds__((SplitGeom<LA, LB>::TPT), (SplitGeom<LA, LB>::TPT / 256)) void fft_split_persist_kernel(const IO io, const cpx<T> *__restrict__ tw,
                                                                                         const size_t batch)
@@ -268,6 +378,10 @@ __global__ __launch_bounds__((SplitGeom<LA, LB>::TPT), (SplitGeom<LA, LB>::TPT /
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     if ((unsigned)(size_t)(__attribute__((address_space(3))) char *)smem_raw != 0u) __builtin_trap();  // SplitLds's addressing
     const int tid = threadIdx.x;
+#if KOFFT_SPLIT_COUNTERS
+    if (tid < 2) *(split_lds_u32 *)(size_t)(unsigned)(2 * Gm::N * (int)sizeof(cpx<T>) + 4 * tid) = 0u;
+    __syncthreads();
+#endif
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int ja = lane / Gm::CA, x = lane % Gm::CA;  // phase A: thread ja of column x of this wavefront
@@ -326,14 +440,20 @@ __global__ __launch_bounds__((SplitGeom<LA, LB>::TPT), (SplitGeom<LA, LB>::TPT /
     typename persist_acc<IO>::type acc{};
     if constexpr (io_has_acc<IO>::value) acc = io.acc_init();
     // 4 loads of a transform, through a descriptor that is EMPTY when there is no such transform (fft_persist.hip.h)
-    auto loads = [&](const rsrc_t d, const int chunk) {
+    auto loads = [&](const rsrc_t d, const int chunk) {  // chunk < 4: loads 4c .. 4c+3; chunk = 100 + i: loads 2i, 2i+1
+        const int u0 = chunk >= 200 ? chunk - 200 : chunk >= 100 ? 2 * (chunk - 100) : 4 * chunk;
+        const int u1 = chunk >= 200 ? u0 + 1 : chunk >= 100 ? u0 + 2 : u0 + 4;
 #pragma unroll
-        for (int u = 4 * chunk; u < 4 * chunk + 4; ++u) raw[u] = io.fetch_d(d, in_lane_bytes, u * Gm::TPT, 0);
+        for (int u = 0; u < R; ++u)
+            if (u >= u0 && u < u1) raw[u] = io.fetch_d(d, in_lane_bytes, u * Gm::TPT, 0);
     };
     // 4 stores of a finished transform (an empty descriptor drops them: the first transform has no predecessor)
     auto stores = [&](const cpx<T> *src, const rsrc_t d, const int chunk) {
+        const int u0 = chunk >= 200 ? chunk - 200 : chunk >= 100 ? 2 * (chunk - 100) : 4 * chunk;
+        const int u1 = chunk >= 200 ? u0 + 1 : chunk >= 100 ? u0 + 2 : u0 + 4;
 #pragma unroll
-        for (int u = 4 * chunk; u < 4 * chunk + 4; ++u) {
+        for (int u = 0; u < R; ++u) {
+            if (u < u0 || u >= u1) continue;
             if constexpr (io_has_acc<IO>::value) io.store_d_acc(d, out_lane_bytes, Gm::out_reg(u), src[u], 0, acc);
             else io.store_d(d, out_lane_bytes, Gm::out_reg(u), src[u], 0);
         }
@@ -382,8 +502,47 @@ __global__ __launch_bounds__((SplitGeom<LA, LB>::TPT), (SplitGeom<LA, LB>::TPT /
         }
 #undef KOFFT_SPLIT_STEP
     };
+#if KOFFT_SPLIT_COUNTERS
+    (void)run;
+    {
+        constexpr int ARRIVED = 2 * Gm::N * (int)sizeof(cpx<T>), DONE = ARRIVED + 4;
+        constexpr unsigned W = Gm::W;
+        bool have_prev = false;
+        size_t prev = base;
+        unsigned t = 0;  // this workgroup's transform counter
+        split_signal(ARRIVED);  // the prologue's A(0)
+#define KOFFT_SPLIT_STEP(OPREV, ONEW, BUF, LEAVE)                                                                    \
+    {                                                                                                                \
+        const size_t nbase = base + step;                                                                            \
+        const bool more = nbase < batch; /* workgroup-uniform */                                                     \
+        const rsrc_t n2d = io.in_desc_n(nbase + step, nbase + step < batch ? 1 : 0);                                 \
+        const rsrc_t pod = io.out_desc_n(prev, have_prev ? 1 : 0);                                                   \
+        if (more)                                                                                                    \
+            split_phase_a<T, LA, LB, 1 - BUF>(raw, st, io, tw, nbase, [&](int c) { loads(n2d, c); },                 \
+                                              [&] { split_wait(DONE, W * t); }, [&] { split_signal(ARRIVED); });     \
+        split_wait(ARRIVED, W * (t + 1));                                                                            \
+        split_phase_b<T, LA, LB, BUF, IO>(ONEW, st, base, [&](int c) { stores(OPREV, pod, c); },                     \
+                                          [&] { split_signal(DONE); });                                              \
+        have_prev = true;                                                                                            \
+        prev = base;                                                                                                 \
+        ++t;                                                                                                         \
+        if (!more) {                                                                                                 \
+            const rsrc_t od = io.out_desc_n(base, 1);                                                                \
+            _Pragma("unroll") for (int c = 0; c < 4; ++c) stores(ONEW, od, c);                                       \
+            LEAVE;                                                                                                   \
+        }                                                                                                            \
+        base = nbase;                                                                                                \
+    }
+        for (;;) {
+            KOFFT_SPLIT_STEP(ob, oa, 0, break)
+            KOFFT_SPLIT_STEP(oa, ob, 1, break)
+        }
+#undef KOFFT_SPLIT_STEP
+    }
+#else
     if (KOFFT_SPLIT_ALTERNATE && st.young) run(std::true_type{});
     else run(std::false_type{});
+#endif
     if constexpr (io_has_acc<IO>::value) io.acc_finish(acc);
 }
 

@@ -374,7 +374,7 @@ template <typename T, int LA, int LB, class IO>
 int launch_split(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t batch)
 {
     using Gm = SplitGeom<LA, LB>;
-    constexpr size_t lds = 2 * (size_t)Gm::N * sizeof(cpx<T>);
+    constexpr size_t lds = 2 * (size_t)Gm::N * sizeof(cpx<T>) + 16;  // (+ the two counters of KOFFT_SPLIT_COUNTERS)
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = fft_split_persist_kernel<T, LA, LB, IO>;
     {

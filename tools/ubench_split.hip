@@ -58,7 +58,7 @@ int main(int argc, char **argv)
     IO io{{}, src, out, N, 1.0f / N};
 #ifndef SPLIT1
     auto k = fft_split_persist_kernel<float, LA, LB, IO>;
-    const size_t lds = 2 * (size_t)N * 8;
+    const size_t lds = 2 * (size_t)N * 8 + 16;
     const int threads = 512;
 #else
     auto k = fft_split1_persist_kernel<float, LA, LB, IO>;
