@@ -98,3 +98,48 @@ def test_two_element_grain_formula_conflicts_with_16_units():
     _, out = geometry(L, RL, 0)
     lanes = range(64)
     assert extra_cycles([old(out(t // xpb, 0), t % xpb) for t in lanes], 16, 32) == 4  # one extra cycle in each of the 4 groups
+
+
+# ---- the wave-split kernels (fft_split.hip.h, round 3): decomposition and XOR swizzle, restated in tools/split_model.py ---------
+def _split_swizzles():
+    """SplitSwizzle<LA, LB>::F as the header has them."""
+    import re
+    from pathlib import Path
+
+    text = (Path(__file__).resolve().parent.parent / "kofft_amd" / "csrc" / "fft_split.hip.h").read_text()
+    out = {}
+    for la, lb, cols in re.findall(r"SplitSwizzle<(\d+), (\d+)> \{ static constexpr int F\[\d+\] = \{([^}]*)\}", text):
+        out[(int(la), int(lb))] = [int(v) for v in cols.split(",")]
+    return out
+
+
+@pytest.mark.parametrize("la,lb", [(7, 6), (7, 7)])
+def test_wave_split_decomposition_and_swizzle(la, lb):
+    """The kernels' thread / register index maps computed on the CPU reproduce numpy's FFT, every stage uses exactly the
+    reference's table entries T[k * n2] (fft.rs:839), the cell function is a bijection, XOR-linear (so that an address is
+    base(thread) ^ const(register)), and none of the six LDS access shapes conflicts under the per-instruction banking."""
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tools"))
+    import split_model as sm
+
+    assert sm.run(la, lb) < 1e-12  # also asserts the per-stage table index sets
+    F = _split_swizzles()[(la, lb)]
+    g = sm.Geom(la, lb)
+    assert len(F) == la and all(0 <= f < (1 << lb) for f in F)
+    assert sm.conflicts(g, F) == 0
+
+    def cell(K, j):
+        return (K << lb) | (j ^ sm.apply_f(F, K))
+
+    cells = {cell(K, j) for K in range(1 << la) for j in range(1 << lb)}
+    assert len(cells) == g.N and max(cells) == g.N - 1
+    import random
+
+    rnd = random.Random(5)
+    for _ in range(2000):  # XOR-linearity on disjoint bit fields: what "base ^ constant" relies on
+        k1, j1 = rnd.randrange(1 << la), rnd.randrange(1 << lb)
+        mk, mj = rnd.randrange(1 << la), rnd.randrange(1 << lb)
+        ka, kb, ja, jb = k1 & mk, k1 & ~mk, j1 & mj, j1 & ~mj
+        assert cell(k1, j1) == cell(ka, ja) ^ cell(kb, jb)
