@@ -165,3 +165,37 @@ def test_cfg5_1024x2p20_c64(oracle):
         assert err < 1e-9, err
     del x, y
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("n,batch", [(8192, 8192 + 7), (16384, 4096 + 3)])
+def test_wave_split_kernels_at_sweep_size(dev_fft, oracle, n, batch):
+    """The sizes tools/sweep.py times the wave-split kernels at (512 MiB per launch, 32 / 16 transforms per workgroup, a ragged
+    tail): EVERY transform against the oracle bit for bit (the oracle does 67 M points in well under a second), forward in
+    place on the device, then the inverse, plus an STFT whose frames overlap fourfold at the same window length."""
+    fft, stream = dev_fft
+    with torch.cuda.stream(stream):
+        g = torch.Generator(device="cuda")
+        g.manual_seed(4321 + n)
+        x = torch.empty((batch, n, 2), dtype=torch.float32, device="cuda").uniform_(-1, 1, generator=g)
+        xh = x.cpu().numpy().view(np.complex64).reshape(batch, n)
+        y = x.clone()
+        fft.fft_dev(y.data_ptr(), n, batch, False)
+        stream.synchronize()
+        want = oracle.fft(xh)
+        assert bits_equal(y.cpu().numpy().view(np.complex64).reshape(batch, n), want)
+        fft.fft_dev(y.data_ptr(), n, batch, True)
+        stream.synchronize()
+        assert bits_equal(y.cpu().numpy().view(np.complex64).reshape(batch, n), oracle.ifft(want))
+        del x, y
+        hop = n // 4
+        frames = 5000 if n == 8192 else 2500
+        sig = torch.empty(hop * frames + 33, dtype=torch.float32, device="cuda").uniform_(-1, 1, generator=g)
+        import kofft_amd
+
+        win = torch.from_numpy(kofft_amd.hann(n)).cuda()
+        nframes = -(-sig.numel() // hop)
+        out = torch.empty((nframes, n, 2), dtype=torch.float32, device="cuda")
+        fft.stft_dev(sig.data_ptr(), sig.numel(), win.data_ptr(), n, hop, out.data_ptr(), 0, nframes)
+        stream.synchronize()
+        ws = oracle.stft(sig.cpu().numpy(), win.cpu().numpy(), hop, nframes)
+        assert bits_equal(out.cpu().numpy().view(np.complex64).reshape(nframes, n), ws)
