@@ -41,6 +41,7 @@ template <int LA, int LB> struct SplitSwizzle;
 // columns of F (bit i of K -> XOR mask on j), tools/split_model.py: residual conflict cycles 0 for every shape
 template <> struct SplitSwizzle<6, 6> { static constexpr int F[6] = {3, 9, 24, 30, 1, 4}; };
 template <> struct SplitSwizzle<7, 6> { static constexpr int F[7] = {8, 10, 30, 17, 27, 6, 24}; };
+template <> struct SplitSwizzle<6, 7> { static constexpr int F[6] = {15, 4, 18, 30, 1, 4}; };
 template <> struct SplitSwizzle<7, 7> { static constexpr int F[7] = {15, 4, 18, 30, 8, 4, 26}; };
 template <> struct SplitSwizzle<8, 6> { static constexpr int F[8] = {5, 9, 24, 30, 8, 4, 26, 30}; };
 
@@ -265,7 +266,9 @@ __device__ __forceinline__ void split_phase_a(const typename IO::Raw *raw, const
 #else
     split_pin(); load_chunk(2); split_pin();
     // ... stages 4 .. LA-1
+#ifndef KOFFT_SPLIT_COPY_ONLY
     split_compute<T, Gm::QA1>(cur, st.twA1);
+#endif
     KOFFT_SPLIT_STAMP(4)
     split_pin(); load_chunk(3); split_pin();
 #endif
@@ -302,16 +305,20 @@ __device__ __forceinline__ void split_phase_b(cpx<T> *cur, const SplitState<T, L
 #else
     split_pin(); store_chunk(0); split_pin();
     // stages LA .. LA+3 of row K ...
+#ifndef KOFFT_SPLIT_COPY_ONLY
     reg_pass_r<T, 4>(cur, st.twB0);
+#endif
     KOFFT_SPLIT_STAMP(8)
     split_pin(); store_chunk(1); split_pin();
 #endif
+#ifndef KOFFT_SPLIT_COPY_ONLY
     exchange_sync<true>();
 #pragma unroll
     for (int u = 0; u < R; ++u) Lds::st(cB ^ (Gm::b0_out_reg(u) ^ BOFF), cur[u]);
     exchange_sync<true>();
 #pragma unroll
     for (int u = 0; u < R; ++u) cur[u] = Lds::ld(gB1 ^ (Gm::b1_in_reg(u) ^ BOFF));
+#endif
     after_gathers();
     KOFFT_SPLIT_STAMP(9)
 #if KOFFT_SPLIT_FINE
@@ -323,7 +330,9 @@ __device__ __forceinline__ void split_phase_b(cpx<T> *cur, const SplitState<T, L
 #else
     split_pin(); store_chunk(2); split_pin();
     // ... and the rest
+#ifndef KOFFT_SPLIT_COPY_ONLY
     split_compute<T, Gm::QB1>(cur, st.twB1);
+#endif
     KOFFT_SPLIT_STAMP(10)
     split_pin(); store_chunk(3); split_pin();
 #endif

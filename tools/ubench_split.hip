@@ -36,7 +36,11 @@ using IO = ComplexIO<float, false>;
 int main(int argc, char **argv)
 {
 #ifndef SPLIT1
-    constexpr int LA = 7, LB = 6, N = 1 << (LA + LB);
+#ifndef SPLIT_LA
+#define SPLIT_LA 7
+#define SPLIT_LB 6
+#endif
+    constexpr int LA = SPLIT_LA, LB = SPLIT_LB, N = 1 << (LA + LB);
 #else
     constexpr int LA = 7, LB = 7, N = 1 << (LA + LB);
 #endif
