@@ -251,7 +251,13 @@ template <class IO> struct PersistCfgBase {
     static constexpr bool kInvInLds = IO::kInvInLds, kTwLastInLds = false;
 };
 template <class IO> struct PersistCfg<13, IO> : PersistCfgBase<IO> { static constexpr int BLOCK = 512, MINW = 2, WG_PER_CU = 1; };
-template <class IO> struct PersistCfg<12, IO> : PersistCfgBase<IO> { static constexpr int BLOCK = 256, MINW = 2, WG_PER_CU = 2; };
+#ifndef KOFFT_PERSIST12_SPREAD
+#define KOFFT_PERSIST12_SPREAD false
+#endif
+template <class IO> struct PersistCfg<12, IO> : PersistCfgBase<IO> {
+    static constexpr int BLOCK = 256, MINW = 2, WG_PER_CU = 2;
+    static constexpr bool kSpread = KOFFT_PERSIST12_SPREAD;  // next transform's loads between the passes instead of one burst (A/B)
+};
 template <class IO> struct PersistCfg<11, IO> : PersistCfgBase<IO> { static constexpr int BLOCK = 256, MINW = 2, WG_PER_CU = 2; };
 template <class IO> struct PersistCfg<10, IO> : PersistCfgBase<IO> {
     static constexpr int BLOCK = 256, MINW = IO::kLeanRegisters ? 3 : 2, WG_PER_CU = MINW;

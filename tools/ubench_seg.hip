@@ -103,6 +103,9 @@ int main()
         run<64, 64, true, 4096, 1>(src, dst, bytes);
         run<8, 16, true, 8192, 4>(src, dst, bytes);
         run<8, 16, true, 8192, 16>(src, dst, bytes);
+        run<4, 16, true, 8192, 4>(src, dst, bytes);
+        run<8, 8, true, 8192, 4>(src, dst, bytes);
+        run<4, 64, true, 8192, 4>(src, dst, bytes);
     }
     return 0;
 }
