@@ -81,3 +81,60 @@ def test_fuzz_stft(fft32, oracle, seed):
         got = fft32.stft_into(signal, window, hop, frames, check_frames=False)
         want = oracle.stft_range(signal, window, hop, 0, frames)
         assert same(got, want), (win_len, hop, length, frames)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_fuzz_multi_gpu_forms_on_one_card(oracle, seed):
+    """kofft_hip_multi_* with G logical devices on card 0 (worker threads, shards, halos, empty tail shards), host and device
+    forms, at random sizes: the union of the shards is the single-device result, bit for bit.  (The RCCL exchange needs
+    distinct devices: tests/test_gpu_multi.py::test_multi_all_cards_of_the_box_with_rccl.)"""
+    import torch
+
+    import kofft_amd
+
+    rng = seeded(9300 + seed)
+    dev = torch.device("cuda", 0)
+    for _ in range(5):
+        g = int(rng.integers(1, 7))
+        m = kofft_amd.HipMulti(g, devices=[0] * g)
+        # STFT, host form: frames may be fewer than devices, frames past the end, any hop
+        win_len = 1 << int(rng.integers(2, 12))
+        hop = int(rng.integers(1, 2 * win_len))
+        length = int(rng.integers(1, 60_000))
+        frames = -(-length // hop) + int(rng.integers(0, 3))
+        if frames * win_len > (1 << 22):
+            hop = max(hop, length * win_len // (1 << 22) + 1)
+            frames = -(-length // hop)
+        sig = rng.uniform(-1, 1, length).astype(np.float32)
+        win = rng.uniform(0, 1, win_len).astype(np.float32)
+        want = oracle.stft(sig, win, hop, frames)
+        assert same(m.stft(sig, win, hop, frames), want), ("stft host", g, win_len, hop, length, frames)
+        # STFT, device form from per-device slices, outputs in the handle's buffers
+        dw = torch.from_numpy(win).to(dev)
+        slices = []
+        for r in range(g):
+            first, count = m.stft_slice(length, win_len, hop, frames, r)
+            slices.append(torch.from_numpy(sig[first:first + count].copy()).to(dev))
+        torch.cuda.synchronize(dev)
+        outs = [torch.zeros((max(m.shard(frames, r)[1], 1), win_len, 2), dtype=torch.float32, device=dev) for r in range(g)]
+        torch.cuda.synchronize(dev)
+        m.stft_dev([t.data_ptr() for t in slices], length, [dw.data_ptr()] * g, win_len, hop, frames, d_out=[t.data_ptr() for t in outs])
+        m.synchronize()
+        for r in range(g):
+            first, count = m.shard(frames, r)
+            if count:
+                got = outs[r].cpu().numpy().view(np.complex64).reshape(-1, win_len)[:count]
+                assert same(got, want[first:first + count]), ("stft dev", g, r)
+        # batched complex and real rows, host forms
+        n = 1 << int(rng.integers(1, 13))
+        batch = int(rng.integers(1, 40))
+        double = rng.random() < 0.4
+        x = rand_c(rng, (batch, n), np.complex128 if double else np.complex64)
+        y = x.copy()
+        inverse = bool(rng.random() < 0.5)
+        m.fft_batch(y, inverse=inverse)
+        assert same(y, oracle.ifft(x) if inverse else oracle.fft(x)), ("fft", g, n, batch, double, inverse)
+        rows = rng.uniform(-1, 1, (batch, 2 * n)).astype(np.float32)
+        w2 = rng.uniform(0, 1, 2 * n).astype(np.float32) if rng.random() < 0.5 else None
+        assert same(m.rfft_batch(rows, w2), oracle.rfft(rows, w2)), ("rfft", g, n, batch)
+        m.close()
