@@ -63,7 +63,7 @@ int main(int argc, char **argv)
 #ifndef SPLIT1
     auto k = fft_split_persist_kernel<float, LA, LB, IO>;
     const size_t lds = 2 * (size_t)N * 8 + 16;
-    const int threads = 512;
+    const int threads = N / 16;
 #else
     auto k = fft_split1_persist_kernel<float, LA, LB, IO>;
     const size_t lds = ((size_t)N + 16 * 7 + 128 * 15) * 8;
@@ -73,16 +73,16 @@ int main(int argc, char **argv)
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(k, dim3(256), dim3(threads), lds, 0, io, dtw, batch);
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(k, dim3(256 * (N <= 4096 ? 2 : 1)), dim3(threads), lds, 0, io, dtw, batch);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(k, dim3(256), dim3(threads), lds, 0, io, dtw, batch);
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(k, dim3(256 * (N <= 4096 ? 2 : 1)), dim3(threads), lds, 0, io, dtw, batch);
     CK(hipEventRecord(e1));
     CK(hipDeviceSynchronize());
     float ms;
     CK(hipEventElapsedTime(&ms, e0, e1));
     ms /= 20;
-    printf("n=%d batch=%zu: %.4f ms per launch, %.1f GB/s, frac %.3f, %.2f us per transform per CU\n", N, batch, ms, 2.0 * bytes / ms / 1e6,
+    printf("n=%d (2^%d x 2^%d) batch=%zu: %.4f ms per launch, %.1f GB/s, frac %.3f, %.2f us per transform per CU\n", N, LA, LB, batch, ms, 2.0 * bytes / ms / 1e6,
            2.0 * bytes / ms / 1e6 / 8000.0, ms * 1e3 / ((double)batch / 256));
 #ifdef STAMPS
     std::vector<unsigned long long> st(8 * NWAVE * MAXT * NSTAMP);
