@@ -62,6 +62,28 @@ __device__ __forceinline__ void reg_pass_r(cpx<T> *v, const cpx<T> *twr)
 template <int L, int RL, int P>
 using PassGeom = WgGeom<L, RL, P>;
 
+// Cells between the exchange buffers of consecutive transforms.  Where one wavefront carries four transforms (n = 64, 128) a
+// ds_read_b64's 32-lane group spans TWO of them: with the buffers 16 cells (mod 32) apart the second transform's 16 cells --
+// a run in natural order (the rfft epilogue, irfft's staged row), or the first one's pattern shifted -- fall on the banks the
+// first leaves free (KOFFT_PERSIST_SLOT16; simulated tests/test_lds_layout.py-style: n = 128 63 -> 16 conflict cycles per transform).
+#ifndef KOFFT_PERSIST_SLOT16
+#define KOFFT_PERSIST_SLOT16 1
+#endif
+__host__ __device__ constexpr int persist_slot_elems(int L)
+{
+    int e = lds_elems(1 << L);
+    if (KOFFT_PERSIST_SLOT16 && L <= 7)
+        while ((e & 31) != 16) ++e;
+    return e;
+}
+
+// The rfft epilogue of a wavefront that carries several transforms stores the group's output as ONE stream (see persist_transform).
+// Measured on one box, rfft32, fraction of the roofline: n = 256 0.63 -> 0.69, n = 512 unchanged; n = 128 0.62 -> 0.60 at
+// two workgroups per CU but 0.66 at three (PersistGrid<6>), where the row-by-row form drops to 0.61.
+#ifndef KOFFT_PERSIST_RFFT_GROUP_MIN_L
+#define KOFFT_PERSIST_RFFT_GROUP_MIN_L 6
+#endif
+
 template <typename T, int L, int RL, int P>
 __device__ __forceinline__ void persist_load_tw(cpx<T> *twr, const int tau, const cpx<T> *__restrict__ tw)
 {
@@ -281,7 +303,35 @@ __device__ __forceinline__ void persist_transform(const typename persist_raw<IO,
             for (int u = 0; u < R; ++u) p[LastG::out_index(0, u)] = cur[u];
         }
         exchange_sync<WAVE>();
-        if (active) {
+        if constexpr (GRP > 1 && L >= KOFFT_PERSIST_RFFT_GROUP_MIN_L) {
+            // A wavefront holds GRP transforms whose output rows are adjacent in memory: GRP * (N + 1) values back to back.
+            // The stores walk that STREAM, not the rows: lane l of store s handles stream element e = 64 s + l - a, where
+            // a is the stream's offset into its 128-byte line, so every store instruction covers four whole lines and a row
+            // boundary falls INSIDE an instruction.  Row by row (below), every row's first and last line is written as two
+            // partial lines by two different instructions.
+            constexpr int LINE = 128 / (int)sizeof(cpx<T>);
+            constexpr int ROW = N + 1;
+            constexpr int SLOT = persist_slot_elems(L);
+            constexpr int S = (GRP * ROW + LINE - 1 + 63) / 64;
+            const int a = io.row_misalign(xf0) & (LINE - 1);  // wave-uniform
+            const rsrc_t od = io.out_desc_back_n(xf0, cnt, LINE);
+            const cpx<T> *gy = ybuf - sub * SLOT;  // the group's first slot
+            const int total = cnt * ROW;
+            const int e0 = sub * TPT + tau - a;
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const int e = e0 + s * 64;
+                if (e >= 0 && e < total) {
+                    const int r = e / ROW, k = e - r * ROW;
+                    const cpx<T> *y = gy + r * SLOT;
+                    const int kc = k < N ? k : N - 1;  // k == N: the table and Y[k] reads are clamped, their values unused
+                    const cpx<T> yk = y[kc], ymk = y[N - k];  // k == 0 reads cell N: inside the slot, value unused
+                    const cpx<T> p = io.post_w(st.rt_lds[kc], yk, ymk);
+                    const cpx<T> x = k == 0 ? mk<T>(yk.re + yk.im, T(0)) : (k == N ? mk<T>(ymk.re - ymk.im, T(0)) : p);
+                    io.store_d(od, (e + LINE) * (int)sizeof(cpx<T>), 0, x, 0);
+                }
+            }
+        } else if (active) {
             // Output rows are (N+1) complex values back to back, so a row starts `a` elements past a 128-byte line.
             // Lane tau of store g handles k = g*TPT + tau - a: every store instruction then covers whole lines (the
             // row-contiguous form touches 5 lines per 512-byte store, 2 of them partially; measured +8 % on config 3),
@@ -357,8 +407,8 @@ __global__ __launch_bounds__(CFG::BLOCK, CFG::MINW) void fft_persist_kernel(cons
     const int sub = (G == 1) ? 0 : (tid & 63) / TPT;
     const int wslot = (G == 1) ? __builtin_amdgcn_readfirstlane(tid / TPT) : __builtin_amdgcn_readfirstlane(tid >> 6) * G;
     const int slot = wslot + sub;
-    cpx<T> *buf0 = reinterpret_cast<cpx<T> *>(smem_raw) + (size_t)slot * NBUF * lds_elems(N);
-    cpx<T> *buf1 = (NBUF == 2) ? buf0 + lds_elems(N) : buf0;
+    cpx<T> *buf0 = reinterpret_cast<cpx<T> *>(smem_raw) + (size_t)slot * NBUF * persist_slot_elems(L);
+    cpx<T> *buf1 = (NBUF == 2) ? buf0 + persist_slot_elems(L) : buf0;
 
     // ---- per-thread invariants, fetched once
     PersistState<T, L, RL, EPI, IO, CFG> st;
@@ -368,7 +418,7 @@ __global__ __launch_bounds__(CFG::BLOCK, CFG::MINW) void fft_persist_kernel(cons
     if constexpr (St::TW3_REG) persist_load_tw<T, L, RL, 3>(st.tw3, tau, tw);
     {
         // transform-independent operands: registers, or (kInvInLds / rfft table) one LDS copy per workgroup
-        char *extra = smem_raw + (size_t)XPB * NBUF * lds_elems(N) * sizeof(cpx<T>);
+        char *extra = smem_raw + (size_t)XPB * NBUF * persist_slot_elems(L) * sizeof(cpx<T>);
         typename IO::Inv *inv_lds = reinterpret_cast<typename IO::Inv *>(extra);
         extra += CFG::kInvInLds ? N * sizeof(typename IO::Inv) : 0;
         cpx<T> *rt_lds = reinterpret_cast<cpx<T> *>(extra);

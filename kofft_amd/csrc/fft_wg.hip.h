@@ -931,7 +931,10 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const cpx<float> *__rest
 // different cache lines per instruction.  The workgroup therefore moves its 256 transforms through LDS: global
 // reads and writes run over the workgroup's elements in memory order (fully coalesced), and each thread picks its
 // row out of LDS (row stride n+1 cells: odd, so the 64 lanes hit distinct banks).
-constexpr int kSmallBlock = 256;
+#ifndef KOFFT_SMALL_BLOCK
+#define KOFFT_SMALL_BLOCK 256
+#endif
+constexpr int kSmallBlock = KOFFT_SMALL_BLOCK;
 template <typename T, int N>
 constexpr size_t small_lds_bytes() { return N == 1 ? 0 : (size_t)kSmallBlock * (N + 1) * sizeof(cpx<T>); }
 

@@ -340,7 +340,10 @@ template <class IO> struct PersistCfg<9, IO> {
 template <int L, class IO> struct PersistGrid {
     static int wg_per_cu(int base, size_t) { return base; }
 };
-template <> struct PersistGrid<6, RfftIO<float>> { static int wg_per_cu(int base, size_t) { return base / 2; } };
+#ifndef KOFFT_RFFT6_WG
+#define KOFFT_RFFT6_WG 3  // with the group-wide stores of round 3 (fft_persist.hip.h) three workgroups beat two by 6 %
+#endif
+template <> struct PersistGrid<6, RfftIO<float>> { static int wg_per_cu(int, size_t) { return KOFFT_RFFT6_WG; } };
 template <> struct PersistGrid<7, RfftIO<float>> { static int wg_per_cu(int base, size_t) { return base / 2; } };
 template <> struct PersistGrid<8, RfftIO<float>> { static int wg_per_cu(int base, size_t) { return base / 2; } };
 template <> struct PersistGrid<9, RfftIO<float>> { static int wg_per_cu(int base, size_t) { return base / 2; } };
@@ -354,7 +357,7 @@ int launch_persist(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t ba
     using Cfg = PersistCfg<L, IO>;
     constexpr int RL = Cfg::RL;
     constexpr int XPB = Cfg::BLOCK / ((1 << L) >> RL);
-    constexpr size_t lds = (size_t)XPB * Cfg::NBUF * lds_elems(1 << L) * sizeof(cpx<T>) +
+    constexpr size_t lds = (size_t)XPB * Cfg::NBUF * persist_slot_elems(L) * sizeof(cpx<T>) +
                            (Cfg::kInvInLds ? (size_t)(1 << L) * sizeof(typename IO::Inv) : 0) +
                            (EPI == EPI_RFFT ? (size_t)(1 << L) * sizeof(cpx<T>) : 0) +
                            (Cfg::kTwLastInLds ? (size_t)(1 << L) / 2 * sizeof(cpx<T>) : 0);
