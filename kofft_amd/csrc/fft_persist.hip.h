@@ -162,6 +162,12 @@ template <class CFG, class = void>
 struct persist_spread { static constexpr bool value = false; };
 template <class CFG>
 struct persist_spread<CFG, decltype((void)CFG::kSpread)> { static constexpr bool value = CFG::kSpread; };
+// CFG::kTwGlobal (f64, n = 8192): no pass keeps its table entries in registers (15 x 4 VGPRs per pass) or in LDS (the exchange
+// buffer fills it): every pass after the first reads them from the table in global memory, as fft_wg_kernel does (L2 hits).
+template <class CFG, class = void>
+struct persist_tw_global { static constexpr bool value = false; };
+template <class CFG>
+struct persist_tw_global<CFG, decltype((void)CFG::kTwGlobal)> { static constexpr bool value = CFG::kTwGlobal; };
 struct PersistNoMid {
     __device__ __forceinline__ void operator()(int) const {}
 };
@@ -175,9 +181,11 @@ template <typename T, int L, int RL, int EPI, class IO, class CFG>
 struct PersistState {
     static constexpr int R = 1 << RL;
     static constexpr int NP = (L + RL - 1) / RL;
-    static constexpr bool TW2_REG = NP >= 3 && !(CFG::kTwLastInLds && NP == 3);
-    static constexpr bool TW3_REG = NP >= 4 && !CFG::kTwLastInLds;
-    cpx<T> tw1[(NP == 2 && CFG::kTwLastInLds) ? 1 : R - 1], tw2[TW2_REG ? R - 1 : 1], tw3[TW3_REG ? R - 1 : 1];
+    static constexpr bool TWG = persist_tw_global<CFG>::value;
+    static constexpr bool TW1_REG = !TWG && !(NP == 2 && CFG::kTwLastInLds);
+    static constexpr bool TW2_REG = !TWG && NP >= 3 && !(CFG::kTwLastInLds && NP == 3);
+    static constexpr bool TW3_REG = !TWG && NP >= 4 && !CFG::kTwLastInLds;
+    cpx<T> tw1[TW1_REG ? R - 1 : 1], tw2[TW2_REG ? R - 1 : 1], tw3[TW3_REG ? R - 1 : 1];
     typename IO::Inv inv[CFG::kInvInLds ? 1 : R];  // window samples etc. (registers unless staged in LDS)
     const typename IO::Inv *inv_lds;               // [N], natural order (kInvInLds)
     const cpx<T> *tw_lds;                          // the whole table T_N, N/2 entries (kTwLastInLds)
@@ -266,7 +274,13 @@ __device__ __forceinline__ void persist_transform(const typename persist_raw<IO,
     persist_lds_scatter<T, L, RL, 0>(cur, buf0, st.sc);
     exchange_sync<WAVE>();
     persist_lds_gather<T, L, RL, 1>(cur, buf0, st.g1);
-    if constexpr (NP == 2 && CFG::kTwLastInLds) wg_compute<T, L, RL, 1>(cur, io, st.tw_lds, xf, tau);
+    using St = PersistState<T, L, RL, EPI, IO, CFG>;
+    // (kTwGlobal: the table addresses depend on tau only -- hoisted out of the transform loop they are 3 x 15 64-bit pointers
+    // held in registers, 168 VGPRs spilled; an opaque copy of tau per transform keeps them a few VALU operations per pass)
+    int tau_tw = tau;
+    if constexpr (St::TWG) asm volatile("" : "+v"(tau_tw));
+    if constexpr (St::TWG) wg_compute<T, L, RL, 1>(cur, io, tw, xf, tau_tw);
+    else if constexpr (NP == 2 && CFG::kTwLastInLds) wg_compute<T, L, RL, 1>(cur, io, st.tw_lds, xf, tau);
     else persist_compute<T, L, RL, 1>(cur, st.tw1);
     mid(2);
     if constexpr (NP >= 3) {
@@ -274,7 +288,8 @@ __device__ __forceinline__ void persist_transform(const typename persist_raw<IO,
         persist_lds_scatter<T, L, RL, 1>(cur, buf1, st.sc);
         exchange_sync<WAVE>();
         persist_lds_gather<T, L, RL, 2>(cur, buf1, st.g2);
-        if constexpr (NP == 3 && CFG::kTwLastInLds) wg_compute<T, L, RL, 2>(cur, io, st.tw_lds, xf, tau);
+        if constexpr (St::TWG) wg_compute<T, L, RL, 2>(cur, io, tw, xf, tau_tw);
+        else if constexpr (NP == 3 && CFG::kTwLastInLds) wg_compute<T, L, RL, 2>(cur, io, st.tw_lds, xf, tau);
         else persist_compute<T, L, RL, 2>(cur, st.tw2);
     }
     mid(3);
@@ -283,7 +298,8 @@ __device__ __forceinline__ void persist_transform(const typename persist_raw<IO,
         persist_lds_scatter<T, L, RL, 2>(cur, buf0, st.sc);
         exchange_sync<WAVE>();
         persist_lds_gather<T, L, RL, 3>(cur, buf0, st.g3);
-        if constexpr (CFG::kTwLastInLds) wg_compute<T, L, RL, 3>(cur, io, st.tw_lds, xf, tau);
+        if constexpr (St::TWG) wg_compute<T, L, RL, 3>(cur, io, tw, xf, tau_tw);
+        else if constexpr (CFG::kTwLastInLds) wg_compute<T, L, RL, 3>(cur, io, st.tw_lds, xf, tau);
         else persist_compute<T, L, RL, 3>(cur, st.tw3);
     }
 
@@ -413,7 +429,7 @@ __global__ __launch_bounds__(CFG::BLOCK, CFG::MINW) void fft_persist_kernel(cons
     // ---- per-thread invariants, fetched once
     PersistState<T, L, RL, EPI, IO, CFG> st;
     using St = PersistState<T, L, RL, EPI, IO, CFG>;
-    if constexpr (!(NP == 2 && CFG::kTwLastInLds)) persist_load_tw<T, L, RL, 1>(st.tw1, tau, tw);
+    if constexpr (St::TW1_REG) persist_load_tw<T, L, RL, 1>(st.tw1, tau, tw);
     if constexpr (St::TW2_REG) persist_load_tw<T, L, RL, 2>(st.tw2, tau, tw);
     if constexpr (St::TW3_REG) persist_load_tw<T, L, RL, 3>(st.tw3, tau, tw);
     {

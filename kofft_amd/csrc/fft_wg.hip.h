@@ -931,17 +931,26 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const cpx<float> *__rest
 // different cache lines per instruction.  The workgroup therefore moves its 256 transforms through LDS: global
 // reads and writes run over the workgroup's elements in memory order (fully coalesced), and each thread picks its
 // row out of LDS (row stride n+1 cells: odd, so the 64 lanes hit distinct banks).
+// n = 32: workgroups of 128 -- four 33 KiB workgroups per CU interleave their load / transform / store phases better than two
+// of 66 KiB (c32 n = 32: 0.60 .. 0.71 -> 0.74 .. 0.75 of the roofline on one box; rfft n = 64 and STFT n = 32 do not care).
+// Tried and dropped in round 3, same box: PERSISTENT workgroups with the next block's loads prefetched into registers
+// (c32 0.69, rfft n = 64 0.60 -> 0.54, STFT n = 32 0.63 -> 0.53: 246 VGPRs, and the phases of two wavefronts per SIMD still do not
+// overlap); the 8-threads-per-transform persistent kernel (bit-equal, 0.42: its loads are 64-byte runs).
 #ifndef KOFFT_SMALL_BLOCK
 #define KOFFT_SMALL_BLOCK 256
 #endif
-constexpr int kSmallBlock = KOFFT_SMALL_BLOCK;
+#ifndef KOFFT_SMALL_BLOCK32
+#define KOFFT_SMALL_BLOCK32 128
+#endif
+template <int N>
+constexpr int small_block_threads() { return N == 32 ? KOFFT_SMALL_BLOCK32 : KOFFT_SMALL_BLOCK; }
 template <typename T, int N>
-constexpr size_t small_lds_bytes() { return N == 1 ? 0 : (size_t)kSmallBlock * (N + 1) * sizeof(cpx<T>); }
+constexpr size_t small_lds_bytes() { return N == 1 ? 0 : (size_t)small_block_threads<N>() * (N + 1) * sizeof(cpx<T>); }
 
 template <typename T, int N, int EPI, class IO>
-__global__ __launch_bounds__(kSmallBlock) void fft_small_kernel(const IO io, const cpx<T> *__restrict__ tw, const size_t batch)
+__global__ __launch_bounds__(small_block_threads<N>()) void fft_small_kernel(const IO io, const cpx<T> *__restrict__ tw, const size_t batch)
 {
-    constexpr int B = kSmallBlock;
+    constexpr int B = small_block_threads<N>();
     constexpr int S = N + 1;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     cpx<T> *buf = reinterpret_cast<cpx<T> *>(smem_raw);

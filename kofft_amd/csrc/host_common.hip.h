@@ -56,6 +56,7 @@ struct kofft_hip_ctx {
     bool zero_copy = true;     // KOFFT_HIP_ZERO_COPY=0: small host calls through staged copies like large ones
     bool host_pipeline = true; // KOFFT_HIP_HOST_PIPELINE=0: host-pointer batches in one upload / kernel / download
     int host_chunks = 0;       // KOFFT_HIP_HOST_CHUNKS: pieces of a pipelined host batch (default 8)
+    bool persist64 = true;     // KOFFT_HIP_PERSIST64=0: c64 n = 8192 on the generic kernel (A/B measurements)
     bool persist_small = true; // KOFFT_HIP_PERSIST_SMALL=0: n = 128, 256 on the generic kernels (A/B measurements)
     int split13 = 1;           // KOFFT_HIP_SPLIT13=2: n = 8192 as TWO independent single-buffer workgroups per CU (fft_split1) instead of one
                                // double-buffered one (measured, same box: c32 0.52-0.53 against 0.61-0.63, STFT 0.41 against 0.43)
@@ -251,6 +252,13 @@ template <class IO> struct PersistCfgBase {
     static constexpr bool kInvInLds = IO::kInvInLds, kTwLastInLds = false;
 };
 template <class IO> struct PersistCfg<13, IO> : PersistCfgBase<IO> { static constexpr int BLOCK = 512, MINW = 2, WG_PER_CU = 1; };
+// c64 n = 8192 (round 3): 136 KiB of exchange buffer is one workgroup per CU either way; the generic kernel then runs its load,
+// transform and store phases with nothing beside them.  Persistent with the next transform's loads in flight; table entries
+// from global memory in every pass (kTwGlobal: no room for them in registers or LDS).
+template <bool INV> struct PersistCfg<13, ComplexIO<double, INV>> {
+    static constexpr int BLOCK = 512, NBUF = 1, RL = 4, MINW = 2, WG_PER_CU = 1;
+    static constexpr bool kInvInLds = false, kTwLastInLds = false, kTwGlobal = true;
+};
 #ifndef KOFFT_PERSIST12_SPREAD
 #define KOFFT_PERSIST12_SPREAD false
 #endif
@@ -426,6 +434,7 @@ int launch_split1(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t bat
 template <typename T, int N, int EPI, class IO>
 int launch_small(kofft_hip_ctx *ctx, const IO &io, size_t batch, const cpx<T> *tw = nullptr)
 {
+    constexpr int kSmallBlock = small_block_threads<N>();
     const size_t blocks = (batch + kSmallBlock - 1) / kSmallBlock;
     if (blocks > 0x7fffffffULL) return KOFFT_ERR_UNSUPPORTED;
     constexpr size_t lds = small_lds_bytes<T, N>();
@@ -480,6 +489,9 @@ int dispatch(kofft_hip_ctx *ctx, const IO &io, size_t n, size_t batch)
     if (rc) return rc;
     // n = 32 in f32: still one thread per transform (64 data registers), IO staged through LDS like the small sizes
     if constexpr (sizeof(T) == 4 && !IO::kSlotMinor) if (L == 5 && ctx->small32) return launch_small<T, 32, EPI>(ctx, io, batch, tw);
+    if constexpr (sizeof(T) == 8 && EPI == EPI_STORE && io_split_ok<IO>::value && IO::kPersist) {
+        if (L == 13 && ctx->use_persist && ctx->persist64 && batch >= (size_t)ctx->num_cus * 4) return launch_persist<T, 13, EPI>(ctx, io, tw, batch);
+    }
     if constexpr (sizeof(T) == 4 && IO::kPersist) if (ctx->use_persist) {
         // streaming sizes: enough transforms to give every resident workgroup several iterations
         if constexpr (EPI == EPI_STORE && io_split_ok<IO>::value)
