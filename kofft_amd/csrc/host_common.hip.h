@@ -20,7 +20,7 @@
 
 #include "fft_big.hip.h"
 #include "fft_persist.hip.h"
-#include "fft_split.hip.h"
+#include "fft_split_wide.hip.h"
 #include "fft_wg.hip.h"
 #include "tables.h"
 
@@ -58,6 +58,7 @@ struct kofft_hip_ctx {
     int host_chunks = 0;       // KOFFT_HIP_HOST_CHUNKS: pieces of a pipelined host batch (default 8)
     bool persist64 = true;     // KOFFT_HIP_PERSIST64=0: c64 n = 8192 on the generic kernel (A/B measurements)
     bool persist_small = true; // KOFFT_HIP_PERSIST_SMALL=0: n = 128, 256 on the generic kernels (A/B measurements)
+    int split14 = 2;           // KOFFT_HIP_SPLIT14=1: n = 16384 on the 16-points-per-thread kernel (fft_split1) instead of the 32-points one (fft_split_wide.hip.h)
     int split13 = 1;           // KOFFT_HIP_SPLIT13=2: n = 8192 as TWO independent single-buffer workgroups per CU (fft_split1) instead of one
                                // double-buffered one (measured, same box: c32 0.52-0.53 against 0.61-0.63, STFT 0.41 against 0.43)
     bool use_split = true;     // KOFFT_HIP_SPLIT=0: n = 8192 on the block-synchronised persistent kernel instead of the wave-split one (A/B)
@@ -431,6 +432,28 @@ int launch_split1(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t bat
     return KOFFT_OK;
 }
 
+// n = 2^14 with 32 points per thread (fft_split_wide.hip.h): 512 threads, one workgroup per CU, 128-byte runs both ways
+template <typename T, int LA, int LB, int QB0, class IO>
+int launch_split_wide(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t batch)
+{
+    using Gm = SplitWideGeom<LA, LB, QB0>;
+    constexpr size_t lds = split_wide_lds_bytes<Gm>();
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = fft_split_wide_persist_kernel<T, LA, LB, QB0, IO>;
+    {
+        static std::atomic<unsigned long long> attr_done{0};
+        const int arc = set_dyn_lds_once(ctx, attr_done, reinterpret_cast<const void *>(kern), lds);
+        if (arc) return arc;
+    }
+    size_t blocks = (size_t)ctx->num_cus * ((160 * 1024) / lds);
+    if (ctx->persist_grid_pct > 0) blocks = blocks * (size_t)ctx->persist_grid_pct / 100;
+    if (blocks < 1) blocks = 1;
+    if (blocks > batch) blocks = batch;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Gm::TPT), lds, ctx->stream, io, tw, batch);
+    KOFFT_HIP_TRY(ctx, hipGetLastError());
+    return KOFFT_OK;
+}
+
 template <typename T, int N, int EPI, class IO>
 int launch_small(kofft_hip_ctx *ctx, const IO &io, size_t batch, const cpx<T> *tw = nullptr)
 {
@@ -494,8 +517,10 @@ int dispatch(kofft_hip_ctx *ctx, const IO &io, size_t n, size_t batch)
     }
     if constexpr (sizeof(T) == 4 && IO::kPersist) if (ctx->use_persist) {
         // streaming sizes: enough transforms to give every resident workgroup several iterations
-        if constexpr (EPI == EPI_STORE && io_split_ok<IO>::value)
+        if constexpr (EPI == EPI_STORE && io_split_ok<IO>::value) {
+            if (L == 14 && ctx->use_split && ctx->split14 == 2 && batch >= (size_t)ctx->num_cus * 4) return launch_split_wide<T, 7, 7, 2>(ctx, io, tw, batch);
             if (L == 14 && ctx->use_split && batch >= (size_t)ctx->num_cus * 4) return launch_split1<T, 7, 7>(ctx, io, tw, batch);
+        }
         if constexpr (EPI == EPI_STORE && IO::kPersistMaxLog2 >= 13) {
             if constexpr (io_split_ok<IO>::value) {
                 if (L == 13 && ctx->use_split && ctx->split13 == 2 && batch >= (size_t)ctx->num_cus * 8) return launch_split1<T, 7, 6>(ctx, io, tw, batch);

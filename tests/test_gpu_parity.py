@@ -1170,10 +1170,12 @@ def test_large_n_batches_around_the_tile_width_steps(fft32, fft64, oracle, dtype
 
 
 @pytest.mark.parametrize("batch", [1024, 1283])
-def test_n16384_single_buffer_wave_split_kernel(fft32, oracle, batch):
-    """fft_split1_persist_kernel (n = 16384: 1024 threads, one LDS buffer, two barriers, table entries of passes A1 / B0 in LDS
-    and of B1 re-read per transform): complex forward / inverse, STFT and magnitudes with a 16384-sample window, against the
-    oracle and against the generic kernel (KOFFT_HIP_SPLIT=0), workgroups with 4, 5 and 6 transforms."""
+def test_n16384_wave_split_kernels(fft32, oracle, batch):
+    """n = 16384.  Default: fft_split_wide_persist_kernel (512 threads, 32 points each, a wavefront owns 2048 points = 128-byte
+    runs both ways; one LDS buffer, two barriers, pass B1's 31 table entries resident in registers).  KOFFT_HIP_SPLIT14=1:
+    fft_split1_persist_kernel (1024 threads, 16 points each).  KOFFT_HIP_SPLIT=0: the generic kernel.  Complex forward / inverse,
+    STFT and magnitudes with a 16384-sample window, all three routes against the oracle bit for bit; workgroups with 4, 5 and
+    6 transforms."""
     import os
 
     import kofft_amd
@@ -1181,24 +1183,25 @@ def test_n16384_single_buffer_wave_split_kernel(fft32, oracle, batch):
     rng = seeded(7300 + batch)
     x = rand_c(rng, (batch, 16384))
     want = oracle.fft(x)
-    for split in ("1", "0"):
-        os.environ["KOFFT_HIP_SPLIT"] = split
-        try:
-            f = kofft_amd.HipFftImpl(np.float32)
-        finally:
-            del os.environ["KOFFT_HIP_SPLIT"]
-        y = x.copy()
-        f.fft_batch(y)
-        assert bits_equal(y, want), f"KOFFT_HIP_SPLIT={split} batch={batch}"
-        f.fft_batch(y, inverse=True)
-        assert bits_equal(y, oracle.ifft(want)), f"inverse KOFFT_HIP_SPLIT={split} batch={batch}"
     sig = rng.uniform(-1, 1, 4096 * batch + 77).astype(np.float32)
     w = oracle.hann(16384)
     frames = -(-sig.size // 4096)
-    assert bits_equal(fft32.stft_into(sig, w, 4096, frames), oracle.stft(sig, w, 4096, frames))
-    mags, mx = fft32.stft_magnitudes(sig, 16384, 4096)
+    want_stft = oracle.stft(sig, w, 4096, frames)
     wm, wmx = oracle.stft_magnitudes(sig, 16384, 4096)
-    assert bits_equal(mags, wm) and mx == wmx
+    for knob, val in (("KOFFT_HIP_SPLIT14", "2"), ("KOFFT_HIP_SPLIT14", "1"), ("KOFFT_HIP_SPLIT", "0")):
+        os.environ[knob] = val
+        try:
+            f = kofft_amd.HipFftImpl(np.float32)
+        finally:
+            del os.environ[knob]
+        y = x.copy()
+        f.fft_batch(y)
+        assert bits_equal(y, want), f"{knob}={val} batch={batch}"
+        f.fft_batch(y, inverse=True)
+        assert bits_equal(y, oracle.ifft(want)), f"inverse {knob}={val} batch={batch}"
+        assert bits_equal(f.stft_into(sig, w, 4096, frames), want_stft), f"stft {knob}={val}"
+        mags, mx = f.stft_magnitudes(sig, 16384, 4096)
+        assert bits_equal(mags, wm) and mx == wmx, f"stft_magnitudes {knob}={val}"
 
 
 # ---- FftStrategy::Radix4, the reference's bytes (opt-in compatibility arm) -----------------------------

@@ -143,3 +143,35 @@ def test_wave_split_decomposition_and_swizzle(la, lb):
         mk, mj = rnd.randrange(1 << la), rnd.randrange(1 << lb)
         ka, kb, ja, jb = k1 & mk, k1 & ~mk, j1 & mj, j1 & ~mj
         assert cell(k1, j1) == cell(ka, ja) ^ cell(kb, jb)
+
+
+@pytest.mark.parametrize("la,lb,qb0,F,G", [(7, 7, 2, [2, 9, 24, 5, 1, 4, 26], [30, 7]), (7, 7, 3, [2, 9, 24, 5, 1, 4, 26], [30, 7]),
+                                        (7, 6, 2, [2, 9, 24, 30, 1, 4, 26], [30]), (6, 7, 2, [3, 9, 24, 30, 1, 4], [26, 30])])
+def test_wide_wave_split_decomposition_and_swizzle(la, lb, qb0, F, G):
+    """fft_split_wide.hip.h (32 points per thread, a wavefront owns 2048 points): the index maps reproduce numpy's FFT with the
+    reference's per-stage table entries, cell(K, j) = K * 2^LB + (j ^ F(K) ^ G(j >> 5)) is a bijection, XOR-linear, and none
+    of the six access shapes conflicts.  The F / G here are the ones SplitWideSwizzle holds."""
+    import re
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(root / "tools"))
+    import split_model as sm
+
+    src = (root / "kofft_amd" / "csrc" / "fft_split_wide.hip.h").read_text()
+    m = re.search(r"SplitWideSwizzle<%d, %d> \{[^}]*F\[\d+\] = \{([^}]*)\};\s*static constexpr int G\[\d+\] = \{([^}]*)\};" % (la, lb), src)
+    assert m and [int(v) for v in m.group(1).split(",")] == F and [int(v) for v in m.group(2).split(",")] == G
+    kw = dict(rlog=5, qa0=5, qb0=qb0)
+    assert sm.run(la, lb, **kw) < 1e-12
+    g = sm.Geom(la, lb, **kw)
+    assert sm.conflicts(g, F, G) == 0
+    cells = {sm.cell_of(g, F, K, j, G) for K in range(1 << la) for j in range(1 << lb)}
+    assert len(cells) == g.N and max(cells) == g.N - 1
+    import random
+
+    rnd = random.Random(6)
+    for _ in range(2000):
+        k1, j1 = rnd.randrange(1 << la), rnd.randrange(1 << lb)
+        mk, mj = rnd.randrange(1 << la), rnd.randrange(1 << lb)
+        assert sm.cell_of(g, F, k1, j1, G) == sm.cell_of(g, F, k1 & mk, j1 & mj, G) ^ sm.cell_of(g, F, k1 & ~mk, j1 & ~mj, G)

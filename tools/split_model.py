@@ -30,64 +30,85 @@ def bitrev(x, b):
 
 
 class Geom:
-    def __init__(self, LA, LB):
+    """rlog = log2(points per thread): 4 (the kernels of fft_split.hip.h up to round 3) or 5 (the wide kernel: a wavefront owns
+    2048 points); qa0 / qb0 = stages of the first register pass of each phase (the second pass takes the rest)."""
+
+    def __init__(self, LA, LB, rlog=4, qa0=None, qb0=None):
         self.LA, self.LB, self.L = LA, LB, LA + LB
         self.N = 1 << self.L
-        self.W = self.N // 1024
-        self.QA1, self.QB1 = LA - 4, LB - 4
-        assert 1 <= self.QA1 <= 4 and 1 <= self.QB1 <= 4
-        self.CA, self.RB = 1024 >> LA, 1024 >> LB   # columns / rows per wavefront
-        self.TA, self.TB = 1 << (LA - 4), 1 << (LB - 4)  # threads per column / per row
+        self.RLOG, self.R = rlog, 1 << rlog
+        self.PW = 64 * self.R                 # points per wavefront
+        self.W = self.N // self.PW
+        self.QA0 = rlog if qa0 is None else qa0
+        self.QB0 = rlog if qb0 is None else qb0
+        self.QA1, self.QB1 = LA - self.QA0, LB - self.QB0
+        assert 1 <= self.QA1 <= rlog and 1 <= self.QB1 <= rlog and self.QA0 <= rlog and self.QB0 <= rlog
+        self.CA, self.RB = self.PW >> LA, self.PW >> LB   # columns / rows per wavefront
+        self.TA, self.TB = (1 << LA) // self.R, (1 << LB) // self.R  # threads per column / per row
 
-    # ---- phase A, lane = ja * CA + x
+    # ---- phase A, lane = ja * CA + x.  Pass A0: groups g of 2^QA0 registers (one group when QA0 == RLOG)
     def a_lane(self, lane):
         return lane // self.CA, lane % self.CA  # (ja, x)
 
-    def a0_in(self, w, lane, c):      # global element index loaded into register c
-        ja, x = self.a_lane(lane)
-        return ((c << (self.LA - 4)) | ja) << self.LB | (w * self.CA + x)
+    def _split(self, u, Q):
+        return u >> Q, u & ((1 << Q) - 1)
 
-    def a0_out(self, lane, c):        # local index (within the column transform) after pass A0
+    def a0_pos(self, lane, u):        # position m of register u's group inside the column: element = c * 2^(LA-QA0) + m
         ja, _ = self.a_lane(lane)
-        return (bitrev(c, 4) << (self.LA - 4)) | ja
+        g, _ = self._split(u, self.QA0)
+        return ja + g * self.TA
+
+    def a0_in(self, w, lane, u):      # global element index loaded into register u
+        _, x = self.a_lane(lane)
+        _, c = self._split(u, self.QA0)
+        return ((c << (self.LA - self.QA0)) | self.a0_pos(lane, u)) << self.LB | (w * self.CA + x)
+
+    def a0_out(self, lane, u):        # local index (within the column transform) after pass A0
+        _, c = self._split(u, self.QA0)
+        return (bitrev(c, self.QA0) << (self.LA - self.QA0)) | self.a0_pos(lane, u)
 
     def a1_in(self, lane, u):         # local index gathered into register u = (g, c') of pass A1
         kk, _ = self.a_lane(lane)
         Q = self.QA1
-        g, c = u >> Q, u & ((1 << Q) - 1)
+        g, c = self._split(u, Q)
         k = kk + g * self.TA
         return (k << Q) | c, k
 
     def a1_out(self, lane, u):        # K: the column transform's output frequency
         kk, _ = self.a_lane(lane)
         Q = self.QA1
-        g, c = u >> Q, u & ((1 << Q) - 1)
-        return (bitrev(c, Q) << 4) | (kk + g * self.TA)
+        g, c = self._split(u, Q)
+        return (bitrev(c, Q) << self.QA0) | (kk + g * self.TA)
 
     # ---- phase B, lane = jb * RB + y
     def b_lane(self, lane):
         return lane // self.RB, lane % self.RB  # (jb, y)
 
-    def b0_in(self, lane, c):         # j within the row
+    def b0_pos(self, lane, u):
         jb, _ = self.b_lane(lane)
-        return (c << (self.LB - 4)) | jb
+        g, _ = self._split(u, self.QB0)
+        return jb + g * self.TB
 
-    def b0_out(self, lane, c):
-        jb, _ = self.b_lane(lane)
-        return (bitrev(c, 4) << (self.LB - 4)) | jb
+    def b0_in(self, lane, u):         # j within the row
+        _, c = self._split(u, self.QB0)
+        return (c << (self.LB - self.QB0)) | self.b0_pos(lane, u)
+
+    def b0_out(self, lane, u):
+        _, c = self._split(u, self.QB0)
+        return (bitrev(c, self.QB0) << (self.LB - self.QB0)) | self.b0_pos(lane, u)
 
     def b1_in(self, lane, u):
         kb, _ = self.b_lane(lane)
         Q = self.QB1
-        g, c = u >> Q, u & ((1 << Q) - 1)
+        g, c = self._split(u, Q)
         k = kb + g * self.TB
         return (k << Q) | c, k
 
     def b1_out(self, w, lane, u):     # global output index
         kb, y = self.b_lane(lane)
         Q = self.QB1
-        g, c = u >> Q, u & ((1 << Q) - 1)
-        q = (bitrev(c, Q) << 4) | (kb + g * self.TB)
+        g, c = self._split(u, Q)
+        q = (bitrev(c, Q) << self.QB0) | (kb + g * self.TB)
         return (q << self.LA) | (w * self.RB + y)
 
 
@@ -109,62 +130,60 @@ def reg_pass(v, Lsub, S0, Q, k, tw_index, used):
 TW = None
 
 
-def run(LA, LB, seed=0):
+def run(LA, LB, seed=0, **kw):
     global TW
-    g = Geom(LA, LB)
-    N, L = g.N, g.L
+    g = Geom(LA, LB, **kw)
+    N, L, R = g.N, g.L, g.R
     TW = np.exp(-2j * np.pi * np.arange(N // 2) / N)
     rng = np.random.default_rng(seed)
     x = rng.standard_normal(N) + 1j * rng.standard_normal(N)
     lds = {}
     out = np.zeros(N, complex)
     used_a, used_b = [], []
+
+    def passes(v, Lsub, S0, Q, ks, tw_index, used):
+        for grp in range(R >> Q):
+            sub = v[grp << Q:(grp + 1) << Q]
+            reg_pass(sub, Lsub, S0, Q, ks[grp << Q], tw_index, used)
+            v[grp << Q:(grp + 1) << Q] = sub
+
     # phase A
     for w in range(g.W):
-        regs = {}
         for lane in range(64):
-            v = [x[g.a0_in(w, lane, c)] for c in range(16)]
-            reg_pass(v, LA, 0, 4, 0, lambda idx, s: idx << LB, used_a)
-            for c in range(16):
-                lds[("A", w, g.a0_out(lane, c), g.a_lane(lane)[1])] = v[c]
+            v = [x[g.a0_in(w, lane, u)] for u in range(R)]
+            # pass A0 acts on stages 0 .. QA0-1: the group's "k" is 0 (all twiddle indices come from the stage-local h)
+            passes(v, LA, 0, g.QA0, [0] * R, lambda idx, s: idx << LB, used_a)
+            for u in range(R):
+                lds[("A", w, g.a0_out(lane, u), g.a_lane(lane)[1])] = v[u]
         for lane in range(64):
             _, xcol = g.a_lane(lane)
-            v = [None] * 16
-            ks = [None] * 16
-            for u in range(16):
+            v, ks = [None] * R, [None] * R
+            for u in range(R):
                 loc, k = g.a1_in(lane, u)
                 v[u] = lds[("A", w, loc, xcol)]
                 ks[u] = k
-            Q = g.QA1
-            for grp in range(16 >> Q):
-                sub = v[grp << Q:(grp + 1) << Q]
-                reg_pass(sub, LA, 4, Q, ks[grp << Q], lambda idx, s: idx << LB, used_a)
-                v[grp << Q:(grp + 1) << Q] = sub
-            for u in range(16):
+            passes(v, LA, g.QA0, g.QA1, ks, lambda idx, s: idx << LB, used_a)
+            for u in range(R):
                 lds[("X", g.a1_out(lane, u), w * g.CA + xcol)] = v[u]
     # phase B
     for w in range(g.W):
         for lane in range(64):
             _, y = g.b_lane(lane)
             K = w * g.RB + y
-            v = [lds[("X", K, g.b0_in(lane, c))] for c in range(16)]
-            reg_pass(v, LB, 0, 4, 0, lambda idx, s: (idx << LA) + (K << (LB - 1 - s)), used_b)
-            for c in range(16):
-                lds[("B", K, g.b0_out(lane, c))] = v[c]
+            v = [lds[("X", K, g.b0_in(lane, u))] for u in range(R)]
+            passes(v, LB, 0, g.QB0, [0] * R, lambda idx, s: (idx << LA) + (K << (LB - 1 - s)), used_b)
+            for u in range(R):
+                lds[("B", K, g.b0_out(lane, u))] = v[u]
         for lane in range(64):
             _, y = g.b_lane(lane)
             K = w * g.RB + y
-            v, ks = [None] * 16, [None] * 16
-            for u in range(16):
+            v, ks = [None] * R, [None] * R
+            for u in range(R):
                 loc, k = g.b1_in(lane, u)
                 v[u] = lds[("B", K, loc)]
                 ks[u] = k
-            Q = g.QB1
-            for grp in range(16 >> Q):
-                sub = v[grp << Q:(grp + 1) << Q]
-                reg_pass(sub, LB, 4, Q, ks[grp << Q], lambda idx, s: (idx << LA) + (K << (LB - 1 - s)), used_b)
-                v[grp << Q:(grp + 1) << Q] = sub
-            for u in range(16):
+            passes(v, LB, g.QB0, g.QB1, ks, lambda idx, s: (idx << LA) + (K << (LB - 1 - s)), used_b)
+            for u in range(R):
                 out[g.b1_out(w, lane, u)] = v[u]
     want = np.fft.fft(x)
     err = np.linalg.norm(out - want) / np.linalg.norm(want)
@@ -185,7 +204,7 @@ def shapes(g):
     """(name, kind, [per-lane list of (K, j)] for register 0).  Conflicts depend on which index bits the lanes of a group
     differ in, and the register only adds a constant (XOR-linear cells): one register per shape is enough -- all are checked anyway."""
     out = []
-    for reg in range(16):
+    for reg in range(g.R):
         out.append((f"A0 scatter r{reg}", "w", [(g.a0_out(l, reg), g.a_lane(l)[1]) for l in range(64)]))
         out.append((f"A1 gather r{reg}", "r", [(g.a1_in(l, reg)[0], g.a_lane(l)[1]) for l in range(64)]))
         out.append((f"A1 scatter r{reg}", "w", [(g.a1_out(l, reg), g.a_lane(l)[1]) for l in range(64)]))
@@ -206,48 +225,56 @@ def apply_f(F, K):
     return r
 
 
-def conflicts(g, F):
+def cell_of(g, F, K, j, G=()):
+    """cell(K, j) = K * 2^LB + (j ^ F(K) ^ G(j >> 5)): F, G linear over GF(2) with values in the low five bits of j (the bank bits).
+    G (wide kernel only) folds the HIGH bits of j in: two lanes of a read group that differ only in bit 5 of j share a bank otherwise."""
+    return (K << g.LB) | (j ^ apply_f(F, K) ^ (apply_f(G, j >> 5) if G else 0))
+
+
+def conflicts(g, F, G=()):
     total = 0
     for name, kind, cells in shapes(g):
         group, banks = (16, 16) if kind == "w" else (32, 32)
         for g0 in range(0, 64, group):
             seen = {}
             for K, j in cells[g0:g0 + group]:
-                cell = (K << g.LB) | (j ^ apply_f(F, K))
+                cell = cell_of(g, F, K, j, G)
                 seen.setdefault(cell % banks, set()).add(cell)
             total += max(len(v) for v in seen.values()) - 1
     return total
 
 
-def search(g, tries=20000, seed=1):
+def search(g, tries=20000, seed=1, with_g=False):
     rng = np.random.default_rng(seed)
     nb = g.LA
-    best = None
-    # only the low 5 bits of j decide a bank; keep F inside the j field
+    ng = max(0, g.LB - 5) if with_g else 0
+    # only the low 5 bits of j decide a bank; keep F (and G) inside them
     mask = (1 << min(g.LB, 5)) - 1
-    cand0 = [0] * nb
-    c0 = conflicts(g, cand0)
+    cand0 = [0] * (nb + ng)
+    c0 = conflicts(g, cand0[:nb], cand0[nb:])
     if c0 == 0:
-        return cand0, 0
+        return (cand0[:nb], cand0[nb:], 0) if with_g else (cand0, 0)
     best = (c0, cand0)
     for _ in range(tries):
-        F = [int(rng.integers(0, mask + 1)) for _ in range(nb)]
-        c = conflicts(g, F)
+        F = [int(rng.integers(0, mask + 1)) for _ in range(nb + ng)]
+        c = conflicts(g, F[:nb], F[nb:])
         if c < best[0]:
             best = (c, F)
             # local improvement: greedy single-column changes
             improved = True
             while improved and best[0] > 0:
                 improved = False
-                for i, val in itertools.product(range(nb), range(mask + 1)):
+                for i, val in itertools.product(range(nb + ng), range(mask + 1)):
                     F2 = list(best[1])
                     F2[i] = val
-                    c2 = conflicts(g, F2)
+                    c2 = conflicts(g, F2[:nb], F2[nb:])
                     if c2 < best[0]:
                         best = (c2, F2)
                         improved = True
             if best[0] == 0:
                 break
+    if with_g:
+        return best[1][:nb], best[1][nb:], best[0]
     return best[1], best[0]
 
 
