@@ -524,6 +524,10 @@ int dispatch(kofft_hip_ctx *ctx, const IO &io, size_t n, size_t batch)
         if constexpr (EPI == EPI_STORE && IO::kPersistMaxLog2 >= 13) {
             if constexpr (io_split_ok<IO>::value) {
                 if (L == 13 && ctx->use_split && ctx->split13 == 2 && batch >= (size_t)ctx->num_cus * 8) return launch_split1<T, 7, 6>(ctx, io, tw, batch);
+#ifdef KOFFT_EXP_WIDE13  // measurement builds: the 32-points-per-thread kernel at n = 8192 (two 256-thread workgroups per CU): 0.58 against 0.63
+                if (L == 13 && ctx->use_split && ctx->split13 == 3 && batch >= (size_t)ctx->num_cus * 8) return launch_split_wide<T, 7, 6, 2>(ctx, io, tw, batch);
+                if (L == 13 && ctx->use_split && ctx->split13 == 5 && batch >= (size_t)ctx->num_cus * 8) return launch_split_wide<T, 6, 7, 2>(ctx, io, tw, batch);
+#endif
                 if (L == 13 && ctx->use_split && batch >= (size_t)ctx->num_cus * 4) return launch_split<T, 7, 6>(ctx, io, tw, batch);
             }
             if (L == 13 && batch >= (size_t)ctx->num_cus * 4) return launch_persist<T, 13, EPI>(ctx, io, tw, batch);
