@@ -135,6 +135,7 @@ struct ComplexIO : PlainTw {
 
 // stft.rs:91-103: frame f starts at start0 + f*hop; x = signal[start+i]*window[i] or 0.
 struct StftIO : PlainTw {
+    static constexpr int kSmallBlock32 = 256;  // fft_small_kernel at n = 32 (StftMagIO inherits it)
     static constexpr bool kSplitOk = true;  // fft_split.hip.h
     static constexpr bool kStreams = true;
     static constexpr bool kPersist = true;
@@ -932,7 +933,8 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const cpx<float> *__rest
 // reads and writes run over the workgroup's elements in memory order (fully coalesced), and each thread picks its
 // row out of LDS (row stride n+1 cells: odd, so the 64 lanes hit distinct banks).
 // n = 32: workgroups of 128 -- four 33 KiB workgroups per CU interleave their load / transform / store phases better than two
-// of 66 KiB (c32 n = 32: 0.60 .. 0.71 -> 0.74 .. 0.75 of the roofline on one box; rfft n = 64 and STFT n = 32 do not care).
+// of 66 KiB (c32 n = 32: 0.60 .. 0.71 -> 0.74 .. 0.77 of the roofline on one box; rfft n = 64 does not care; STFT n = 32 loses
+// 6 % and keeps 256: StftIO::kSmallBlock32).
 // Tried and dropped in round 3, same box: PERSISTENT workgroups with the next block's loads prefetched into registers
 // (c32 0.69, rfft n = 64 0.60 -> 0.54, STFT n = 32 0.63 -> 0.53: 246 VGPRs, and the phases of two wavefronts per SIMD still do not
 // overlap); the 8-threads-per-transform persistent kernel (bit-equal, 0.42: its loads are 64-byte runs).
@@ -942,15 +944,20 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const cpx<float> *__rest
 #ifndef KOFFT_SMALL_BLOCK32
 #define KOFFT_SMALL_BLOCK32 128
 #endif
-template <int N>
-constexpr int small_block_threads() { return N == 32 ? KOFFT_SMALL_BLOCK32 : KOFFT_SMALL_BLOCK; }
-template <typename T, int N>
-constexpr size_t small_lds_bytes() { return N == 1 ? 0 : (size_t)small_block_threads<N>() * (N + 1) * sizeof(cpx<T>); }
+// (a policy may ask for its own n = 32 workgroup: kSmallBlock32 -- the STFT kernels lose 6 % with 128 threads, same box)
+template <class IO, class = void>
+struct io_small_block32 { static constexpr int value = KOFFT_SMALL_BLOCK32; };
+template <class IO>
+struct io_small_block32<IO, decltype((void)IO::kSmallBlock32)> { static constexpr int value = IO::kSmallBlock32; };
+template <int N, class IO>
+constexpr int small_block_threads() { return N == 32 ? io_small_block32<IO>::value : KOFFT_SMALL_BLOCK; }
+template <typename T, int N, class IO>
+constexpr size_t small_lds_bytes() { return N == 1 ? 0 : (size_t)small_block_threads<N, IO>() * (N + 1) * sizeof(cpx<T>); }
 
 template <typename T, int N, int EPI, class IO>
-__global__ __launch_bounds__(small_block_threads<N>()) void fft_small_kernel(const IO io, const cpx<T> *__restrict__ tw, const size_t batch)
+__global__ __launch_bounds__((small_block_threads<N, IO>())) void fft_small_kernel(const IO io, const cpx<T> *__restrict__ tw, const size_t batch)
 {
-    constexpr int B = small_block_threads<N>();
+    constexpr int B = small_block_threads<N, IO>();
     constexpr int S = N + 1;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     cpx<T> *buf = reinterpret_cast<cpx<T> *>(smem_raw);

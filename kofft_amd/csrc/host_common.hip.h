@@ -457,10 +457,10 @@ int launch_split_wide(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t
 template <typename T, int N, int EPI, class IO>
 int launch_small(kofft_hip_ctx *ctx, const IO &io, size_t batch, const cpx<T> *tw = nullptr)
 {
-    constexpr int kSmallBlock = small_block_threads<N>();
+    constexpr int kSmallBlock = small_block_threads<N, IO>();
     const size_t blocks = (batch + kSmallBlock - 1) / kSmallBlock;
     if (blocks > 0x7fffffffULL) return KOFFT_ERR_UNSUPPORTED;
-    constexpr size_t lds = small_lds_bytes<T, N>();
+    constexpr size_t lds = small_lds_bytes<T, N, IO>();
     auto kern = fft_small_kernel<T, N, EPI, IO>;
     if (lds > 64 * 1024) {
         static std::atomic<unsigned long long> attr_done{0};
