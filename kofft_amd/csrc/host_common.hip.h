@@ -56,7 +56,7 @@ struct kofft_hip_ctx {
     bool zero_copy = true;     // KOFFT_HIP_ZERO_COPY=0: small host calls through staged copies like large ones
     bool host_pipeline = true; // KOFFT_HIP_HOST_PIPELINE=0: host-pointer batches in one upload / kernel / download
     int host_chunks = 0;       // KOFFT_HIP_HOST_CHUNKS: pieces of a pipelined host batch (default 8)
-    bool persist64 = true;     // KOFFT_HIP_PERSIST64=0: c64 n = 8192 on the generic kernel (A/B measurements)
+    int persist64 = 1;         // KOFFT_HIP_PERSIST64=0: c64 n = 4096 / 8192 on the generic kernel (A/B measurements)
     bool persist_small = true; // KOFFT_HIP_PERSIST_SMALL=0: n = 128, 256 on the generic kernels (A/B measurements)
     int split14 = 2;           // KOFFT_HIP_SPLIT14=1: n = 16384 on the 16-points-per-thread kernel (fft_split1) instead of the 32-points one (fft_split_wide.hip.h)
     int split13 = 1;           // KOFFT_HIP_SPLIT13=2: n = 8192 as TWO independent single-buffer workgroups per CU (fft_split1) instead of one
@@ -253,11 +253,15 @@ template <class IO> struct PersistCfgBase {
     static constexpr bool kInvInLds = IO::kInvInLds, kTwLastInLds = false;
 };
 template <class IO> struct PersistCfg<13, IO> : PersistCfgBase<IO> { static constexpr int BLOCK = 512, MINW = 2, WG_PER_CU = 1; };
-// c64 n = 8192 (round 3): 136 KiB of exchange buffer is one workgroup per CU either way; the generic kernel then runs its load,
+// c64 n = 8192 (round 3; n = 4096 below): 136 KiB of exchange buffer is one workgroup per CU either way; the generic kernel then runs its load,
 // transform and store phases with nothing beside them.  Persistent with the next transform's loads in flight; table entries
 // from global memory in every pass (kTwGlobal: no room for them in registers or LDS).
 template <bool INV> struct PersistCfg<13, ComplexIO<double, INV>> {
     static constexpr int BLOCK = 512, NBUF = 1, RL = 4, MINW = 2, WG_PER_CU = 1;
+    static constexpr bool kInvInLds = false, kTwLastInLds = false, kTwGlobal = true;
+};
+template <bool INV> struct PersistCfg<12, ComplexIO<double, INV>> {
+    static constexpr int BLOCK = 256, NBUF = 1, RL = 4, MINW = 2, WG_PER_CU = 2;
     static constexpr bool kInvInLds = false, kTwLastInLds = false, kTwGlobal = true;
 };
 #ifndef KOFFT_PERSIST12_SPREAD
@@ -514,6 +518,8 @@ int dispatch(kofft_hip_ctx *ctx, const IO &io, size_t n, size_t batch)
     if constexpr (sizeof(T) == 4 && !IO::kSlotMinor) if (L == 5 && ctx->small32) return launch_small<T, 32, EPI>(ctx, io, batch, tw);
     if constexpr (sizeof(T) == 8 && EPI == EPI_STORE && io_split_ok<IO>::value && IO::kPersist) {
         if (L == 13 && ctx->use_persist && ctx->persist64 && batch >= (size_t)ctx->num_cus * 4) return launch_persist<T, 13, EPI>(ctx, io, tw, batch);
+        // n = 4096: two 256-thread workgroups per CU, same box 0.64-0.65 -> 0.67-0.68; n = 2048 measured too: no change (0.70), left
+        if (L == 12 && ctx->use_persist && ctx->persist64 && batch >= (size_t)ctx->num_cus * 8) return launch_persist<T, 12, EPI>(ctx, io, tw, batch);
     }
     if constexpr (sizeof(T) == 4 && IO::kPersist) if (ctx->use_persist) {
         // streaming sizes: enough transforms to give every resident workgroup several iterations

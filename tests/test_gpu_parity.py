@@ -858,17 +858,18 @@ def test_n8192_wave_split_kernel_around_the_grid(fft32, oracle, batch):
         assert bits_equal(y, oracle.ifft(want)), f"inverse KOFFT_HIP_SPLIT={split} batch={batch}"
 
 
-@pytest.mark.parametrize("batch", [1024, 1025, 1281])
-def test_c64_n8192_persistent_kernel_around_the_grid(oracle, batch):
-    """c64 n = 8192 from num_cus * 4 transforms up: fft_persist_kernel<double, 13> (one 512-thread workgroup per CU, the next
-    transform's loads in flight, table entries from global memory in every pass) -- bit for bit the generic kernel's and the
-    oracle's results, forward and inverse, with workgroups of 4 and 5 transforms and the empty-descriptor prefetch."""
+@pytest.mark.parametrize("n,batch", [(8192, 1024), (8192, 1025), (8192, 1281), (4096, 2048), (4096, 2561)])
+def test_c64_persistent_kernels_around_the_grid(oracle, n, batch):
+    """c64 n = 8192 from num_cus * 4 transforms up (n = 4096: num_cus * 8): fft_persist_kernel<double, 13 / 12> (one 512-thread /
+    two 256-thread workgroups per CU, the next transform's loads in flight, table entries from global memory in every pass) --
+    bit for bit the generic kernel's and the oracle's results, forward and inverse, with workgroups of 4 and 5 transforms and
+    the empty-descriptor prefetch."""
     import os
 
     import kofft_amd
 
     rng = seeded(7300 + batch)
-    x = rand_c(rng, (batch, 8192), np.complex128)
+    x = rand_c(rng, (batch, n), np.complex128)
     want = oracle.fft(x)
     for persist in ("1", "0"):
         os.environ["KOFFT_HIP_PERSIST64"] = persist
