@@ -305,7 +305,7 @@ __device__ __forceinline__ void persist_transform(const typename persist_raw<IO,
 
     if constexpr (EPI == EPI_RFFT) {
         // rfft.rs:450-463: Y in natural order through LDS, then X[k] from Y[k], Y[m-k]
-        static_assert(L <= 12, "rfft epilogue: the staged tables do not fit next to an 8192-point exchange buffer");
+        static_assert(L <= 12 || !CFG::kInvInLds, "rfft epilogue: a staged window does not fit next to an 8192-point exchange buffer and the post-pass table");
         cpx<T> *ybuf = (NP == 3) ? buf0 : buf1;  // not the buffer the last gather read from (when NBUF == 2)
         if (NBUF == 1) exchange_sync<WAVE>();
         // Y goes into the buffer in PLAIN natural order, not the padded exchange layout: every access of this epilogue is a

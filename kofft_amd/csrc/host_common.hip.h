@@ -56,6 +56,7 @@ struct kofft_hip_ctx {
     bool zero_copy = true;     // KOFFT_HIP_ZERO_COPY=0: small host calls through staged copies like large ones
     bool host_pipeline = true; // KOFFT_HIP_HOST_PIPELINE=0: host-pointer batches in one upload / kernel / download
     int host_chunks = 0;       // KOFFT_HIP_HOST_CHUNKS: pieces of a pipelined host batch (default 8)
+    bool rfft13_persist = true; // KOFFT_HIP_RFFT13_PERSIST=0: rfft / irfft n = 16384 on the generic kernel
     int persist64 = 1;         // KOFFT_HIP_PERSIST64=0: c64 n = 4096 / 8192 on the generic kernel (A/B measurements)
     bool persist_small = true; // KOFFT_HIP_PERSIST_SMALL=0: n = 128, 256 on the generic kernels (A/B measurements)
     int split14 = 2;           // KOFFT_HIP_SPLIT14=1: n = 16384 on the 16-points-per-thread kernel (fft_split1) instead of the 32-points one (fft_split_wide.hip.h)
@@ -325,6 +326,19 @@ template <> struct PersistCfg<12, RfftIO<float>> {
     static constexpr int BLOCK = 256, NBUF = 1, RL = 4, MINW = 2, WG_PER_CU = 2;
     static constexpr bool kInvInLds = false, kTwLastInLds = false;
 };
+#ifndef KOFFT_IRFFT13_TWGLOBAL
+#define KOFFT_IRFFT13_TWGLOBAL false
+#endif
+// rfft 16384 (m = 8192): one 512-thread workgroup per CU (exchange buffer 68 KiB + post-pass table 64 KiB)
+template <> struct PersistCfg<13, RfftIO<float>> {
+    static constexpr int BLOCK = 512, NBUF = 1, RL = 4, MINW = 2, WG_PER_CU = 1;
+    static constexpr bool kInvInLds = false, kTwLastInLds = false;
+};
+// irfft 16384 (m = 8192): the same, with the pre-pass table in LDS and every pass's twiddles from global memory
+template <> struct PersistCfg<13, IrfftIO<float>> {
+    static constexpr int BLOCK = 512, NBUF = 1, RL = 4, MINW = 2, WG_PER_CU = 1;
+    static constexpr bool kInvInLds = true, kTwLastInLds = false, kTwGlobal = KOFFT_IRFFT13_TWGLOBAL;
+};
 // n = 64: 4 points per thread, 16 threads per transform, three passes of two stages
 template <class IO> struct PersistCfg<6, IO> {
     static constexpr int BLOCK = 256, NBUF = 1, RL = 2, MINW = 4, WG_PER_CU = 4;
@@ -538,6 +552,12 @@ int dispatch(kofft_hip_ctx *ctx, const IO &io, size_t n, size_t batch)
             }
             if (L == 13 && batch >= (size_t)ctx->num_cus * 4) return launch_persist<T, 13, EPI>(ctx, io, tw, batch);
             if (L == 12 && batch >= (size_t)ctx->num_cus * 4) return launch_persist<T, 12, EPI>(ctx, io, tw, batch);
+        }
+        if constexpr (EPI == EPI_STORE && io_pairs_in_wave<IO>::value) {
+            if (L == 13 && ctx->rfft13_persist && batch >= (size_t)ctx->num_cus * 4) return launch_persist<T, 13, EPI>(ctx, io, tw, batch);
+        }
+        if constexpr (EPI == EPI_RFFT) {
+            if (L == 13 && ctx->rfft13_persist && batch >= (size_t)ctx->num_cus * 4) return launch_persist<T, 13, EPI>(ctx, io, tw, batch);
         }
         if constexpr (EPI == EPI_RFFT || (EPI == EPI_STORE && IO::kPersistMaxLog2 == 12)) {
             if (L == 12 && batch >= (size_t)ctx->num_cus * 4) return launch_persist<T, 12, EPI>(ctx, io, tw, batch);

@@ -1205,6 +1205,33 @@ def test_n16384_wave_split_kernels(fft32, oracle, batch):
         assert bits_equal(mags, wm) and mx == wmx, f"stft_magnitudes {knob}={val}"
 
 
+@pytest.mark.parametrize("batch", [1024, 1285])
+def test_rfft_irfft_n16384_persistent_kernels(oracle, batch):
+    """rfft / irfft of 16384 reals from num_cus * 4 rows up: fft_persist_kernel<float, 13> with the rfft epilogue (post-pass table in
+    LDS beside the 8192-point exchange buffer) and with irfft's paired input through the exchange buffer -- against the oracle
+    and the generic kernels (KOFFT_HIP_RFFT13_PERSIST=0), plain and with a row window."""
+    import os
+
+    import kofft_amd
+
+    rng = seeded(7500 + batch)
+    x = rng.uniform(-1, 1, (batch, 16384)).astype(np.float32)
+    win = rng.uniform(0.1, 1, 16384).astype(np.float32)
+    want = oracle.rfft(x)
+    want_w = oracle.rfft(x, win)
+    spec = rand_c(rng, (batch, 8193))
+    want_inv = oracle.irfft(spec, 16384)
+    for persist in ("1", "0"):
+        os.environ["KOFFT_HIP_RFFT13_PERSIST"] = persist
+        try:
+            f = kofft_amd.HipFftImpl(np.float32)
+        finally:
+            del os.environ["KOFFT_HIP_RFFT13_PERSIST"]
+        assert bits_equal(f.rfft_batch(x), want), f"rfft KOFFT_HIP_RFFT13_PERSIST={persist} batch={batch}"
+        assert bits_equal(f.rfft_batch(x, win), want_w), f"windowed rfft KOFFT_HIP_RFFT13_PERSIST={persist} batch={batch}"
+        assert bits_equal(f.irfft_batch(spec, 16384), want_inv), f"irfft KOFFT_HIP_RFFT13_PERSIST={persist} batch={batch}"
+
+
 # ---- FftStrategy::Radix4, the reference's bytes (opt-in compatibility arm; VERDICT r2 item 7) -----------------------------
 @pytest.mark.parametrize("n", [1, 4, 16, 64, 256, 1024, 4096, 65536, 8, 32, 12])
 def test_radix4_compat_reproduces_the_reference_arm(oracle, n):

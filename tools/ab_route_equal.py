@@ -2,7 +2,7 @@
 """Bit-equality of two dispatch routes of the same call, on one box: the environment knobs named on the command line are
 set for context B only (contexts read them when they are created).
 
-usage: python3 tools/ab_route_equal.py KOFFT_HIP_PERSIST5=1 [--kinds rfft,stft,stftmag] [--n 64] [--batch 600011]"""
+usage: python3 tools/ab_route_equal.py KOFFT_HIP_SPLIT14=1 [--kinds fft,rfft,rfftw,irfft,stft,stftmag,fft64,ifft64] [--n 16384] [--batch 1300]"""
 import argparse
 import os
 import sys
@@ -28,6 +28,9 @@ def run(kind, n, batch, seed):
         if kind == "rfftw":
             x = rng.standard_normal((batch, n), dtype=np.float32)
             return f.rfft_batch(x, rng.standard_normal(n, dtype=np.float32))
+        if kind == "irfft":
+            x = (rng.standard_normal((batch, n // 2 + 1)) + 1j * rng.standard_normal((batch, n // 2 + 1))).astype(np.complex64)
+            return f.irfft_batch(x, n)
         if kind == "fft":
             x = (rng.standard_normal((batch, n)) + 1j * rng.standard_normal((batch, n))).astype(np.complex64)
             f.fft_batch(x)
