@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Randomised differential soak of the kernels that only run from ~1000 transforms up at n >= 4096 (the wave-split kernels at
+8192 / 16384, c64 4096 / 8192, rfft / irfft 16384) and of the group-wide rfft stores (n = 128 .. 512): random batch sizes around
+and above the dispatch thresholds, random STFT hops with frames running past the end, against the oracle, bit for bit.
+usage (GPU box, repo root): python3 tools/soak_big.py [rounds=6] [seed=1]"""
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+import kofft_amd  # noqa: E402
+from conftest import bits_equal, rand_c  # noqa: E402
+from oracle import pyoracle as oracle  # noqa: E402
+
+
+def main():
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    oracle.build()
+    f32, f64 = kofft_amd.HipFftImpl(np.float32), kofft_amd.HipFftImpl(np.float64)
+    bad = n_cases = 0
+
+    def check(ok, what):
+        nonlocal bad, n_cases
+        n_cases += 1
+        if not ok:
+            bad += 1
+            print("FAIL", what, flush=True)
+
+    for r in range(rounds):
+        for n, lo in ((8192, 1024), (16384, 1024)):
+            batch = int(rng.integers(lo, lo + 700))
+            x = rand_c(rng, (batch, n))
+            y = x.copy()
+            inv = bool(rng.random() < 0.5)
+            f32.fft_batch(y, inverse=inv)
+            check(bits_equal(y, oracle.ifft(x) if inv else oracle.fft(x)), ("c32", n, batch, inv))
+            hop = int(rng.integers(n // 8, n // 2))
+            frames = int(rng.integers(lo, lo + 300))
+            length = frames * hop - int(rng.integers(0, hop))
+            sig = rng.uniform(-1, 1, length).astype(np.float32)
+            win = rng.uniform(0, 1, n).astype(np.float32)
+            fr = -(-length // hop)
+            check(bits_equal(f32.stft_into(sig, win, hop, fr), oracle.stft(sig, win, hop, fr)), ("stft", n, hop, fr))
+            hop2 = n // 4
+            mags, mx = f32.stft_magnitudes(sig, n, hop2)
+            wm, wmx = oracle.stft_magnitudes(sig, n, hop2)
+            check(bits_equal(mags, wm) and mx == wmx, ("stft_magnitudes", n, hop2))
+        for n, lo in ((4096, 2048), (8192, 1024)):
+            batch = int(rng.integers(lo, lo + 500))
+            x = rand_c(rng, (batch, n), np.complex128)
+            y = x.copy()
+            inv = bool(rng.random() < 0.5)
+            f64.fft_batch(y, inverse=inv)
+            check(bits_equal(y, oracle.ifft(x) if inv else oracle.fft(x)), ("c64", n, batch, inv))
+        batch = int(rng.integers(1024, 1500))
+        x = rng.uniform(-1, 1, (batch, 16384)).astype(np.float32)
+        win = rng.uniform(0, 1, 16384).astype(np.float32) if rng.random() < 0.5 else None
+        check(bits_equal(f32.rfft_batch(x, win), oracle.rfft(x, win)), ("rfft", 16384, batch, win is not None))
+        spec = rand_c(rng, (batch, 8193))
+        check(bits_equal(f32.irfft_batch(spec, 16384), oracle.irfft(spec, 16384)), ("irfft", 16384, batch))
+        for n in (128, 256, 512):
+            batch = int(rng.integers(256 * 2048 // n, 256 * 2048 // n + 3000))  # above the persistent kernel's threshold
+            x = rng.uniform(-1, 1, (batch, n)).astype(np.float32)
+            win = rng.uniform(0, 1, n).astype(np.float32) if rng.random() < 0.5 else None
+            check(bits_equal(f32.rfft_batch(x, win), oracle.rfft(x, win)), ("rfft", n, batch, win is not None))
+        print(f"round {r}: {n_cases} cases, {bad} failures", flush=True)
+    print("soak done, failures:", bad)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
