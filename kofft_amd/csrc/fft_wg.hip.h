@@ -58,6 +58,9 @@ struct PlainTw {
     __device__ __forceinline__ TwPlain tw_map(size_t) const { return {}; }
 };
 
+#ifndef KOFFT_STFT_SMALL_BLOCK32
+#define KOFFT_STFT_SMALL_BLOCK32 64
+#endif
 // FftImpl::fft (fft.rs:1054) / ifft (fft.rs:1134-1174: conj, fft, conj, *scale).
 template <typename T, bool INVERSE>
 struct ComplexIO : PlainTw {
@@ -135,7 +138,7 @@ struct ComplexIO : PlainTw {
 
 // stft.rs:91-103: frame f starts at start0 + f*hop; x = signal[start+i]*window[i] or 0.
 struct StftIO : PlainTw {
-    static constexpr int kSmallBlock32 = 256;  // fft_small_kernel at n = 32 (StftMagIO inherits it)
+    static constexpr int kSmallBlock32 = KOFFT_STFT_SMALL_BLOCK32;  // fft_small_kernel at n = 32 (StftMagIO inherits it)
     static constexpr bool kSplitOk = true;  // fft_split.hip.h
     static constexpr bool kStreams = true;
     static constexpr bool kPersist = true;
@@ -932,9 +935,11 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const cpx<float> *__rest
 // different cache lines per instruction.  The workgroup therefore moves its 256 transforms through LDS: global
 // reads and writes run over the workgroup's elements in memory order (fully coalesced), and each thread picks its
 // row out of LDS (row stride n+1 cells: odd, so the 64 lanes hit distinct banks).
-// n = 32: workgroups of 128 -- four 33 KiB workgroups per CU interleave their load / transform / store phases better than two
-// of 66 KiB (c32 n = 32: 0.60 .. 0.71 -> 0.74 .. 0.77 of the roofline on one box; rfft n = 64 does not care; STFT n = 32 loses
-// 6 % and keeps 256: StftIO::kSmallBlock32).
+// n = 32: workgroups of ONE wavefront -- nine 17 KiB workgroups per CU, each running its load / transform / store phases on its
+// own (the barriers are no-ops), interleave better than two of 66 KiB.  Same box, fraction of the roofline, 256 -> 128 -> 64
+// threads: c32 n = 32 0.60..0.71 -> 0.75 -> 0.78..0.80, rfft n = 64 0.59 -> 0.59 -> 0.62..0.63, irfft n = 64 0.60 -> 0.60 -> 0.64,
+// STFT n = 32 0.61..0.66 -> 0.61..0.63 -> 0.65..0.69.  (n <= 16 at 64 threads: c64 +2..5 %, c32 n = 8 / 16 -2 %, rfft64 n = 32
+// -4 %: mixed, left at 256.)
 // Tried and dropped in round 3, same box: PERSISTENT workgroups with the next block's loads prefetched into registers
 // (c32 0.69, rfft n = 64 0.60 -> 0.54, STFT n = 32 0.63 -> 0.53: 246 VGPRs, and the phases of two wavefronts per SIMD still do not
 // overlap); the 8-threads-per-transform persistent kernel (bit-equal, 0.42: its loads are 64-byte runs).
@@ -942,9 +947,9 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const cpx<float> *__rest
 #define KOFFT_SMALL_BLOCK 256
 #endif
 #ifndef KOFFT_SMALL_BLOCK32
-#define KOFFT_SMALL_BLOCK32 128
+#define KOFFT_SMALL_BLOCK32 64
 #endif
-// (a policy may ask for its own n = 32 workgroup: kSmallBlock32 -- the STFT kernels lose 6 % with 128 threads, same box)
+// (a policy may ask for its own n = 32 workgroup: kSmallBlock32)
 template <class IO, class = void>
 struct io_small_block32 { static constexpr int value = KOFFT_SMALL_BLOCK32; };
 template <class IO>
