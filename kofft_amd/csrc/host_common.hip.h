@@ -217,13 +217,23 @@ constexpr int rl_for_kind(int L)
     return (L >= 13 && (sizeof(T) == 8 || EPI == EPI_RFFT)) ? 4 : rl_for(L);
 }
 
+#ifndef KOFFT_WG_MIN_BLOCK
+#define KOFFT_WG_MIN_BLOCK 256
+#endif
+#ifndef KOFFT_WG64_SMALL_FROM
+#define KOFFT_WG64_SMALL_FROM 9
+#endif
 template <typename T, int L, int EPI, class IO, int BLOCK_OVERRIDE = 0>
 int launch_wg(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t batch)
 {
     // (sub-transforms of the large-n path come with their own block size, computed for rl_for)
     constexpr int RL = BLOCK_OVERRIDE ? rl_for(L) : rl_for_kind<T, EPI>(L);
     constexpr int TPT0 = (1 << L) >> RL;
-    constexpr int BLOCK = BLOCK_OVERRIDE ? BLOCK_OVERRIDE : (TPT0 > 256 ? TPT0 : 256);
+    // f64 from n = 512: one transform per workgroup down to a single wavefront (round 3, same box, 256 -> 64 / 128 threads: rfft64
+    // n = 2048 0.62 -> 0.71, c64 2048 0.72 -> 0.75, c64 / rfft64 512 .. 1024 +2..4 %, irfft64 2048 0.63 -> 0.64..0.66; below
+    // 512 and for f32 the results are mixed (+-4 %) and the workgroups stay at 256)
+    constexpr int MINB = (sizeof(T) == 8 && L >= KOFFT_WG64_SMALL_FROM) ? 64 : KOFFT_WG_MIN_BLOCK;
+    constexpr int BLOCK = BLOCK_OVERRIDE ? BLOCK_OVERRIDE : (TPT0 > MINB ? TPT0 : MINB);
     constexpr int TPT = (1 << L) >> RL;
     constexpr int XPB = BLOCK / TPT;
     constexpr size_t lds = lds_wg_bytes<T, wg_split_lds<T, L, EPI, IO>(), IO::kSlotMinor, XPB>(1 << L);
