@@ -93,6 +93,12 @@ struct SplitWideGeom {
         const int g = u >> QB1, c = u & ((1 << QB1) - 1);
         return cell_bytes(0, ((g * TB) << QB1) | c);
     }
+    // the cell of output register u in the thread's own row: (K, q), q = (bitrev(c) << QB0) | (kb + g * TB) -- register part
+    __host__ __device__ static constexpr int y_reg(int u)
+    {
+        const int g = u >> QB1, c = u & ((1 << QB1) - 1);
+        return cell_bytes(0, (bitrev(c, QB1) << QB0) | (g * TB));
+    }
     // element offset of output register u relative to the thread's tauB = (kb << LA) | K
     __host__ __device__ static constexpr int out_reg(int u)
     {
@@ -114,7 +120,18 @@ constexpr size_t split_wide_lds_bytes()
 #define KOFFT_SPLITW_TWB_RESIDENT 1
 #endif
 
-template <typename T, int LA, int LB, int QB0, class IO>
+// EPI_RFFT (IO = RfftIO<float>): the real-FFT
+// post-pass (rfft.rs:450-463) on the transform's results before they leave the CU.  Every thread puts its results Y[o],
+// o = q * 2^LA + K, back into its OWN row's cells (K, q) -- wave-local, so only the wavefront's own earlier gathers have to be
+// behind it -- and after one more s_barrier thread t computes X[k] for k = 512 s + kk, kk = (t - a) mod 512 (a = the output
+// row's offset into its 128-byte line: every wavefront then stores whole lines), from Y[k] = cell(k mod 2^LA, k >> LA),
+// Y[m - k] and W[k] (the post-pass table, read from global memory: a third of the transform's input volume, L2-resident).
+// Both cells are "per-thread base ^ constant of s" like every other access here: m - k = (2^LA - K) + 2^LA * (2^LB - 1 - q),
+// and q = 4 s + q0 complements bit by bit.  (K = 0 -- four threads -- pairs with 2^LB - q instead: address computed per s.)
+// WIN (EPI_RFFT with a row window): the thread's 32 window pairs are re-read (L2) at the end of every epilogue, into the registers
+// its post-pass table entries have just left, and consumed by the next transform's first lines (resident they are 64 registers
+// too many: 118 spilled; pass B1's table entries re-read instead: the same).
+template <typename T, int LA, int LB, int QB0, class IO, int EPI = EPI_STORE, bool WIN = false>
 __global__ __launch_bounds__((SplitWideGeom<LA, LB, QB0>::TPT), 2) void fft_split_wide_persist_kernel(const IO io, const cpx<T> *__restrict__ tw, const size_t batch)
 {
     using Gm = SplitWideGeom<LA, LB, QB0>;
@@ -177,10 +194,13 @@ __global__ __launch_bounds__((SplitWideGeom<LA, LB, QB0>::TPT), 2) void fft_spli
                         twd, (tauB << (LB - 1 - Gm::QB0 - t)) * (int)sizeof(cpx<T>),
                         (((g * Gm::TB) << (Gm::L - 1 - Gm::QB0 - t)) + (bitrev(h, t) << (Gm::L - 1 - t))) * (int)sizeof(cpx<T>));
     };
-    if (KOFFT_SPLITW_TWB_RESIDENT) load_twb();
-    typename IO::Inv inv[R];
+    constexpr bool TWB_RES = KOFFT_SPLITW_TWB_RESIDENT;
+    if (TWB_RES) load_twb();
+    typename IO::Inv inv[EPI == EPI_RFFT ? 1 : R];
+    if constexpr (EPI != EPI_RFFT) {
 #pragma unroll
-    for (int u = 0; u < R; ++u) inv[u] = io.invariant(u * Gm::TPT + tauA);
+        for (int u = 0; u < R; ++u) inv[u] = io.invariant(u * Gm::TPT + tauA);
+    }
     __syncthreads();  // tables complete
 
     const size_t step = gridDim.x;
@@ -188,6 +208,14 @@ __global__ __launch_bounds__((SplitWideGeom<LA, LB, QB0>::TPT), 2) void fft_spli
     if (base >= batch) return;
 
     Raw raw[R];
+    cpx<T> winv[WIN ? R : 1];
+    auto load_win = [&]() {
+        if constexpr (WIN) {
+            const rsrc_t wind = make_rsrc(io.window, (unsigned)Gm::N * (unsigned)sizeof(cpx<T>));  // N pairs of reals
+#pragma unroll
+            for (int u = 0; u < R; ++u) winv[u] = buf_load_cpx<T, AUX_DEFAULT>(wind, tauA * (int)sizeof(cpx<T>), u * Gm::TPT * (int)sizeof(cpx<T>));
+        }
+    };
     const int in_lane_bytes = tauA * IO::kRawBytes;
     const int out_lane_bytes = tauB * (int)sizeof(cpx<T>);
     typename persist_acc<IO>::type acc{};
@@ -201,6 +229,7 @@ __global__ __launch_bounds__((SplitWideGeom<LA, LB, QB0>::TPT), 2) void fft_spli
 #pragma unroll
         for (int c = 0; c < 4; ++c) loads(d0, c);
     }
+    load_win();
     for (;;) {
         const size_t nbase = base + step;
         const bool more = nbase < batch;  // workgroup-uniform
@@ -210,7 +239,14 @@ __global__ __launch_bounds__((SplitWideGeom<LA, LB, QB0>::TPT), 2) void fft_spli
         int cA = cA0, gA1 = gA10, cB = cB0, gB1 = gB10, tA = twA1_off, tB = twB0_off;
         asm volatile("" : "+v"(cA), "+v"(gA1), "+v"(cB), "+v"(gB1), "+v"(tA), "+v"(tB));
         cpx<T> cur[R];
-        if (io.inside(xf)) {
+        if constexpr (EPI == EPI_RFFT && !WIN) {
+            // no window: the reference multiplies by exactly 1, which leaves every value as it is (launch_split_wide_rfft checks)
+#pragma unroll
+            for (int u = 0; u < R; ++u) cur[u] = raw[u];
+        } else if constexpr (EPI == EPI_RFFT) {
+#pragma unroll
+            for (int u = 0; u < R; ++u) cur[u] = io.finish_in(raw[u], winv[u]);
+        } else if (io.inside(xf)) {
 #pragma unroll
             for (int u = 0; u < R; ++u) cur[u] = io.finish_in(raw[u], inv[u]);
         } else {
@@ -250,7 +286,7 @@ __global__ __launch_bounds__((SplitWideGeom<LA, LB, QB0>::TPT), 2) void fft_spli
 #pragma unroll
         for (int u = 0; u < R; ++u) Lds::st(cA ^ Gm::a1_out_reg(u), cur[u]);
         __syncthreads();  // the block-wide exchange
-        if (!KOFFT_SPLITW_TWB_RESIDENT) load_twb();
+        if (!TWB_RES) load_twb();
 #pragma unroll
         for (int u = 0; u < R; ++u) cur[u] = Lds::ld(cB ^ Gm::b0_in_reg(u));
         {
@@ -266,6 +302,53 @@ __global__ __launch_bounds__((SplitWideGeom<LA, LB, QB0>::TPT), 2) void fft_spli
         exchange_sync<true>();
 #pragma unroll
         for (int u = 0; u < R; ++u) cur[u] = Lds::ld(gB1 ^ Gm::b1_in_reg(u));
+        if constexpr (EPI == EPI_RFFT) {
+#pragma unroll
+            for (int g = 0; g < GB1; ++g) reg_pass_r<T, Gm::QB1>(cur + g * (1 << Gm::QB1), twb + g * EB1);
+            exchange_sync<true>();  // this wavefront's last gathers out of its rows are done
+#pragma unroll
+            for (int u = 0; u < R; ++u) Lds::st(cB ^ Gm::y_reg(u), cur[u]);
+            constexpr int NK = 1 << LA, QT = Gm::TPT >> LA;  // threads cover QT = 4 values of q per step
+            static_assert(QT >= 1 && (QT & (QT - 1)) == 0 && (Gm::TPT & (Gm::TPT - 1)) == 0, "epilogue geometry");
+            const int a = io.row_misalign(xf) & (128 / (int)sizeof(cpx<T>) - 1);
+            const int kk = (tid - a) & (Gm::TPT - 1);
+            // the post-pass table entries of all this thread's outputs, requested before the barrier (the registers of cur[]
+            // are free from here): in chunks between the computations every chunk waited an L2 round trip, 0.35 of the roofline
+            constexpr int STEPS = Gm::N / Gm::TPT;
+            const rsrc_t wd = make_rsrc(io.rtab, (unsigned)Gm::N * (unsigned)sizeof(cpx<T>));
+            const int lane_b = kk * (int)sizeof(cpx<T>);
+            cpx<T> wv[STEPS];
+            split_pin();
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) wv[s] = buf_load_cpx<T, AUX_DEFAULT>(wd, lane_b, s * Gm::TPT * (int)sizeof(cpx<T>));
+            split_pin();
+            __syncthreads();
+            const int Kk = kk & (NK - 1), q0 = kk >> LA;
+            int yk = Gm::cell_bytes(Kk, q0);
+            int ymk = Gm::cell_bytes((NK - Kk) & (NK - 1), QT - 1 - q0);
+            asm volatile("" : "+v"(yk), "+v"(ymk));
+            const bool krow0 = Kk == 0;
+            const rsrc_t xd = io.out_desc(xf);
+            {
+#pragma unroll
+                for (int s = 0; s < STEPS; ++s) {
+                    const cpx<T> ya = Lds::ld(yk ^ Gm::cell_bytes(0, s * QT));
+                    int maddr = ymk ^ Gm::cell_bytes(0, (STEPS - 1 - s) * QT);
+                    if (krow0) {  // K = 0: m - k = 2^LA * (2^LB - q); q = 0 is k = 0 (value unused)
+                        const int q2 = ((1 << LB) - (s * QT + q0)) & ((1 << LB) - 1);
+                        maddr = (q2 ^ Gm::gj(q2 >> 5)) * (int)sizeof(cpx<T>);
+                    }
+                    const cpx<T> yb = Lds::ld(maddr);
+                    cpx<T> x = io.post_w(wv[s], ya, yb);
+                    if (s == 0 && kk == 0) x = mk<T>(ya.re + ya.im, T(0));  // X[0] (rfft.rs:451)
+                    io.store_d(xd, lane_b, s * Gm::TPT, x, 0);
+                    if (s == 0 && kk == 0) io.store_d(xd, 0, Gm::N, mk<T>(ya.re - ya.im, T(0)), 0);  // X[m] (rfft.rs:452)
+                }
+            }
+            split_pin();
+            load_win();  // (also after the last transform: a conditional reload would keep the old values live across the iteration)
+            split_pin();
+        } else {
         const rsrc_t od = io.out_desc_n(xf, 1);
 #pragma unroll
         for (int g = 0; g < GB1; ++g) {  // results leave as each group completes
@@ -277,6 +360,7 @@ __global__ __launch_bounds__((SplitWideGeom<LA, LB, QB0>::TPT), 2) void fft_spli
                 else io.store_d(od, out_lane_bytes, Gm::out_reg(u), cur[u], 0);
             }
             split_pin();
+        }
         }
         if (!more) break;
         base = nbase;

@@ -56,6 +56,7 @@ struct kofft_hip_ctx {
     bool zero_copy = true;     // KOFFT_HIP_ZERO_COPY=0: small host calls through staged copies like large ones
     bool host_pipeline = true; // KOFFT_HIP_HOST_PIPELINE=0: host-pointer batches in one upload / kernel / download
     int host_chunks = 0;       // KOFFT_HIP_HOST_CHUNKS: pieces of a pipelined host batch (default 8)
+    bool rfft14_wide = true;    // KOFFT_HIP_RFFT14_WIDE=0: rfft of 32768 reals on the generic kernel
     bool rfft13_persist = true; // KOFFT_HIP_RFFT13_PERSIST=0: rfft / irfft n = 16384 on the generic kernel
     int persist64 = 1;         // KOFFT_HIP_PERSIST64=0: c64 n = 4096 / 8192 on the generic kernel (A/B measurements)
     bool persist_small = true; // KOFFT_HIP_PERSIST_SMALL=0: n = 128, 256 on the generic kernels (A/B measurements)
@@ -482,6 +483,28 @@ int launch_split_wide(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t
     return KOFFT_OK;
 }
 
+// rfft of 2^15 reals: the same kernel with the post-pass as its epilogue (two instances: with / without a row window)
+template <typename T, int LA, int LB, int QB0, class IO>
+int launch_split_wide_rfft(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t batch)
+{
+    using Gm = SplitWideGeom<LA, LB, QB0>;
+    constexpr size_t lds = split_wide_lds_bytes<Gm>();
+    const bool win = io.window != nullptr;
+    auto kern = win ? fft_split_wide_persist_kernel<T, LA, LB, QB0, IO, EPI_RFFT, true> : fft_split_wide_persist_kernel<T, LA, LB, QB0, IO, EPI_RFFT, false>;
+    {
+        static std::atomic<unsigned long long> attr_done[2] = {{0}, {0}};
+        const int arc = set_dyn_lds_once(ctx, attr_done[win ? 1 : 0], reinterpret_cast<const void *>(kern), lds);
+        if (arc) return arc;
+    }
+    size_t blocks = (size_t)ctx->num_cus * ((160 * 1024) / lds);
+    if (ctx->persist_grid_pct > 0) blocks = blocks * (size_t)ctx->persist_grid_pct / 100;
+    if (blocks < 1) blocks = 1;
+    if (blocks > batch) blocks = batch;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Gm::TPT), lds, ctx->stream, io, tw, batch);
+    KOFFT_HIP_TRY(ctx, hipGetLastError());
+    return KOFFT_OK;
+}
+
 template <typename T, int N, int EPI, class IO>
 int launch_small(kofft_hip_ctx *ctx, const IO &io, size_t batch, const cpx<T> *tw = nullptr)
 {
@@ -567,6 +590,8 @@ int dispatch(kofft_hip_ctx *ctx, const IO &io, size_t n, size_t batch)
             if (L == 13 && ctx->rfft13_persist && batch >= (size_t)ctx->num_cus * 4) return launch_persist<T, 13, EPI>(ctx, io, tw, batch);
         }
         if constexpr (EPI == EPI_RFFT) {
+            if (L == 14 && ctx->use_split && ctx->rfft14_wide && batch >= (size_t)ctx->num_cus * 4)
+                return launch_split_wide_rfft<T, 7, 7, 2>(ctx, io, tw, batch);
             if (L == 13 && ctx->rfft13_persist && batch >= (size_t)ctx->num_cus * 4) return launch_persist<T, 13, EPI>(ctx, io, tw, batch);
         }
         if constexpr (EPI == EPI_RFFT || (EPI == EPI_STORE && IO::kPersistMaxLog2 == 12)) {

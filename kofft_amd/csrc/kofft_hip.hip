@@ -489,6 +489,7 @@ int kofft_hip_create(int device, kofft_hip_ctx **out)
     if (const char *e = getenv("KOFFT_HIP_BIG_LAST_MODE")) ctx->big_last_mode = atoi(e);
     if (const char *e = getenv("KOFFT_HIP_BIG_PERSIST_MIN_UNITS")) ctx->big_persist_min_units = (size_t)atol(e);
     if (const char *e = getenv("KOFFT_HIP_BIG_ROWS_RESIDENT")) ctx->big_rows_resident = !(e[0] == '0');
+    if (const char *e = getenv("KOFFT_HIP_RFFT14_WIDE")) ctx->rfft14_wide = !(e[0] == '0');
     if (const char *e = getenv("KOFFT_HIP_RFFT13_PERSIST")) ctx->rfft13_persist = !(e[0] == '0');
     if (const char *e = getenv("KOFFT_HIP_PERSIST64")) ctx->persist64 = atoi(e);
     if (const char *e = getenv("KOFFT_HIP_PERSIST_SMALL")) ctx->persist_small = !(e[0] == '0');

@@ -1232,6 +1232,31 @@ def test_rfft_irfft_n16384_persistent_kernels(oracle, batch):
         assert bits_equal(f.irfft_batch(spec, 16384), want_inv), f"irfft KOFFT_HIP_RFFT13_PERSIST={persist} batch={batch}"
 
 
+@pytest.mark.parametrize("batch", [1024, 1100])
+def test_rfft_n32768_post_pass_inside_the_wave_split_kernel(oracle, batch):
+    """rfft of 32768 reals from num_cus * 4 rows up: fft_split_wide_persist_kernel with the post-pass (rfft.rs:450-463) as its
+    epilogue -- results back into the thread's own row cells, one more barrier, X[k] from Y[k], Y[m-k] (XOR-addressed; the K = 0
+    threads pair differently) and W[k], stores rotated onto whole lines (all 16 row alignments occur); with a row window the
+    window pairs are re-read per transform.  Against the oracle and the generic kernel (KOFFT_HIP_RFFT14_WIDE=0)."""
+    import os
+
+    import kofft_amd
+
+    rng = seeded(7900 + batch)
+    x = rng.uniform(-1, 1, (batch, 32768)).astype(np.float32)
+    want = oracle.rfft(x)
+    win = rng.uniform(0.1, 1, 32768).astype(np.float32)
+    want_w = oracle.rfft(x, win)
+    for wide in ("1", "0"):
+        os.environ["KOFFT_HIP_RFFT14_WIDE"] = wide
+        try:
+            f = kofft_amd.HipFftImpl(np.float32)
+        finally:
+            del os.environ["KOFFT_HIP_RFFT14_WIDE"]
+        assert bits_equal(f.rfft_batch(x), want), f"KOFFT_HIP_RFFT14_WIDE={wide} batch={batch}"
+        assert bits_equal(f.rfft_batch(x, win), want_w), f"windowed, KOFFT_HIP_RFFT14_WIDE={wide} batch={batch}"
+
+
 @pytest.mark.parametrize("win_len,frames", [(32, 300), (64, 3000), (256, 40000), (1024, 9000), (4096, 2100), (8192, 1100), (16384, 1030)])
 def test_stft_keeps_special_values(fft32, oracle, win_len, frames):
     """The reference multiplies every input (x * w, +0) by the first stage's T[0] = (1, 0) like any other entry, so an Inf or NaN

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised differential soak of the kernels that only run from ~1000 transforms up at n >= 4096 (the wave-split kernels at
-8192 / 16384, c64 4096 / 8192, rfft / irfft 16384) and of the group-wide rfft stores (n = 128 .. 512): random batch sizes around
+8192 / 16384, c64 4096 / 8192, rfft / irfft 16384, rfft 32768) and of the group-wide rfft stores (n = 128 .. 512): random batch sizes around
 and above the dispatch thresholds, random STFT hops with frames running past the end, against the oracle, bit for bit.
 usage (GPU box, repo root): python3 tools/soak_big.py [rounds=6] [seed=1]"""
 import sys
@@ -62,6 +62,10 @@ def main():
         check(bits_equal(f32.rfft_batch(x, win), oracle.rfft(x, win)), ("rfft", 16384, batch, win is not None))
         spec = rand_c(rng, (batch, 8193))
         check(bits_equal(f32.irfft_batch(spec, 16384), oracle.irfft(spec, 16384)), ("irfft", 16384, batch))
+        batch = int(rng.integers(1024, 1200))
+        x = rng.uniform(-1, 1, (batch, 32768)).astype(np.float32)
+        win = rng.uniform(0, 1, 32768).astype(np.float32) if rng.random() < 0.5 else None
+        check(bits_equal(f32.rfft_batch(x, win), oracle.rfft(x, win)), ("rfft", 32768, batch, win is not None))
         for n in (128, 256, 512):
             batch = int(rng.integers(256 * 2048 // n, 256 * 2048 // n + 3000))  # above the persistent kernel's threshold
             x = rng.uniform(-1, 1, (batch, n)).astype(np.float32)

@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--mb", type=int, default=512, help="input size per launch in MiB")
     ap.add_argument("--out", default="gpurun_out/sweep.json")
     ap.add_argument("--kinds", default="c32,c64,rfft32,stft")
+    ap.add_argument("--rfft-no-window", action="store_true", help="rfft32 without the Hann row window (default: with, like config 3)")
     ap.add_argument("--only-n", type=int, default=0, help="restrict every kind to this n")
     ap.add_argument("--max-n", type=int, default=0, help="skip sizes above this n")
     args = ap.parse_args()
@@ -110,7 +111,8 @@ def main():
                     src = torch.empty((batch, n), dtype=torch.float32, device=dev).uniform_(-1, 1)
                     dst = torch.empty((batch, n // 2 + 1, 2), dtype=torch.float32, device=dev)
                     win = torch.from_numpy(kofft_amd.hann(n)).to(dev)
-                    ms = timeit(stream, lambda: fft.rfft_dev(src.data_ptr(), dst.data_ptr(), win.data_ptr(), n, batch))
+                    wptr = None if args.rfft_no_window else win.data_ptr()
+                    ms = timeit(stream, lambda: fft.rfft_dev(src.data_ptr(), dst.data_ptr(), wptr, n, batch))
                     gbs = batch * (4 * n + 8 * (n // 2 + 1)) / ms / 1e6
                     rows.append(dict(kind=kind, n=n, batch=batch, ms=ms, gbs=gbs, frac=gbs / 8000))
                     print(f"{kind:7s} n={n:9d} batch={batch:9d} {ms:8.4f} ms {gbs:8.1f} GB/s frac {gbs/8000:.3f}", flush=True)
