@@ -116,6 +116,9 @@ constexpr size_t split_wide_lds_bytes()
 #ifndef KOFFT_SPLITW_LOADS
 #define KOFFT_SPLITW_LOADS 2
 #endif
+#ifndef KOFFT_SPLITW_PAIRED_TWB_RELOAD
+#define KOFFT_SPLITW_PAIRED_TWB_RELOAD 0
+#endif
 #ifndef KOFFT_SPLITW_TWB_RESIDENT
 #define KOFFT_SPLITW_TWB_RESIDENT 1
 #endif
@@ -131,6 +134,11 @@ constexpr size_t split_wide_lds_bytes()
 // WIN (EPI_RFFT with a row window): the thread's 32 window pairs are re-read (L2) at the end of every epilogue, into the registers
 // its post-pass table entries have just left, and consumed by the next transform's first lines (resident they are 64 registers
 // too many: 118 spilled; pass B1's table entries re-read instead: the same).
+// PAIRED input (IO = IrfftIO<float>, irfft of 2^15 reals): value k of the pre-pass (rfft.rs:487-506) needs input[k] and
+// input[m - k].  Every element is loaded ONCE (prefetched like any other input), the row goes through the -- at that moment
+// free -- exchange buffer in the (K, q) cells of the rfft epilogue, k = 2^LA q + K, and every thread reads its 32 partners back
+// (the same "base ^ constant" cells, bit-complemented q); the pre-pass table entries W[k] are requested at the top of the
+// transform into the registers the previous results have left.  Two more s_barriers per transform (four in all).
 template <typename T, int LA, int LB, int QB0, class IO, int EPI = EPI_STORE, bool WIN = false>
 __global__ __launch_bounds__((SplitWideGeom<LA, LB, QB0>::TPT), 2) void fft_split_wide_persist_kernel(const IO io, const cpx<T> *__restrict__ tw, const size_t batch)
 {
@@ -141,7 +149,9 @@ __global__ __launch_bounds__((SplitWideGeom<LA, LB, QB0>::TPT), 2) void fft_spli
     constexpr int TABLE_A = Gm::N * (int)sizeof(cpx<T>);                             // [k < 2^QA0][EA]
     constexpr int TABLE_B = TABLE_A + (1 << Gm::QA0) * EA * (int)sizeof(cpx<T>);     // [K < 2^LA][EB0]
     static_assert(sizeof(cpx<T>) == 8, "8-byte cells");
-    using Raw = typename IO::Raw;
+    constexpr bool PAIRED = io_pairs_in_wave<IO>::value;  // IrfftIO<float>
+    static_assert(!PAIRED || EPI == EPI_STORE, "paired input with the plain store epilogue");
+    using Raw = typename std::conditional<PAIRED, cpx<T>, typename IO::Raw>::type;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     if ((unsigned)(size_t)(__attribute__((address_space(3))) char *)smem_raw != 0u) __builtin_trap();  // SplitLds's addressing
     const int tid = threadIdx.x;
@@ -194,10 +204,10 @@ __global__ __launch_bounds__((SplitWideGeom<LA, LB, QB0>::TPT), 2) void fft_spli
                         twd, (tauB << (LB - 1 - Gm::QB0 - t)) * (int)sizeof(cpx<T>),
                         (((g * Gm::TB) << (Gm::L - 1 - Gm::QB0 - t)) + (bitrev(h, t) << (Gm::L - 1 - t))) * (int)sizeof(cpx<T>));
     };
-    constexpr bool TWB_RES = KOFFT_SPLITW_TWB_RESIDENT;
+    constexpr bool TWB_RES = KOFFT_SPLITW_TWB_RESIDENT && !(PAIRED && KOFFT_SPLITW_PAIRED_TWB_RELOAD);  // (paired input: re-reading them per transform measured 0.363 against 0.383 resident)
     if (TWB_RES) load_twb();
-    typename IO::Inv inv[EPI == EPI_RFFT ? 1 : R];
-    if constexpr (EPI != EPI_RFFT) {
+    typename IO::Inv inv[(EPI == EPI_RFFT || PAIRED) ? 1 : R];
+    if constexpr (EPI != EPI_RFFT && !PAIRED) {
 #pragma unroll
         for (int u = 0; u < R; ++u) inv[u] = io.invariant(u * Gm::TPT + tauA);
     }
@@ -216,13 +226,20 @@ __global__ __launch_bounds__((SplitWideGeom<LA, LB, QB0>::TPT), 2) void fft_spli
             for (int u = 0; u < R; ++u) winv[u] = buf_load_cpx<T, AUX_DEFAULT>(wind, tauA * (int)sizeof(cpx<T>), u * Gm::TPT * (int)sizeof(cpx<T>));
         }
     };
-    const int in_lane_bytes = tauA * IO::kRawBytes;
+    const int in_lane_bytes = tauA * (PAIRED ? (int)sizeof(cpx<T>) : (int)IO::kRawBytes);
     const int out_lane_bytes = tauB * (int)sizeof(cpx<T>);
     typename persist_acc<IO>::type acc{};
     if constexpr (io_has_acc<IO>::value) acc = io.acc_init();
+    Raw raw_m{};  // PAIRED: input[m], the partner of k = 0 (the same address in every lane)
+    auto fetch1 = [&](const rsrc_t d, const int u) -> Raw {
+        if constexpr (PAIRED) return buf_load_cpx<T, AUX_NT>(d, in_lane_bytes, u * Gm::TPT * (int)sizeof(cpx<T>));
+        else return io.fetch_d(d, in_lane_bytes, u * Gm::TPT, 0);
+    };
     auto loads = [&](const rsrc_t d, const int chunk) {  // 8 of the 32 loads
 #pragma unroll
-        for (int u = 8 * chunk; u < 8 * chunk + 8; ++u) raw[u] = io.fetch_d(d, in_lane_bytes, u * Gm::TPT, 0);
+        for (int u = 8 * chunk; u < 8 * chunk + 8; ++u) raw[u] = fetch1(d, u);
+        if constexpr (PAIRED)
+            if (chunk == 3) raw_m = buf_load_cpx<T, AUX_NT>(d, 0, Gm::N * (int)sizeof(cpx<T>));
     };
     {
         const rsrc_t d0 = io.in_desc_n(base, 1);
@@ -239,7 +256,36 @@ __global__ __launch_bounds__((SplitWideGeom<LA, LB, QB0>::TPT), 2) void fft_spli
         int cA = cA0, gA1 = gA10, cB = cB0, gB1 = gB10, tA = twA1_off, tB = twB0_off;
         asm volatile("" : "+v"(cA), "+v"(gA1), "+v"(cB), "+v"(gB1), "+v"(tA), "+v"(tB));
         cpx<T> cur[R];
-        if constexpr (EPI == EPI_RFFT && !WIN) {
+        if constexpr (PAIRED) {
+            constexpr int NK = 1 << LA, QT = Gm::TPT >> LA, STEPS = Gm::N / Gm::TPT;
+            static_assert(STEPS == R, "one staged element per register");
+            const rsrc_t wd = make_rsrc(io.rtab, (unsigned)Gm::N * (unsigned)sizeof(cpx<T>));
+            cpx<T> wv[R];
+            split_pin();
+#pragma unroll
+            for (int u = 0; u < R; ++u) wv[u] = buf_load_cpx<T, AUX_DEFAULT>(wd, in_lane_bytes, u * Gm::TPT * (int)sizeof(cpx<T>));
+            split_pin();
+            // element k = u * TPT + tauA = 2^LA * (QT u + ja) + col: cell (col, QT u + ja); partner m - k: (2^LA - col, complement)
+            int stg = Gm::cell_bytes(col, ja);
+            int pstg = Gm::cell_bytes((NK - col) & (NK - 1), QT - 1 - ja);
+            asm volatile("" : "+v"(stg), "+v"(pstg));
+            __syncthreads();  // every wavefront has read the previous transform out of the buffer
+#pragma unroll
+            for (int u = 0; u < R; ++u) Lds::st(stg ^ Gm::cell_bytes(0, u * QT), raw[u]);
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                if (u % 8 == 0) split_pin();  // eight partners in flight at a time (all 32 hoisted: 64 more registers, 19 spilled)
+                int paddr = pstg ^ Gm::cell_bytes(0, (R - 1 - u) * QT);
+                if (col == 0) {  // K = 0: m - k = 2^LA * (2^LB - q); q = 0 is k = 0, whose partner is input[m]
+                    const int q2 = ((1 << LB) - (u * QT + ja)) & ((1 << LB) - 1);
+                    paddr = (q2 ^ Gm::gj(q2 >> 5)) * (int)sizeof(cpx<T>);
+                }
+                cpx<T> pb = Lds::ld(paddr);
+                if (u == 0 && tauA == 0) pb = raw_m;
+                cur[u] = io.pre((u == 0 && tauA == 0) ? 0 : 1, raw[u], pb, wv[u]);
+            }
+        } else if constexpr (EPI == EPI_RFFT && !WIN) {
             // no window: the reference multiplies by exactly 1, which leaves every value as it is (launch_split_wide_rfft checks)
 #pragma unroll
             for (int u = 0; u < R; ++u) cur[u] = raw[u];
@@ -258,7 +304,9 @@ __global__ __launch_bounds__((SplitWideGeom<LA, LB, QB0>::TPT), 2) void fft_spli
         auto loads4 = [&](const int c4) {  // KOFFT_SPLITW_LOADS == 3: eight slots of four
             split_pin();
 #pragma unroll
-            for (int u = 4 * c4; u < 4 * c4 + 4; ++u) raw[u] = io.fetch_d(nd, in_lane_bytes, u * Gm::TPT, 0);
+            for (int u = 4 * c4; u < 4 * c4 + 4; ++u) raw[u] = fetch1(nd, u);
+            if constexpr (PAIRED)
+                if (c4 == 7) raw_m = buf_load_cpx<T, AUX_NT>(nd, 0, Gm::N * (int)sizeof(cpx<T>));
             split_pin();
         };
         if (KOFFT_SPLITW_LOADS == 3) {

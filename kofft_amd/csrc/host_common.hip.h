@@ -56,7 +56,7 @@ struct kofft_hip_ctx {
     bool zero_copy = true;     // KOFFT_HIP_ZERO_COPY=0: small host calls through staged copies like large ones
     bool host_pipeline = true; // KOFFT_HIP_HOST_PIPELINE=0: host-pointer batches in one upload / kernel / download
     int host_chunks = 0;       // KOFFT_HIP_HOST_CHUNKS: pieces of a pipelined host batch (default 8)
-    bool rfft14_wide = true;    // KOFFT_HIP_RFFT14_WIDE=0: rfft of 32768 reals on the generic kernel
+    bool rfft14_wide = true;    // KOFFT_HIP_RFFT14_WIDE=0: rfft / irfft of 32768 reals on the generic kernel
     bool rfft13_persist = true; // KOFFT_HIP_RFFT13_PERSIST=0: rfft / irfft n = 16384 on the generic kernel
     int persist64 = 1;         // KOFFT_HIP_PERSIST64=0: c64 n = 4096 / 8192 on the generic kernel (A/B measurements)
     bool persist_small = true; // KOFFT_HIP_PERSIST_SMALL=0: n = 128, 256 on the generic kernels (A/B measurements)
@@ -587,6 +587,7 @@ int dispatch(kofft_hip_ctx *ctx, const IO &io, size_t n, size_t batch)
             if (L == 12 && batch >= (size_t)ctx->num_cus * 4) return launch_persist<T, 12, EPI>(ctx, io, tw, batch);
         }
         if constexpr (EPI == EPI_STORE && io_pairs_in_wave<IO>::value) {
+            if (L == 14 && ctx->use_split && ctx->rfft14_wide && batch >= (size_t)ctx->num_cus * 4) return launch_split_wide<T, 7, 7, 2>(ctx, io, tw, batch);
             if (L == 13 && ctx->rfft13_persist && batch >= (size_t)ctx->num_cus * 4) return launch_persist<T, 13, EPI>(ctx, io, tw, batch);
         }
         if constexpr (EPI == EPI_RFFT) {

@@ -1233,11 +1233,13 @@ def test_rfft_irfft_n16384_persistent_kernels(oracle, batch):
 
 
 @pytest.mark.parametrize("batch", [1024, 1100])
-def test_rfft_n32768_post_pass_inside_the_wave_split_kernel(oracle, batch):
+def test_rfft_irfft_n32768_inside_the_wave_split_kernel(oracle, batch):
     """rfft of 32768 reals from num_cus * 4 rows up: fft_split_wide_persist_kernel with the post-pass (rfft.rs:450-463) as its
     epilogue -- results back into the thread's own row cells, one more barrier, X[k] from Y[k], Y[m-k] (XOR-addressed; the K = 0
     threads pair differently) and W[k], stores rotated onto whole lines (all 16 row alignments occur); with a row window the
-    window pairs are re-read per transform.  Against the oracle and the generic kernel (KOFFT_HIP_RFFT14_WIDE=0)."""
+    window pairs are re-read per transform.  irfft of 32768 reals on the same kernel: the input row staged through the exchange
+    buffer so that every thread reads its partners input[m-k] back (pre-pass, rfft.rs:487-506).  Against the oracle and the
+    generic kernels (KOFFT_HIP_RFFT14_WIDE=0)."""
     import os
 
     import kofft_amd
@@ -1247,6 +1249,8 @@ def test_rfft_n32768_post_pass_inside_the_wave_split_kernel(oracle, batch):
     want = oracle.rfft(x)
     win = rng.uniform(0.1, 1, 32768).astype(np.float32)
     want_w = oracle.rfft(x, win)
+    spec = rand_c(rng, (batch, 16385))
+    want_inv = oracle.irfft(spec, 32768)
     for wide in ("1", "0"):
         os.environ["KOFFT_HIP_RFFT14_WIDE"] = wide
         try:
@@ -1255,6 +1259,7 @@ def test_rfft_n32768_post_pass_inside_the_wave_split_kernel(oracle, batch):
             del os.environ["KOFFT_HIP_RFFT14_WIDE"]
         assert bits_equal(f.rfft_batch(x), want), f"KOFFT_HIP_RFFT14_WIDE={wide} batch={batch}"
         assert bits_equal(f.rfft_batch(x, win), want_w), f"windowed, KOFFT_HIP_RFFT14_WIDE={wide} batch={batch}"
+        assert bits_equal(f.irfft_batch(spec, 32768), want_inv), f"irfft, KOFFT_HIP_RFFT14_WIDE={wide} batch={batch}"
 
 
 @pytest.mark.parametrize("win_len,frames", [(32, 300), (64, 3000), (256, 40000), (1024, 9000), (4096, 2100), (8192, 1100), (16384, 1030)])

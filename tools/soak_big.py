@@ -66,6 +66,8 @@ def main():
         x = rng.uniform(-1, 1, (batch, 32768)).astype(np.float32)
         win = rng.uniform(0, 1, 32768).astype(np.float32) if rng.random() < 0.5 else None
         check(bits_equal(f32.rfft_batch(x, win), oracle.rfft(x, win)), ("rfft", 32768, batch, win is not None))
+        spec = rand_c(rng, (batch, 16385))
+        check(bits_equal(f32.irfft_batch(spec, 32768), oracle.irfft(spec, 32768)), ("irfft", 32768, batch))
         for n in (128, 256, 512):
             batch = int(rng.integers(256 * 2048 // n, 256 * 2048 // n + 3000))  # above the persistent kernel's threshold
             x = rng.uniform(-1, 1, (batch, n)).astype(np.float32)
