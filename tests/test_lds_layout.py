@@ -175,3 +175,36 @@ def test_wide_wave_split_decomposition_and_swizzle(la, lb, qb0, F, G):
         k1, j1 = rnd.randrange(1 << la), rnd.randrange(1 << lb)
         mk, mj = rnd.randrange(1 << la), rnd.randrange(1 << lb)
         assert sm.cell_of(g, F, k1, j1, G) == sm.cell_of(g, F, k1 & mk, j1 & mj, G) ^ sm.cell_of(g, F, k1 & ~mk, j1 & ~mj, G)
+
+
+def test_wide_kernel_pairing_cells_are_base_xor_constant():
+    """fft_split_wide.hip.h, rfft epilogue / irfft pre-pass (n = 32768 reals): element k = 2^LA q + K of a row lives in cell (K, q);
+    thread kk handles k = 512 s + kk, i.e. K = kk mod 128, q = 4 s + q0.  Claimed: cell(k) = cell(K, q0) ^ cell(0, 4 s), and for
+    K != 0 the partner m - k sits in cell(128 - K, 3 - q0) ^ cell(0, 4 (31 - s)) (q complements bit by bit); K = 0 pairs with
+    q' = 128 - q instead (computed per step in the kernel)."""
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tools"))
+    import split_model as sm
+
+    la = lb = 7
+    F, G = [2, 9, 24, 5, 1, 4, 26], [30, 7]
+    g = sm.Geom(la, lb, rlog=5, qa0=5, qb0=2)
+    m = g.N
+
+    def cell(K, j):
+        return sm.cell_of(g, F, K, j, G)
+
+    def cell_of_k(k):
+        return cell(k & 127, k >> 7)
+
+    for kk in range(512):
+        K, q0 = kk & 127, kk >> 7
+        for s in range(32):
+            k = 512 * s + kk
+            assert cell_of_k(k) == cell(K, q0) ^ cell(0, 4 * s)
+            if K:
+                assert cell_of_k(m - k) == cell(128 - K, 3 - q0) ^ cell(0, 4 * (31 - s))
+            elif k:
+                assert cell_of_k(m - k) == cell(0, 128 - (4 * s + q0))
