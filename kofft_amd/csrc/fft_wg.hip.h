@@ -61,9 +61,16 @@ struct PlainTw {
 #ifndef KOFFT_STFT_SMALL_BLOCK32
 #define KOFFT_STFT_SMALL_BLOCK32 64
 #endif
+#ifndef KOFFT_SMALL_BLOCK
+#define KOFFT_SMALL_BLOCK 256
+#endif
+#ifndef KOFFT_C64_SMALL_BLOCK
+#define KOFFT_C64_SMALL_BLOCK 64
+#endif
 // FftImpl::fft (fft.rs:1054) / ifft (fft.rs:1134-1174: conj, fft, conj, *scale).
 template <typename T, bool INVERSE>
 struct ComplexIO : PlainTw {
+    static constexpr int kSmallBlock16 = sizeof(T) == 8 ? KOFFT_C64_SMALL_BLOCK : KOFFT_SMALL_BLOCK;  // fft_small_kernel, n = 16
     static constexpr bool kSplitOk = true;  // fft_split.hip.h
     static constexpr bool kStreams = true;  // descriptor loads in the generic kernels
     static constexpr bool kPersist = true;  // eligible for the persistent prefetching kernel
@@ -954,8 +961,13 @@ template <class IO, class = void>
 struct io_small_block32 { static constexpr int value = KOFFT_SMALL_BLOCK32; };
 template <class IO>
 struct io_small_block32<IO, decltype((void)IO::kSmallBlock32)> { static constexpr int value = IO::kSmallBlock32; };
+// (and for n = 16: kSmallBlock16 -- c64 runs 64: 0.72 -> 0.745 on two boxes; n = 2 .. 8 at 64: -4 .. +3 %, left)
+template <class IO, class = void>
+struct io_small_block16 { static constexpr int value = KOFFT_SMALL_BLOCK; };
+template <class IO>
+struct io_small_block16<IO, decltype((void)IO::kSmallBlock16)> { static constexpr int value = IO::kSmallBlock16; };
 template <int N, class IO>
-constexpr int small_block_threads() { return N == 32 ? io_small_block32<IO>::value : KOFFT_SMALL_BLOCK; }
+constexpr int small_block_threads() { return N == 32 ? io_small_block32<IO>::value : N == 16 ? io_small_block16<IO>::value : KOFFT_SMALL_BLOCK; }
 template <typename T, int N, class IO>
 constexpr size_t small_lds_bytes() { return N == 1 ? 0 : (size_t)small_block_threads<N, IO>() * (N + 1) * sizeof(cpx<T>); }
 
