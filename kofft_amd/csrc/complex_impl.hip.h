@@ -12,6 +12,10 @@ namespace host {
 // large n: two factors (fft_big.hip.h)
 // ---------------------------------------------------------------------------------
 
+#ifndef KOFFT_ROWS_C32_CAP_KB
+#define KOFFT_ROWS_C32_CAP_KB 80
+#endif
+
 // The persistent, prefetching form of a factor (fft_tile_persist_kernel): 512 threads per CU (one or several workgroups),
 // so that every thread may use 256 registers -- two register sets and a pass's twiddles, no scratch.
 template <typename T, int LS, class IO>
@@ -60,9 +64,6 @@ int launch_rows_persist(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size
     constexpr int RL = rl_for(LS);
     // (c32 rows of 2^10 points: 16-row tiles need 1024 threads at 128 registers and spill 30 of them -- measured slower
     // than 8-row tiles at 512 threads, 2^19: 0.244 vs 0.282 of the roofline)
-#ifndef KOFFT_ROWS_C32_CAP_KB
-#define KOFFT_ROWS_C32_CAP_KB 80
-#endif
     constexpr int BLOCK = big_block<T, IO, LS, (sizeof(T) == 4 ? KOFFT_ROWS_C32_CAP_KB : 128) * 1024>();
     constexpr int TPT = (1 << LS) >> RL;
     constexpr int XPB = BLOCK / TPT;
@@ -194,6 +195,38 @@ int launch_mid(kofft_hip_ctx *ctx, const BigMidIO<T> &io, const cpx<T> *tw, int 
 template <typename T>
 inline int big_rows_per_wg(int LB) { return LB <= 9 ? KOFFT_BIG_XPB(T) : LB == 10 ? 8 : LB == 11 ? 4 : LB == 12 ? 2 : 1; }
 
+// units (columns / rows) per tile of the two persistent factor kernels, as launch_tile_persist / launch_rows_persist compute them
+struct NoIO {};
+template <typename T>
+inline int tile_persist_xpb(int LS)
+{
+    switch (LS) {
+#define KOFFT_CASE(LL) \
+    case LL: return big_block<T, NoIO, LL, 128 * 1024>() / ((1 << LL) >> rl_for(LL));
+        KOFFT_CASE(7)
+        KOFFT_CASE(8)
+        KOFFT_CASE(9)
+        KOFFT_CASE(10)
+        KOFFT_CASE(11)
+#undef KOFFT_CASE
+    default: return 0;
+    }
+}
+template <typename T>
+inline int rows_persist_xpb(int LS)
+{
+    switch (LS) {
+#define KOFFT_CASE(LL) \
+    case LL: return big_block<T, NoIO, LL, (sizeof(T) == 4 ? KOFFT_ROWS_C32_CAP_KB : 128) * 1024>() / ((1 << LL) >> rl_for(LL));
+        KOFFT_CASE(7)
+        KOFFT_CASE(8)
+        KOFFT_CASE(9)
+        KOFFT_CASE(10)
+#undef KOFFT_CASE
+    default: return 0;
+    }
+}
+
 // The factor path with the policies of its first and last factor as parameters (round 3): ColsIO / RowsIO are BigColsIO /
 // BigRowsIO instances, possibly with a folded pointwise factor (PRE / POST) whose extra fields fix_cols / fix_rows fill in;
 // such policies may read input rows of in_row values and write output rows of out_row values (the transform itself is n).
@@ -227,13 +260,21 @@ int fft_big_core(kofft_hip_ctx *ctx, const cpx<T> *in_base, size_t in_row, cpx<T
     if (chunk > batch) chunk = batch;
     const size_t need = chunk * xf_bytes * (three ? 2 : 1);
     if (ctx->big_tmp_bytes < need) {
+        if (ctx->big_tmp_external) return KOFFT_ERR_ALLOC;
         if (ctx->big_tmp) KOFFT_HIP_TRY(ctx, hipFree(ctx->big_tmp));
         ctx->big_tmp = nullptr;
         ctx->big_tmp_bytes = 0;
+        // (Round 4, tools/exp_c64_alloc.py: a physically contiguous buffer -- hipExtMallocWithFlags(hipDeviceMallocContiguous) -- made
+        // the last factor's reads fast on one box (188-192 us per 512 MiB chunk on 16 of 16 buffers against 217-231 us on most plain
+        // ones) but not on the next (4 of 5 slow), slowed the first factor's writes by 10 % on both, and small contiguous buffers
+        // returned stale data to the plain loads of the narrow-tile kernels: not used.)
         KOFFT_HIP_TRY(ctx, hipMalloc(&ctx->big_tmp, need));
         ctx->big_tmp_bytes = need;
     }
     cpx<T> *mid = static_cast<cpx<T> *>(ctx->big_tmp);
+#ifdef KOFFT_EXP_TMP_PRINT
+    fprintf(stderr, "kofft big_tmp %p mid %p\n", ctx->big_tmp, (void *)mid);
+#endif
     cpx<T> *mid2 = mid + chunk * n;
     const T scale = (T)1 / (T)(float)n;
     for (size_t b0 = 0; b0 < batch; b0 += chunk) {
@@ -243,7 +284,20 @@ int fft_big_core(kofft_hip_ctx *ctx, const cpx<T> *in_base, size_t in_row, cpx<T
         // first factor: stages 0 .. L1-1 down the columns of a 2^L1 x 2^(L-L1) matrix
         ColsIO a{src, mid, L - L1, L - L1, n};
         fix_cols(a);
-        rc = launch_sub<T>(ctx, a, tw, L1, nb << (L - L1), ctx->big_first_persist >= 0 ? ctx->big_first_persist != 0 : ctx->big_persist);
+        const bool first_persist = ctx->big_first_persist >= 0 ? ctx->big_first_persist != 0 : ctx->big_persist;
+        const int last_mode = ctx->big_last_mode >= 0 ? ctx->big_last_mode : (!ctx->big_persist ? 0 : (ctx->big_rows_resident ? 2 : 1));
+        const size_t persist_units = (size_t)ctx->num_cus * ctx->big_persist_min_units;
+        // Both factors on their persistent kernels (the conditions of launch_sub and of the rows branch below): the intermediate
+        // is then block-interleaved -- see BigColsIO::out_lane.
+        const bool rows_resident = last_mode == 2 && (nb << (L - L3)) >= persist_units && L3 >= 7 && L3 <= 10;
+        // c64 only (same box, tools/sweep.py, 512 MiB per launch): c64 2^14 .. 2^20 0.338-0.353 -> 0.349-0.395, config 5 12.01 -> 11.91 ms on
+        // a box in the last factor's fast mode, its slow mode 222-231 -> 206 us per chunk; c32 2^18 .. 2^20 LOSES 4-6 % (0.324 / 0.315 /
+        // 0.284 -> 0.305 / 0.295 / 0.269; with streaming loads of the 512-byte runs 0.27) and keeps the natural layout.
+        if (sizeof(T) == 8 && ctx->big_blocked && !three && first_persist && (nb << (L - L1)) >= persist_units && L1 >= 7 && L1 <= 10 && rows_resident) {
+            a.blk_c = ilog2((size_t)tile_persist_xpb<T>(L1));
+            a.blk_r = ilog2((size_t)rows_persist_xpb<T>(L3));
+        }
+        rc = launch_sub<T>(ctx, a, tw, L1, nb << (L - L1), first_persist);
         if (rc) return rc;
         const cpx<T> *last_in = mid;
         if (three) {
@@ -256,6 +310,8 @@ int fft_big_core(kofft_hip_ctx *ctx, const cpx<T> *in_base, size_t in_row, cpx<T
         const int LP = L - L3;
         RowsIO b{last_in, dst, LP, L3, L - L3, L - 1 - LP, n, scale, big_rows_per_wg<T>(L3) * sizeof(cpx<T>) >= 64};
         fix_rows(b);
+        b.blk_r = a.blk_r;
+        b.blk_c = a.blk_c;
         // an intermediate small enough to stay in the 256 MiB Infinity Cache is read with plain loads (measured on a
         // copy model, tools/ubench_mall: streaming hints on the caller's buffers only, 3.1 -> 2.5 ms per 2 x 4 GiB)
         // ... and only where a wavefront's load instruction covers at least half a line per row: with 16-row c32 tiles (rows up
@@ -267,8 +323,7 @@ int fft_big_core(kofft_hip_ctx *ctx, const cpx<T> *in_base, size_t in_row, cpx<T
         rc = KOFFT_ERR_UNSUPPORTED;
         // last factor: 2 = rows resident (table entries per row tile in LDS), 1 = the generic persistent tile kernel, 0 = one tile
         // per workgroup (two 512-thread workgroups per CU at 128 registers); KOFFT_HIP_BIG_LAST_MODE for A/B measurements
-        const int last_mode = ctx->big_last_mode >= 0 ? ctx->big_last_mode : (!ctx->big_persist ? 0 : (ctx->big_rows_resident ? 2 : 1));
-        if (last_mode == 2 && (nb << LP) >= (size_t)ctx->num_cus * ctx->big_persist_min_units) {
+        if (rows_resident) {
             switch (L3) {
             case 7: rc = launch_rows_persist<T, 7>(ctx, b, tw, nb); break;
             case 8: rc = launch_rows_persist<T, 8>(ctx, b, tw, nb); break;
@@ -277,7 +332,10 @@ int fft_big_core(kofft_hip_ctx *ctx, const cpx<T> *in_base, size_t in_row, cpx<T
             default: break;
             }
         }
-        if (rc == KOFFT_ERR_UNSUPPORTED) rc = launch_sub<T>(ctx, b, tw, L3, nb << LP, last_mode >= 1);
+        if (rc == KOFFT_ERR_UNSUPPORTED) {
+            if (b.blk_r != 0) return KOFFT_ERR_UNSUPPORTED;  // (never: the blocked layout is only chosen where the rows kernel runs)
+            rc = launch_sub<T>(ctx, b, tw, L3, nb << LP, last_mode >= 1);
+        }
         if (rc) return rc;
     }
     return KOFFT_OK;

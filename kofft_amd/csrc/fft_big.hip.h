@@ -88,6 +88,20 @@ struct BigColsIO {
     __device__ __forceinline__ int in_sl() const { return LB; }
     __device__ __forceinline__ unsigned out_off(size_t xf) const { return in_off(xf); }
     __device__ __forceinline__ int out_sl() const { return LB; }
+    // Block-interleaved intermediate (round 4; fft_tile_persist_kernel + fft_rows_persist_kernel only): element (q, j) of the
+    // 2^LA x 2^LB matrix lives at  [q >> br][j >> bc][q & (2^br - 1)][j & (2^bc - 1)], br = log2(rows of a last-factor tile),
+    // bc = log2(columns of a first-factor tile).  A wavefront's store then covers ONE contiguous run of 2^(br+bc) values
+    // (1 KiB for 8 x 8 c64) instead of 2^br runs of 2^bc values a row apart, and the last factor reads its row tile as one
+    // contiguous 2^(LB+br)-value stream.  br = 0 is the natural layout.  The store's thread part, in elements (the register part
+    // out_index(0, u) << LB is the same in both layouts: its low br bits are zero).
+    int blk_r = 0, blk_c = 0;
+    static constexpr bool kBlockedOut = true;
+    __device__ __forceinline__ unsigned out_lane(size_t xf, int tau) const
+    {
+        const unsigned j = in_off(xf);
+        return (((unsigned)tau >> blk_r) << (LB + blk_r)) + ((j >> blk_c) << (blk_r + blk_c)) + (((unsigned)tau & ((1u << blk_r) - 1)) << blk_c) +
+               (j & ((1u << blk_c) - 1));
+    }
     __device__ __forceinline__ cpx<T> load(size_t xf, int c) const
     {
         const size_t b = xf >> LB, j = xf & ((size_t(1) << LB) - 1);
@@ -168,6 +182,14 @@ struct BigRowsIO {
     __device__ __forceinline__ int in_sl() const { return 0; }
     __device__ __forceinline__ unsigned out_off(size_t xf) const { return (unsigned)(xf & ((size_t(1) << LA) - 1)); }
     __device__ __forceinline__ int out_sl() const { return LA; }
+    // the block-interleaved intermediate of BigColsIO (blk_r = 0: natural): thread part of the load of row K, elements tau + U
+    // (U = in_index(0, u), a multiple of 2^blk_c: its part of the address is U << blk_r)
+    int blk_r = 0, blk_c = 0;
+    __device__ __forceinline__ unsigned in_lane(unsigned K, int tau) const
+    {
+        return ((K >> blk_r) << (LB + blk_r)) + (((unsigned)tau >> blk_c) << (blk_r + blk_c)) + ((K & ((1u << blk_r) - 1)) << blk_c) +
+               ((unsigned)tau & ((1u << blk_c) - 1));
+    }
     __device__ __forceinline__ cpx<T> load(size_t xf, int c) const
     {
         const size_t b = xf >> LA, K = xf & ((size_t(1) << LA) - 1);
@@ -359,6 +381,10 @@ template <class IO>
 struct io_post<IO, decltype((void)IO::kPost)> { static constexpr int value = IO::kPost; };
 
 template <class IO, class = void>
+struct io_blocked_out { static constexpr bool value = false; };
+template <class IO>
+struct io_blocked_out<IO, decltype((void)IO::kBlockedOut)> { static constexpr bool value = IO::kBlockedOut; };
+template <class IO, class = void>
 struct io_tile_group_tw { static constexpr bool value = false; };
 template <class IO>
 struct io_tile_group_tw<IO, decltype((void)IO::kTileGroupTw)> { static constexpr bool value = IO::kTileGroupTw; };
@@ -496,7 +522,13 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 1024 ? 4 : 2)) void fft_tile_persi
         if constexpr (NP > 4) { TileExchange<T, L, RL, XPB, SPLIT>::template run<3>(cur, smem_raw, tau, slot); compute(std::integral_constant<int, 4>{}, cur, xf); }
         const size_t xf0 = t * XPB;
         const rsrc_t d = make_rsrc(io.out + io.xf_transform(xf0) * out_row, out_bytes);
-        const int lane = (int)((io.out_off(xf) + ((unsigned)tau << out_sl)) * (unsigned)ES);
+        int lane;
+        if constexpr (io_blocked_out<IO>::value) {
+            static_assert(TPT >= 16, "the block's row bits are thread bits of the last pass's output index");
+            lane = (int)(io.out_lane(xf, tau) * (unsigned)ES);
+        } else {
+            lane = (int)((io.out_off(xf) + ((unsigned)tau << out_sl)) * (unsigned)ES);
+        }
         const T scale = io.out_scale();
         // 16-byte stores: the register offset goes into the VGPR offset, NOT into the SGPR offset field.  hipcc pads the
         // "store of more than 8 bytes, then a VALU write to its data registers" hazard only when the instruction has no
@@ -654,13 +686,15 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 1024 ? 4 : 2)) void fft_rows_persi
         // (walking the transforms last to first, so that the most recently written part of the intermediate is read first,
         // measured no gain from the Infinity Cache: 12.4 vs 12.1 ms on config 5)
         const rsrc_t d = make_rsrc(io.in + (size_t)(valid ? tb : 0) * io.n, valid ? xf_bytes : 0u);
-        const int lane = (int)(((((valid ? tkt : 0) * XPB + slot) << io.LB) + (unsigned)tau) * (unsigned)ES);
+        static_assert(G0::JB >= 4, "the block's column bits are thread bits of the first pass's input index");
+        const int lane = (int)(io.in_lane((valid ? tkt : 0) * XPB + slot, tau) * (unsigned)ES);
+        const int bsh = io.blk_r;  // register part: in_index(0, u) << blk_r elements (wave-uniform)
         if (io.nt_in()) {
 #pragma unroll
-            for (int u = 0; u < R; ++u) dst[u] = buf_load_cpx<T, AUX_NT>(d, lane, G0::in_index(0, u) * ES);
+            for (int u = 0; u < R; ++u) dst[u] = buf_load_cpx<T, AUX_NT>(d, lane, (G0::in_index(0, u) << bsh) * ES);
         } else {
 #pragma unroll
-            for (int u = 0; u < R; ++u) dst[u] = buf_load_cpx<T, AUX_DEFAULT>(d, lane, G0::in_index(0, u) * ES);
+            for (int u = 0; u < R; ++u) dst[u] = buf_load_cpx<T, AUX_DEFAULT>(d, lane, (G0::in_index(0, u) << bsh) * ES);
         }
     };
 

@@ -508,6 +508,7 @@ int kofft_hip_create(int device, kofft_hip_ctx **out)
     if (const char *e = getenv("KOFFT_HIP_BIG_NARROW_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 16) ctx->big_narrow_per_cu = v; }
     if (const char *e = getenv("KOFFT_HIP_ND_TRANSPOSE_MIN")) ctx->nd_transpose_min = atoi(e);
     if (const char *e = getenv("KOFFT_HIP_HOST_CHUNKS")) ctx->host_chunks = atoi(e);
+    if (const char *e = getenv("KOFFT_HIP_BIG_BLOCKED")) ctx->big_blocked = !(e[0] == '0');
     if (const char *e = getenv("KOFFT_HIP_BIG_CHUNK_MB")) {
         const long mb = atol(e);
         if (mb > 0) ctx->big_chunk_bytes = (size_t)mb << 20;
@@ -534,7 +535,7 @@ int kofft_hip_destroy(kofft_hip_ctx *ctx)
     for (auto &kv : ctx->tables) (void)hipFree(kv.second);
     for (int i = 0; i < 3; ++i)
         if (ctx->stage[i]) (void)hipFree(ctx->stage[i]);
-    if (ctx->big_tmp) (void)hipFree(ctx->big_tmp);
+    if (ctx->big_tmp && !ctx->big_tmp_external) (void)hipFree(ctx->big_tmp);
     if (ctx->blue_tmp) (void)hipFree(ctx->blue_tmp);
     if (ctx->real_tmp) (void)hipFree(ctx->real_tmp);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -566,6 +567,23 @@ int kofft_hip_synchronize(kofft_hip_ctx *ctx)
     return KOFFT_OK;
 }
 
+#ifdef KOFFT_EXP_API /* measurement builds only (tools/build_variant.sh): the experiment script supplies the large-n intermediate */
+int kofft_hip_exp_set_big_tmp(kofft_hip_ctx *ctx, void *d_ptr, size_t bytes)
+{
+    if (!ctx) return KOFFT_ERR_NULL;
+    if (ctx->big_tmp && !ctx->big_tmp_external) (void)hipFree(ctx->big_tmp);
+    ctx->big_tmp = d_ptr;
+    ctx->big_tmp_bytes = bytes;
+    ctx->big_tmp_external = d_ptr != nullptr;
+    return KOFFT_OK;
+}
+int kofft_hip_exp_malloc(size_t bytes, unsigned flags, void **out)
+{
+    return hipExtMallocWithFlags(out, bytes, flags) == hipSuccess ? KOFFT_OK : KOFFT_ERR_ALLOC;
+}
+int kofft_hip_exp_free(void *p) { return hipFree(p) == hipSuccess ? KOFFT_OK : KOFFT_ERR_HIP; }
+#endif
+
 int kofft_hip_release_scratch(kofft_hip_ctx *ctx)
 {
     if (!ctx) return KOFFT_ERR_NULL;
@@ -579,7 +597,7 @@ int kofft_hip_release_scratch(kofft_hip_ctx *ctx)
     void **bufs[] = {&ctx->big_tmp, &ctx->blue_tmp, &ctx->real_tmp};
     size_t *sizes[] = {&ctx->big_tmp_bytes, &ctx->blue_tmp_bytes, &ctx->real_tmp_bytes};
     for (int i = 0; i < 3; ++i) {
-        if (*bufs[i]) (void)hipFree(*bufs[i]);
+        if (*bufs[i] && !(i == 0 && ctx->big_tmp_external)) (void)hipFree(*bufs[i]);
         *bufs[i] = nullptr;
         *sizes[i] = 0;
     }

@@ -435,6 +435,32 @@ def test_large_n_persistent_factor_kernels(fft32, fft64, oracle, dtype, log2n, b
     assert_parity(y[pick], oracle.ifft(want), f"persistent factors inverse {dtype} 2^{log2n}", tol)
 
 
+@pytest.mark.parametrize("log2n,batch", [(14, 70), (15, 33), (17, 40), (19, 20), (20, 10)])
+def test_c64_factor_intermediate_layouts_agree(oracle, log2n, batch, monkeypatch):
+    """Round 4: between the two persistent factor kernels the c64 intermediate is block-interleaved (BigColsIO::out_lane: one
+    contiguous 1 KiB run per wavefront store, the last factor's row tile one contiguous stream); KOFFT_HIP_BIG_BLOCKED=0 keeps
+    the natural matrix layout.  Same butterflies either way: EVERY transform of the batch byte for byte, forward and inverse,
+    and the first / last against the oracle."""
+    import kofft_amd
+
+    n = 1 << log2n
+    x = rand_c(seeded(4100 + log2n), (batch, n), np.complex128)
+    outs = []
+    for blocked in ("1", "0"):
+        monkeypatch.setenv("KOFFT_HIP_BIG_BLOCKED", blocked)  # read when the context is created
+        f = kofft_amd.HipFftImpl(np.float64)
+        y = x.copy()
+        f.fft_batch(y)
+        z = y.copy()
+        f.fft_batch(z, inverse=True)
+        outs.append((y, z))
+    assert bits_equal(outs[0][0], outs[1][0]) and bits_equal(outs[0][1], outs[1][1])
+    pick = [0, batch - 1]
+    want = oracle.fft(x[pick])
+    assert_parity(outs[0][0][pick], want, f"blocked intermediate c64 2^{log2n}", REL_TOL_F64)
+    assert_parity(outs[0][1][pick], oracle.ifft(want), f"blocked intermediate inverse c64 2^{log2n}", REL_TOL_F64)
+
+
 # ---- real / STFT lengths beyond the fused kernels: composed from fft_dev (VERDICT r1 item 6) ------------------------------
 @pytest.mark.parametrize("n,batch", [(2, 5), (6, 4), (12, 7), (30, 3), (1000, 9), (65536, 3), (1 << 20, 2), (40000, 2)])
 def test_rfft_irfft_any_length_f32(fft32, oracle, n, batch):

@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--rfft-no-window", action="store_true", help="rfft32 without the Hann row window (default: with, like config 3)")
     ap.add_argument("--only-n", type=int, default=0, help="restrict every kind to this n")
     ap.add_argument("--max-n", type=int, default=0, help="skip sizes above this n")
+    ap.add_argument("--min-n", type=int, default=0, help="skip sizes below this n")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
@@ -60,7 +61,7 @@ def main():
                 esz = 8 if kind == "c32" else 16
                 for L in range(1, 25):
                     n = 1 << L
-                    if (args.only_n and n != args.only_n) or (args.max_n and n > args.max_n):
+                    if (args.only_n and n != args.only_n) or (args.max_n and n > args.max_n) or n < args.min_n:
                         continue
                     batch = max(1, (args.mb << 20) // (esz * n))
                     src = torch.empty((batch, n, 2), dtype=dt, device=dev).uniform_(-1, 1)
@@ -87,7 +88,7 @@ def main():
                 fft.set_stream(stream.cuda_stream)
                 for L in range(2, 15):
                     n = 1 << L
-                    if (args.only_n and n != args.only_n) or (args.max_n and n > args.max_n):
+                    if (args.only_n and n != args.only_n) or (args.max_n and n > args.max_n) or n < args.min_n:
                         continue
                     batch = max(1, (args.mb << 20) // (8 * n))
                     re = torch.empty((batch, n), dtype=torch.float64, device=dev).uniform_(-1, 1)
@@ -105,7 +106,7 @@ def main():
                 fft.set_stream(stream.cuda_stream)
                 for L in range(2, 16):
                     n = 1 << L
-                    if (args.only_n and n != args.only_n) or (args.max_n and n > args.max_n):
+                    if (args.only_n and n != args.only_n) or (args.max_n and n > args.max_n) or n < args.min_n:
                         continue
                     batch = max(1, (args.mb << 20) // (4 * n))
                     src = torch.empty((batch, n), dtype=torch.float32, device=dev).uniform_(-1, 1)
@@ -122,7 +123,7 @@ def main():
                 fft.set_stream(stream.cuda_stream)
                 for L in range(2, 16):
                     n = 1 << L
-                    if (args.only_n and n != args.only_n) or (args.max_n and n > args.max_n):
+                    if (args.only_n and n != args.only_n) or (args.max_n and n > args.max_n) or n < args.min_n:
                         continue
                     batch = max(1, (args.mb << 20) // (4 * n))
                     src = torch.empty((batch, n // 2 + 1, 2), dtype=torch.float32, device=dev).uniform_(-1, 1)
@@ -139,7 +140,7 @@ def main():
                 sig = torch.empty(total, dtype=torch.float32, device=dev).uniform_(-1, 1)
                 for L in range(5, 15):
                     n = 1 << L
-                    if (args.only_n and n != args.only_n) or (args.max_n and n > args.max_n):
+                    if (args.only_n and n != args.only_n) or (args.max_n and n > args.max_n) or n < args.min_n:
                         continue
                     hop = n // 4
                     frames = -(-total // hop)
