@@ -553,6 +553,24 @@ int fft_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t batch,
     KOFFT_HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!is_pow2(n))  // fft.rs:1083-1132
         return inverse ? fft_bluestein_dev<T, true>(ctx, d_in, d_out, n, batch) : fft_bluestein_dev<T, false>(ctx, d_in, d_out, n, batch);
+    if (n == (size_t(2) << max_log2<T>()) && ctx->use_regfile && batch >= (size_t)ctx->num_cus * 2) {
+        // 256 KiB per transform: one pass over HBM with the transform in the CU's register file (fft_regfile.hip.h)
+        const cpx<T> *tw = nullptr;
+        const int trc = get_table<T>(ctx, Kind<T>::tw, n, &tw);
+        if (trc) return trc;
+        const T scale = (T)1 / (T)(float)n;  // fft.rs:1167
+#ifdef KOFFT_RF_C32_ALT /* measurement builds: 2^7 x 2^8 (128-byte load runs, 64-byte store runs) instead of 2^8 x 2^7 */
+        constexpr int RLA = 7, RLB = sizeof(T) == 4 ? 8 : 7, RQB0 = sizeof(T) == 4 ? 5 : 4;
+#else
+        constexpr int RLA = sizeof(T) == 4 ? 8 : 7, RLB = 7, RQB0 = 4;
+#endif
+        if (inverse) {
+            ComplexIO<T, true> io{{}, reinterpret_cast<const cpx<T> *>(d_in), reinterpret_cast<cpx<T> *>(d_out), (int)n, scale};
+            return launch_regfile<T, RLA, RLB, RQB0>(ctx, io, tw, batch);
+        }
+        ComplexIO<T, false> io{{}, reinterpret_cast<const cpx<T> *>(d_in), reinterpret_cast<cpx<T> *>(d_out), (int)n, scale};
+        return launch_regfile<T, RLA, RLB, RQB0>(ctx, io, tw, batch);
+    }
     if (n > (size_t(1) << max_log2<T>()))
         return inverse ? fft_big_dev<T, true>(ctx, d_in, d_out, n, batch) : fft_big_dev<T, false>(ctx, d_in, d_out, n, batch);
     if (n == 1) {  // fft.rs:1059 / 1139: nothing to do

@@ -1,0 +1,332 @@
+// fft_regfile.hip.h -- one workgroup per transform of 256 KiB: c32 n = 2^15, c64 n = 2^14 (round 4).
+//
+// The single-pass kernels stopped where a transform no longer fits the CU's 160 KiB of LDS (c32 2^14, c64 2^13), and the next
+// size fell to two passes over HBM (0.31 / 0.35 of the roofline against 0.60 / 0.64).  But the CU's REGISTER FILE holds 512 KiB:
+// 1024 threads x 64 data registers are the whole transform, and the LDS only has to carry the exchanges -- in two rounds, the
+// real parts and then the imaginary parts, through cells of ONE real (N cells = 128 KiB for both sizes).
+//
+// Structure = the wave-split kernels (fft_split.hip.h, fft_split_wide.hip.h): N = 2^(LA + LB), R = 32 (f32) / 16 (f64) points
+// per thread, 16 wavefronts of 64 R points each:
+//   phase A  stages 0 .. LA-1: wavefront w owns CA = 64 R >> LA adjacent columns.  Pass A0 = log2 R stages on the thread's
+//            values (k = 0: compile-time table indices, scalar loads), wave-local exchange, pass A1 = LA - log2 R stages
+//            (entries from an LDS table: they depend on the position only);
+//   block-wide exchange, cell (K, j);
+//   phase B  stages LA .. L-1 of row K: wavefront w owns RB = 64 R >> LB adjacent rows.  Pass B0 = QB0 stages (entries depend
+//            on K only: LDS table [K][2^QB0 - 1], read as they are used), wave-local exchange, pass B1 = 3 stages on groups of 8
+//            values -- their 7 entries per group depend on the thread AND the row and are read from the L2-resident table per
+//            transform, a group ahead (f32) / before the block-wide exchange and behind the first group (f64): there is no
+//            register left to keep them.
+// No register set for a prefetched transform either: the next transform's loads go into a group's registers as soon as that
+// group's results have been stored.  What overlaps a workgroup's load and store phases is the OTHER 255 CUs.
+// Same butterflies, same table entries T_n[k * n2] (fft.rs:836-898), same order per output value as every other kernel here:
+// tools/split_model.py runs the decomposition (Geom(LA, LB, rlog, qa0 = rlog, qb0)) against numpy and the reference's
+// per-stage index sets.
+// LDS: cell(K, j) = K * 2^LB + (j ^ F(K) ^ G(j >> 5)), one real per cell; F, G from tools/split_model.py (CELL_BYTES = 4:
+// ds_write_b32 / ds_read_b32 serve two groups of 32 lanes on 32 banks, a 2-way write conflict is free; 8: the rules of the
+// 8-byte cells) -- no conflict cycle in any of the six access shapes.  XOR-linear: every address is base(thread) ^ const(register).
+// Barriers per transform: one before the first LDS write (every wavefront has read the previous transform out of its rows)
+// and three inside the block-wide exchange (re written | re read | im written | im read).
+#pragma once
+
+#include "fft_split.hip.h"
+
+#ifndef KOFFT_RF_NTW
+#define KOFFT_RF_NTW 1
+#endif
+
+namespace kofft {
+
+template <typename T, int LA, int LB, int QB0> struct RfSwizzle;
+template <> struct RfSwizzle<float, 8, 7, 4> {
+    static constexpr int F[8] = {25, 9, 5, 10, 16, 25, 27, 18};
+    static constexpr int G[2] = {1, 3};
+};
+template <> struct RfSwizzle<float, 7, 8, 5> {
+    static constexpr int F[7] = {25, 10, 20, 7, 5, 25, 27};
+    static constexpr int G[3] = {18, 1, 3};
+};
+template <> struct RfSwizzle<double, 7, 7, 4> {  // = SplitSwizzle<7, 7>: the 16-points-per-thread shapes on 8-byte cells
+    static constexpr int F[7] = {15, 4, 18, 30, 8, 4, 26};
+    static constexpr int G[2] = {0, 0};
+};
+
+template <typename T, int LA_, int LB_, int QB0_>
+struct RfGeom {
+    static constexpr int LA = LA_, LB = LB_, L = LA + LB, N = 1 << L;
+    static constexpr int RLOG = sizeof(T) == 4 ? 5 : 4, R = 1 << RLOG, TPT = N / R, PW = 64 * R, W = N / PW;
+    static constexpr int QA0 = RLOG, QA1 = LA - RLOG, QB0 = QB0_, QB1 = LB - QB0_;
+    static constexpr int CA = PW >> LA, RB = PW >> LB;            // columns / rows per wavefront
+    static constexpr int TA = (1 << LA) / R, TB = (1 << LB) / R;  // threads per column / per row
+    static constexpr int CELL = (int)sizeof(T);
+    static_assert(TPT == 1024 && W == 16, "the whole register file of a CU: 16 wavefronts");
+    static_assert(QA1 >= 1 && QA1 <= RLOG && QB0 >= 1 && QB0 <= RLOG && QB1 >= 1 && QB1 <= RLOG, "pass shapes");
+    static_assert(LB >= 5 && LB <= 8, "G covers bits 5 .. 7 of j");
+    __host__ __device__ static constexpr int f(int K)
+    {
+        int r = 0;
+        for (int i = 0; i < LA; ++i)
+            if ((K >> i) & 1) r ^= RfSwizzle<T, LA, LB, QB0>::F[i];
+        return r;
+    }
+    __host__ __device__ static constexpr int gj(int jh)
+    {
+        int r = 0;
+        for (int i = 0; i < LB - 5; ++i)
+            if ((jh >> i) & 1) r ^= RfSwizzle<T, LA, LB, QB0>::G[i];
+        return r;
+    }
+    // byte offset of logical cell (K, j); XOR-linear in the bits of (K, j)
+    __host__ __device__ static constexpr int cell_bytes(int K, int j) { return ((K << LB) | (j ^ f(K) ^ gj(j >> 5))) * CELL; }
+    // register parts (compile-time constants once the loops are unrolled); u = (g, c), c the low Q bits
+    __host__ __device__ static constexpr int a0_out_reg(int u) { return cell_bytes(bitrev(u, QA0) << (LA - QA0), 0); }
+    __host__ __device__ static constexpr int a1_in_reg(int u)
+    {
+        const int g = u >> QA1, c = u & ((1 << QA1) - 1);
+        return cell_bytes(((g * TA) << QA1) | c, 0);
+    }
+    __host__ __device__ static constexpr int a1_out_reg(int u)
+    {
+        const int g = u >> QA1, c = u & ((1 << QA1) - 1);
+        return cell_bytes((bitrev(c, QA1) << QA0) | (g * TA), 0);
+    }
+    __host__ __device__ static constexpr int b0_in_reg(int u)
+    {
+        const int g = u >> QB0, c = u & ((1 << QB0) - 1);
+        return cell_bytes(0, (c << (LB - QB0)) | (g * TB));
+    }
+    __host__ __device__ static constexpr int b0_out_reg(int u)
+    {
+        const int g = u >> QB0, c = u & ((1 << QB0) - 1);
+        return cell_bytes(0, (bitrev(c, QB0) << (LB - QB0)) | (g * TB));
+    }
+    __host__ __device__ static constexpr int b1_in_reg(int u)
+    {
+        const int g = u >> QB1, c = u & ((1 << QB1) - 1);
+        return cell_bytes(0, ((g * TB) << QB1) | c);
+    }
+    // element offset of output register u relative to the thread's tauB = (jb << LA) | K
+    __host__ __device__ static constexpr int out_reg(int u)
+    {
+        const int g = u >> QB1, c = u & ((1 << QB1) - 1);
+        return (bitrev(c, QB1) << (QB0 + LA)) | ((g * TB) << LA);
+    }
+};
+
+template <class Gm, typename T>
+constexpr size_t regfile_lds_bytes()
+{
+    return (size_t)Gm::N * Gm::CELL + (size_t)(1 << Gm::QA0) * ((1 << Gm::QA1) - 1) * sizeof(cpx<T>) +
+           (size_t)(1 << Gm::LA) * ((1 << Gm::QB0) - 1) * sizeof(cpx<T>);
+}
+
+// one real per cell, addressed by the integer LDS offset (dynamic LDS starts at 0: checked at kernel entry)
+template <typename T>
+struct RfCell {
+    typedef __attribute__((address_space(3))) T lds_t;
+    __device__ __forceinline__ static T ld(int byte_off) { return *(lds_t *)(size_t)(unsigned)byte_off; }
+    __device__ __forceinline__ static void st(int byte_off, const T v) { *(lds_t *)(size_t)(unsigned)byte_off = v; }
+};
+
+template <typename T, int LA, int LB, int QB0, class IO>
+__global__ __launch_bounds__(1024, 4) void fft_regfile_persist_kernel(const IO io, const cpx<T> *__restrict__ tw, const size_t batch)
+{
+    using Gm = RfGeom<T, LA, LB, QB0>;
+    using Lds = SplitLds<T, LA, LB, IO>;  // whole complex values: the tables
+    using Cell = RfCell<T>;
+    constexpr int R = Gm::R, ES = (int)sizeof(cpx<T>);
+    constexpr int QA0 = Gm::QA0, QA1 = Gm::QA1, QB1 = Gm::QB1;
+    constexpr int EA = (1 << QA1) - 1, EB0 = (1 << QB0) - 1, EB1 = (1 << QB1) - 1;
+    constexpr int TABLE_A = Gm::N * Gm::CELL;                 // [k < 2^QA0][EA]
+    constexpr int TABLE_B = TABLE_A + (1 << QA0) * EA * ES;   // [K < 2^LA][EB0]
+    constexpr int GB1 = R >> QB1;                             // groups of pass B1
+    constexpr int NTW = KOFFT_RF_NTW;                         // B1 entry sets in registers (2 = a group ahead: 14 more registers, spilled)
+    using Raw = typename IO::Raw;
+    static_assert(std::is_same<Raw, cpx<T>>::value, "one complex value per element (ComplexIO)");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    if ((unsigned)(size_t)(__attribute__((address_space(3))) char *)smem_raw != 0u) __builtin_trap();  // integer LDS addressing
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int ja = lane / Gm::CA, x = lane % Gm::CA;
+    const int jb = lane / Gm::RB, y = lane % Gm::RB;
+    const int col = w * Gm::CA + x, K = w * Gm::RB + y;
+
+    // ---- tables in LDS, built once (TwSubFirst / TwSub index forms, as in fft_split_wide_persist_kernel)
+    for (int e = tid; e < (1 << QA0) * EA; e += Gm::TPT) {
+        const int k = e / EA, i = e % EA;
+        int t = 0;
+        while (((2 << t) - 1) <= i) ++t;  // i = (1 << t) - 1 + h
+        const int h = i - ((1 << t) - 1);
+        int hr = 0;
+        for (int b = 0; b < t; ++b) hr |= ((h >> b) & 1) << (t - 1 - b);
+        Lds::st(TABLE_A + e * ES, tw[((k << (LA - 1 - QA0 - t)) + (hr << (LA - 1 - t))) << LB]);
+    }
+    for (int e = tid; e < (1 << LA) * EB0; e += Gm::TPT) {
+        const int row = e / EB0, i = e % EB0;
+        int t = 0;
+        while (((2 << t) - 1) <= i) ++t;
+        const int h = i - ((1 << t) - 1);
+        int hr = 0;
+        for (int b = 0; b < t; ++b) hr |= ((h >> b) & 1) << (t - 1 - b);
+        Lds::st(TABLE_B + e * ES, tw[((hr << (LB - 1 - t)) << LA) + (row << (LB - 1 - t))]);
+    }
+
+    // Every per-thread constant of the loop lives in THREE registers (two 16-bit fields each: cell and element indices are below
+    // 2^15) and is unpacked where it is used -- ten loop-invariant registers were what the allocator spilled (and every reload from
+    // scratch is an s_waitcnt vmcnt(0): it also waits for whatever the wavefront has in flight).
+    const unsigned packA = (unsigned)(Gm::cell_bytes(ja, col) / Gm::CELL) | ((unsigned)(Gm::cell_bytes(ja << QA1, col) / Gm::CELL) << 16);
+    const unsigned packB = (unsigned)(Gm::cell_bytes(K, jb) / Gm::CELL) | ((unsigned)(Gm::cell_bytes(K, jb << QB1) / Gm::CELL) << 16);
+    const unsigned packT = (unsigned)((ja << LB) | col) | ((unsigned)((jb << LA) | K) << 16);  // tauA | tauB << 16
+    static_assert(Gm::N <= (1 << 15), "16-bit fields");
+    auto fresh = [](unsigned v) {  // an opaque copy: what is unpacked from it cannot be hoisted out of the transform loop
+        asm volatile("" : "+v"(v));
+        return v;
+    };
+    auto lo_cell = [&](unsigned p) { return (int)((fresh(p) & 0xffffu) * (unsigned)Gm::CELL); };
+    auto hi_cell = [&](unsigned p) { return (int)((fresh(p) >> 16) * (unsigned)Gm::CELL); };
+    auto tau_a = [&]() { return (int)(fresh(packT) & 0xffffu); };
+    auto tau_b = [&]() { return (int)(fresh(packT) >> 16); };
+    const rsrc_t twd = make_rsrc(tw, (unsigned)(Gm::N / 2) * (unsigned)ES);
+    // pass B1's entries of group g: T[(tauB << (LB-1-QB0-t)) + ((g TB) << (L-1-QB0-t)) + (rev_t(h) << (L-1-t))], t < QB1
+    auto load_twb = [&](const int g, cpx<T> *dst) {
+        const int tauB = tau_b();
+#pragma unroll
+        for (int t = 0; t < QB1; ++t)
+#pragma unroll
+            for (int h = 0; h < (1 << t); ++h)
+                dst[(1 << t) - 1 + h] = buf_load_cpx<T, AUX_DEFAULT>(
+                    twd, (tauB << (LB - 1 - QB0 - t)) * ES,
+                    (((g * Gm::TB) << (Gm::L - 1 - QB0 - t)) + (bitrev(h, t) << (Gm::L - 1 - t))) * ES);
+    };
+    __syncthreads();  // tables complete
+
+    const size_t step = gridDim.x;
+    size_t base = blockIdx.x;
+    if (base >= batch) return;
+
+    Raw raw[R];
+    {
+        const rsrc_t d0 = io.in_desc_n(base, 1);
+        const int in_lane_bytes = tau_a() * (int)IO::kRawBytes;
+#pragma unroll
+        for (int u = 0; u < R; ++u) raw[u] = io.fetch_d(d0, in_lane_bytes, u * Gm::TPT, 0);
+    }
+    for (;;) {
+        const size_t nbase = base + step;
+        const bool more = nbase < batch;  // workgroup-uniform
+        const rsrc_t nd = io.in_desc_n(nbase, more ? 1 : 0);  // empty when there is no next transform: the loads return zeros
+        const size_t xf = base;
+        cpx<T> cur[R];
+#pragma unroll
+        for (int u = 0; u < R; ++u) cur[u] = io.finish_in(raw[u], io.invariant(0));
+        // ---- phase A
+        reg_pass<T, LA, 0, QA0, true>(cur, 0, tw, TwSubFirst{LB});
+        __syncthreads();  // every wavefront has read the previous transform out of the buffer
+        {
+            const int a = lo_cell(packA);
+#pragma unroll
+            for (int u = 0; u < R; ++u) Cell::st(a ^ Gm::a0_out_reg(u), cur[u].re);
+        }
+        exchange_sync<true>();
+        {
+            const int a = hi_cell(packA);
+#pragma unroll
+            for (int u = 0; u < R; ++u) cur[u].re = Cell::ld(a ^ Gm::a1_in_reg(u));
+        }
+        exchange_sync<true>();
+        {
+            const int a = lo_cell(packA);
+#pragma unroll
+            for (int u = 0; u < R; ++u) Cell::st(a ^ Gm::a0_out_reg(u), cur[u].im);
+        }
+        exchange_sync<true>();
+        {
+            const int a = hi_cell(packA);
+#pragma unroll
+            for (int u = 0; u < R; ++u) cur[u].im = Cell::ld(a ^ Gm::a1_in_reg(u));
+        }
+        {
+            const int tA = TABLE_A + (tau_a() >> LB) * (EA * ES);  // + ja * EA entries
+#pragma unroll
+            for (int g = 0; g < (R >> QA1); ++g) reg_pass_lds<T, QA1, Lds>(cur + g * (1 << QA1), tA + g * Gm::TA * EA * ES);
+        }
+        // ---- the block-wide exchange, real parts then imaginary parts
+        exchange_sync<true>();  // this wavefront's gathers above are done before its cells are overwritten
+        {
+            const int a = lo_cell(packA);
+#pragma unroll
+            for (int u = 0; u < R; ++u) Cell::st(a ^ Gm::a1_out_reg(u), cur[u].re);
+        }
+        __syncthreads();
+        {
+            const int a = lo_cell(packB);
+#pragma unroll
+            for (int u = 0; u < R; ++u) cur[u].re = Cell::ld(a ^ Gm::b0_in_reg(u));
+        }
+        __syncthreads();
+        {
+            const int a = lo_cell(packA);
+#pragma unroll
+            for (int u = 0; u < R; ++u) Cell::st(a ^ Gm::a1_out_reg(u), cur[u].im);
+        }
+        __syncthreads();
+        {
+            const int a = lo_cell(packB);
+#pragma unroll
+            for (int u = 0; u < R; ++u) cur[u].im = Cell::ld(a ^ Gm::b0_in_reg(u));
+        }
+        // ---- phase B: this thread's row K from here on, every cell touched below belongs to this wavefront's rows.
+        // Pass B1's first entries travel while pass B0 and the wave-local exchange run.
+        cpx<T> twb[NTW][EB1];
+        split_pin();
+#pragma unroll
+        for (int b = 0; b < NTW; ++b) load_twb(b, twb[b]);
+        split_pin();
+        {
+            const int tB = TABLE_B + (tau_b() & ((1 << LA) - 1)) * (EB0 * ES);  // + K * EB0 entries
+#pragma unroll
+            for (int g = 0; g < (R >> QB0); ++g) reg_pass_lds<T, QB0, Lds>(cur + g * (1 << QB0), tB);
+        }
+        exchange_sync<true>();
+        {
+            const int a = lo_cell(packB);
+#pragma unroll
+            for (int u = 0; u < R; ++u) Cell::st(a ^ Gm::b0_out_reg(u), cur[u].re);
+        }
+        exchange_sync<true>();
+        {
+            const int a = hi_cell(packB);
+#pragma unroll
+            for (int u = 0; u < R; ++u) cur[u].re = Cell::ld(a ^ Gm::b1_in_reg(u));
+        }
+        exchange_sync<true>();
+        {
+            const int a = lo_cell(packB);
+#pragma unroll
+            for (int u = 0; u < R; ++u) Cell::st(a ^ Gm::b0_out_reg(u), cur[u].im);
+        }
+        exchange_sync<true>();
+        {
+            const int a = hi_cell(packB);
+#pragma unroll
+            for (int u = 0; u < R; ++u) cur[u].im = Cell::ld(a ^ Gm::b1_in_reg(u));
+        }
+        const rsrc_t od = io.out_desc_n(xf, 1);
+        const int out_lane_bytes = tau_b() * ES, in_lane_bytes = tau_a() * (int)IO::kRawBytes;
+#pragma unroll
+        for (int g = 0; g < GB1; ++g) {  // results leave as each group completes; its registers take the next transform's loads
+            reg_pass_r<T, QB1>(cur + g * (1 << QB1), twb[g % NTW]);
+            split_pin();
+            if (g + NTW < GB1) load_twb(g + NTW, twb[g % NTW]);
+#pragma unroll
+            for (int u = g << QB1; u < ((g + 1) << QB1); ++u) io.store_d(od, out_lane_bytes, Gm::out_reg(u), cur[u], 0);
+#pragma unroll
+            for (int u = g << QB1; u < ((g + 1) << QB1); ++u) raw[u] = io.fetch_d(nd, in_lane_bytes, u * Gm::TPT, 0);
+            split_pin();
+        }
+        if (!more) break;
+        base = nbase;
+    }
+}
+
+}  // namespace kofft

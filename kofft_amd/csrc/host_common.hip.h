@@ -20,6 +20,7 @@
 
 #include "fft_big.hip.h"
 #include "fft_persist.hip.h"
+#include "fft_regfile.hip.h"
 #include "fft_split_wide.hip.h"
 #include "fft_wg.hip.h"
 #include "tables.h"
@@ -63,6 +64,7 @@ struct kofft_hip_ctx {
     int split14 = 2;           // KOFFT_HIP_SPLIT14=1: n = 16384 on the 16-points-per-thread kernel (fft_split1) instead of the 32-points one (fft_split_wide.hip.h)
     int split13 = 1;           // KOFFT_HIP_SPLIT13=2: n = 8192 as TWO independent single-buffer workgroups per CU (fft_split1) instead of one
                                // double-buffered one (measured, same box: c32 0.52-0.53 against 0.61-0.63, STFT 0.41 against 0.43)
+    bool use_regfile = true;   // KOFFT_HIP_REGFILE=0: c32 2^15 / c64 2^14 on the two-factor path instead of the register-file-resident kernel (A/B)
     bool use_split = true;     // KOFFT_HIP_SPLIT=0: n = 8192 on the block-synchronised persistent kernel instead of the wave-split one (A/B)
     std::string last_error;
     // planner caches: (kind, n) -> device table.  kind 0/1 = FftPlanner twiddles f32/f64,
@@ -477,6 +479,28 @@ int launch_split_wide(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t
         if (arc) return arc;
     }
     size_t blocks = (size_t)ctx->num_cus * ((160 * 1024) / lds);
+    if (ctx->persist_grid_pct > 0) blocks = blocks * (size_t)ctx->persist_grid_pct / 100;
+    if (blocks < 1) blocks = 1;
+    if (blocks > batch) blocks = batch;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Gm::TPT), lds, ctx->stream, io, tw, batch);
+    KOFFT_HIP_TRY(ctx, hipGetLastError());
+    return KOFFT_OK;
+}
+
+// c32 n = 2^15 / c64 n = 2^14: the whole transform in the CU's register file (fft_regfile.hip.h), one 1024-thread workgroup per CU
+template <typename T, int LA, int LB, int QB0, class IO>
+int launch_regfile(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t batch)
+{
+    using Gm = RfGeom<T, LA, LB, QB0>;
+    constexpr size_t lds = regfile_lds_bytes<Gm, T>();
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = fft_regfile_persist_kernel<T, LA, LB, QB0, IO>;
+    {
+        static std::atomic<unsigned long long> attr_done{0};
+        const int arc = set_dyn_lds_once(ctx, attr_done, reinterpret_cast<const void *>(kern), lds);
+        if (arc) return arc;
+    }
+    size_t blocks = (size_t)ctx->num_cus;
     if (ctx->persist_grid_pct > 0) blocks = blocks * (size_t)ctx->persist_grid_pct / 100;
     if (blocks < 1) blocks = 1;
     if (blocks > batch) blocks = batch;

@@ -494,6 +494,7 @@ int kofft_hip_create(int device, kofft_hip_ctx **out)
     if (const char *e = getenv("KOFFT_HIP_PERSIST64")) ctx->persist64 = atoi(e);
     if (const char *e = getenv("KOFFT_HIP_PERSIST_SMALL")) ctx->persist_small = !(e[0] == '0');
     if (const char *e = getenv("KOFFT_HIP_SPLIT")) ctx->use_split = !(e[0] == '0');
+    if (const char *e = getenv("KOFFT_HIP_REGFILE")) ctx->use_regfile = !(e[0] == '0');
     if (const char *e = getenv("KOFFT_HIP_SPLIT13")) ctx->split13 = atoi(e);
     if (const char *e = getenv("KOFFT_HIP_SPLIT14")) ctx->split14 = atoi(e);
     if (const char *e = getenv("KOFFT_HIP_HOST_PIPELINE")) ctx->host_pipeline = !(e[0] == '0');

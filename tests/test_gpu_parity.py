@@ -435,6 +435,34 @@ def test_large_n_persistent_factor_kernels(fft32, fft64, oracle, dtype, log2n, b
     assert_parity(y[pick], oracle.ifft(want), f"persistent factors inverse {dtype} 2^{log2n}", tol)
 
 
+@pytest.mark.parametrize("dtype,log2n,batch", [("c32", 15, 515), ("c64", 14, 520), ("c32", 15, 1030), ("c64", 14, 777)])
+def test_regfile_resident_kernels_every_transform(oracle, dtype, log2n, batch, monkeypatch):
+    """Round 4: c32 n = 2^15 and c64 n = 2^14 (256 KiB per transform) run ONE pass over HBM with the transform held in the CU's
+    register file (fft_regfile.hip.h: 1024 threads x 32 / 16 points, exchanges through LDS in a real and an imaginary round) once
+    the batch gives every CU two transforms; KOFFT_HIP_REGFILE=0 keeps the two-factor path.  EVERY transform against the oracle,
+    forward and inverse, and both routes byte for byte."""
+    import kofft_amd
+
+    n = 1 << log2n
+    cdt = np.complex128 if dtype == "c64" else np.complex64
+    rdt = np.float64 if dtype == "c64" else np.float32
+    tol = REL_TOL_F64 if dtype == "c64" else REL_TOL_F32
+    x = rand_c(seeded(4300 + log2n + batch), (batch, n), cdt)
+    want = oracle.fft(x)
+    outs = []
+    for regfile in ("1", "0"):
+        monkeypatch.setenv("KOFFT_HIP_REGFILE", regfile)  # read when the context is created
+        f = kofft_amd.HipFftImpl(rdt)
+        y = x.copy()
+        f.fft_batch(y)
+        assert_parity(y, want, f"regfile={regfile} {dtype} 2^{log2n} x {batch}", tol)
+        z = y.copy()
+        f.fft_batch(z, inverse=True)
+        outs.append((y, z))
+    assert bits_equal(outs[0][1], outs[1][1])
+    assert_parity(outs[0][1], oracle.ifft(want), f"regfile inverse {dtype} 2^{log2n} x {batch}", tol)
+
+
 @pytest.mark.parametrize("log2n,batch", [(14, 70), (15, 33), (17, 40), (19, 20), (20, 10)])
 def test_c64_factor_intermediate_layouts_agree(oracle, log2n, batch, monkeypatch):
     """Round 4: between the two persistent factor kernels the c64 intermediate is block-interleaved (BigColsIO::out_lane: one
