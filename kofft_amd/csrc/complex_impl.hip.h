@@ -559,11 +559,8 @@ int fft_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t batch,
         const int trc = get_table<T>(ctx, Kind<T>::tw, n, &tw);
         if (trc) return trc;
         const T scale = (T)1 / (T)(float)n;  // fft.rs:1167
-#ifdef KOFFT_RF_C32_ALT /* measurement builds: 2^7 x 2^8 (128-byte load runs, 64-byte store runs) instead of 2^8 x 2^7 */
-        constexpr int RLA = 7, RLB = sizeof(T) == 4 ? 8 : 7, RQB0 = sizeof(T) == 4 ? 5 : 4;
-#else
+        // (c32 as 2^7 x 2^8 -- 128-byte load runs, 64-byte store runs -- measured 0.374-0.378 against 0.396-0.402 for 2^8 x 2^7)
         constexpr int RLA = sizeof(T) == 4 ? 8 : 7, RLB = 7, RQB0 = 4;
-#endif
         if (inverse) {
             ComplexIO<T, true> io{{}, reinterpret_cast<const cpx<T> *>(d_in), reinterpret_cast<cpx<T> *>(d_out), (int)n, scale};
             return launch_regfile<T, RLA, RLB, RQB0>(ctx, io, tw, batch);

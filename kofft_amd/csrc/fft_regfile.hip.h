@@ -30,11 +30,22 @@
 
 #include "fft_split.hip.h"
 
-#ifndef KOFFT_RF_NTW
-#define KOFFT_RF_NTW 1
+#ifndef KOFFT_RF_SPLIT_BARRIER
+#define KOFFT_RF_SPLIT_BARRIER 1
 #endif
-
+// Measurement hooks (variant builds only, tools/build_variant.sh; the product defines none of them):
+//   KOFFT_RF_NO_MEM     the arithmetic and the exchanges without global traffic inside the loop
+//   KOFFT_RF_COPY_ONLY  the loads and stores alone
+//   KOFFT_RF_STAMPS     s_memtime at the phase boundaries (tools/rf_stamps.py)
 namespace kofft {
+
+#ifdef KOFFT_RF_STAMPS /* diagnostic builds only (tools/rf_stamps.py): s_memtime at the phase boundaries, first 4 workgroups x 8 transforms */
+static __device__ unsigned long long g_rf_stamps[4 * 8 * 16 * 16];
+#define KOFFT_RF_STAMP(id)                                                                                              \
+    if (lane == 0 && blockIdx.x < 4 && iter < 8) g_rf_stamps[((blockIdx.x * 8 + iter) * 16 + w) * 16 + (id)] = __builtin_amdgcn_s_memtime();
+#else
+#define KOFFT_RF_STAMP(id)
+#endif
 
 template <typename T, int LA, int LB, int QB0> struct RfSwizzle;
 template <> struct RfSwizzle<float, 8, 7, 4> {
@@ -116,7 +127,7 @@ template <class Gm, typename T>
 constexpr size_t regfile_lds_bytes()
 {
     return (size_t)Gm::N * Gm::CELL + (size_t)(1 << Gm::QA0) * ((1 << Gm::QA1) - 1) * sizeof(cpx<T>) +
-           (size_t)(1 << Gm::LA) * ((1 << Gm::QB0) - 1) * sizeof(cpx<T>);
+           (size_t)(1 << Gm::LA) * ((1 << Gm::QB0) - 1) * sizeof(cpx<T>) + 16;  // + the arrival counter
 }
 
 // one real per cell, addressed by the integer LDS offset (dynamic LDS starts at 0: checked at kernel entry)
@@ -138,8 +149,11 @@ __global__ __launch_bounds__(1024, 4) void fft_regfile_persist_kernel(const IO i
     constexpr int EA = (1 << QA1) - 1, EB0 = (1 << QB0) - 1, EB1 = (1 << QB1) - 1;
     constexpr int TABLE_A = Gm::N * Gm::CELL;                 // [k < 2^QA0][EA]
     constexpr int TABLE_B = TABLE_A + (1 << QA0) * EA * ES;   // [K < 2^LA][EB0]
+    constexpr int COUNTER = TABLE_B + (1 << LA) * EB0 * ES;   // arrivals at "this wavefront has read the transform out of its rows"
+    // (f32 only: same box, 512 MiB / 4 GiB per launch 0.401 / 0.48 -> 0.418 / 0.505; in f64 the extra live values spill 9 registers, +-0)
+    constexpr bool SPLITBAR = KOFFT_RF_SPLIT_BARRIER && sizeof(T) == 4;
     constexpr int GB1 = R >> QB1;                             // groups of pass B1
-    constexpr int NTW = KOFFT_RF_NTW;                         // B1 entry sets in registers (2 = a group ahead: 14 more registers, spilled)
+    constexpr int NTW = 1;  // B1 entry sets in registers (2 = a group ahead: 14 more registers, 5 spilled, no faster)
     using Raw = typename IO::Raw;
     static_assert(std::is_same<Raw, cpx<T>>::value, "one complex value per element (ComplexIO)");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -198,6 +212,8 @@ __global__ __launch_bounds__(1024, 4) void fft_regfile_persist_kernel(const IO i
                     twd, (tauB << (LB - 1 - QB0 - t)) * ES,
                     (((g * Gm::TB) << (Gm::L - 1 - QB0 - t)) + (bitrev(h, t) << (Gm::L - 1 - t))) * ES);
     };
+    typedef __attribute__((address_space(3))) unsigned lds_u32;
+    if (tid == 0) *(lds_u32 *)(size_t)(unsigned)COUNTER = 0u;
     __syncthreads();  // tables complete
 
     const size_t step = gridDim.x;
@@ -211,7 +227,8 @@ __global__ __launch_bounds__(1024, 4) void fft_regfile_persist_kernel(const IO i
 #pragma unroll
         for (int u = 0; u < R; ++u) raw[u] = io.fetch_d(d0, in_lane_bytes, u * Gm::TPT, 0);
     }
-    for (;;) {
+    for (int iter = 0;; ++iter) {  // (2^31 transforms per workgroup would be 512 TiB)
+        KOFFT_RF_STAMP(0)
         const size_t nbase = base + step;
         const bool more = nbase < batch;  // workgroup-uniform
         const rsrc_t nd = io.in_desc_n(nbase, more ? 1 : 0);  // empty when there is no next transform: the loads return zeros
@@ -219,9 +236,41 @@ __global__ __launch_bounds__(1024, 4) void fft_regfile_persist_kernel(const IO i
         cpx<T> cur[R];
 #pragma unroll
         for (int u = 0; u < R; ++u) cur[u] = io.finish_in(raw[u], io.invariant(0));
+#ifdef KOFFT_RF_COPY_ONLY /* measurement only: loads and stores alone */
+        if (true) {
+            const rsrc_t od = io.out_desc_n(xf, 1);
+            const int out_lane_bytes = tau_b() * ES, in_lane_bytes = tau_a() * (int)IO::kRawBytes;
+#pragma unroll
+            for (int u = 0; u < R; ++u) io.store_d(od, out_lane_bytes, Gm::out_reg(u), cur[u], 0);
+#pragma unroll
+            for (int u = 0; u < R; ++u) raw[u] = io.fetch_d(nd, in_lane_bytes, u * Gm::TPT, 0);
+            if (!more) break;
+            base = nbase;
+            continue;
+        }
+#endif
+#ifdef KOFFT_RF_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        KOFFT_RF_STAMP(1)
         // ---- phase A
         reg_pass<T, LA, 0, QA0, true>(cur, 0, tw, TwSubFirst{LB});
-        __syncthreads();  // every wavefront has read the previous transform out of the buffer
+        KOFFT_RF_STAMP(2)
+        if constexpr (SPLITBAR) {
+        // Every wavefront has read the previous transform out of its rows -- a SPLIT barrier: a wavefront arrives (below) as soon as
+        // its last gathers are done, long before it has stored its results, loaded the next inputs and run pass A0, and only waits
+        // here.  With s_barrier in this place the wavefronts whose memory instructions were queued first sat out those of the last
+        // ones (s_memtime stamps, tools/rf_stamps.py: 0.1 .. 21 us at this point), and all sixteen then ran the wave-local exchange
+        // and pass A1 together instead of behind one another.
+        {
+            const unsigned target = 16u * (unsigned)iter;
+            while (__builtin_amdgcn_readfirstlane(*(volatile lds_u32 *)(size_t)(unsigned)COUNTER) < target) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        } else {
+            __syncthreads();  // every wavefront has read the previous transform out of the buffer
+        }
+        KOFFT_RF_STAMP(3)
         {
             const int a = lo_cell(packA);
 #pragma unroll
@@ -245,11 +294,13 @@ __global__ __launch_bounds__(1024, 4) void fft_regfile_persist_kernel(const IO i
 #pragma unroll
             for (int u = 0; u < R; ++u) cur[u].im = Cell::ld(a ^ Gm::a1_in_reg(u));
         }
+        KOFFT_RF_STAMP(4)
         {
             const int tA = TABLE_A + (tau_a() >> LB) * (EA * ES);  // + ja * EA entries
 #pragma unroll
             for (int g = 0; g < (R >> QA1); ++g) reg_pass_lds<T, QA1, Lds>(cur + g * (1 << QA1), tA + g * Gm::TA * EA * ES);
         }
+        KOFFT_RF_STAMP(5)
         // ---- the block-wide exchange, real parts then imaginary parts
         exchange_sync<true>();  // this wavefront's gathers above are done before its cells are overwritten
         {
@@ -275,6 +326,7 @@ __global__ __launch_bounds__(1024, 4) void fft_regfile_persist_kernel(const IO i
 #pragma unroll
             for (int u = 0; u < R; ++u) cur[u].im = Cell::ld(a ^ Gm::b0_in_reg(u));
         }
+        KOFFT_RF_STAMP(6)
         // ---- phase B: this thread's row K from here on, every cell touched below belongs to this wavefront's rows.
         // Pass B1's first entries travel while pass B0 and the wave-local exchange run.
         cpx<T> twb[NTW][EB1];
@@ -287,6 +339,7 @@ __global__ __launch_bounds__(1024, 4) void fft_regfile_persist_kernel(const IO i
 #pragma unroll
             for (int g = 0; g < (R >> QB0); ++g) reg_pass_lds<T, QB0, Lds>(cur + g * (1 << QB0), tB);
         }
+        KOFFT_RF_STAMP(7)
         exchange_sync<true>();
         {
             const int a = lo_cell(packB);
@@ -311,6 +364,14 @@ __global__ __launch_bounds__(1024, 4) void fft_regfile_persist_kernel(const IO i
 #pragma unroll
             for (int u = 0; u < R; ++u) cur[u].im = Cell::ld(a ^ Gm::b1_in_reg(u));
         }
+        if constexpr (SPLITBAR) {
+        // arrive: this wavefront's rows are free (the values just gathered have landed: the counter add follows them in the LDS queue
+        // only if it is issued after the wait)
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_fetch_add((lds_u32 *)(size_t)(unsigned)COUNTER, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        KOFFT_RF_STAMP(8)
         const rsrc_t od = io.out_desc_n(xf, 1);
         const int out_lane_bytes = tau_b() * ES, in_lane_bytes = tau_a() * (int)IO::kRawBytes;
 #pragma unroll
@@ -319,11 +380,19 @@ __global__ __launch_bounds__(1024, 4) void fft_regfile_persist_kernel(const IO i
             split_pin();
             if (g + NTW < GB1) load_twb(g + NTW, twb[g % NTW]);
 #pragma unroll
+#ifdef KOFFT_RF_NO_MEM /* measurement only: the arithmetic and the exchanges without global traffic inside the loop */
+            for (int u = g << QB1; u < ((g + 1) << QB1); ++u) {
+                if (!more) io.store_d(od, out_lane_bytes, Gm::out_reg(u), cur[u], 0);
+                raw[u] = cur[u];
+            }
+#else
             for (int u = g << QB1; u < ((g + 1) << QB1); ++u) io.store_d(od, out_lane_bytes, Gm::out_reg(u), cur[u], 0);
 #pragma unroll
             for (int u = g << QB1; u < ((g + 1) << QB1); ++u) raw[u] = io.fetch_d(nd, in_lane_bytes, u * Gm::TPT, 0);
+#endif
             split_pin();
         }
+        KOFFT_RF_STAMP(9)
         if (!more) break;
         base = nbase;
     }

@@ -8,3 +8,11 @@ template int fft_radix4_dev<float>(kofft_hip_ctx *, const float *, float *, size
 template int fft_big_windowed_dev<float>(kofft_hip_ctx *, const float *, float *, const float *, size_t, size_t);
 }  // namespace host
 }  // namespace kofft
+
+#if defined(KOFFT_RF_STAMPS)
+// diagnostic builds only: the s_memtime stamps of fft_regfile_persist_kernel<float, ...> (this translation unit's copy)
+extern "C" int kofft_hip_exp_rf_stamps_f32(void *out, size_t bytes)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(kofft::g_rf_stamps), bytes) == hipSuccess ? 0 : -1;
+}
+#endif

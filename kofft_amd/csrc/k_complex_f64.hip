@@ -8,3 +8,10 @@ template int fft_radix4_dev<double>(kofft_hip_ctx *, const double *, double *, s
 template int fft_big_windowed_dev<double>(kofft_hip_ctx *, const double *, double *, const double *, size_t, size_t);
 }  // namespace host
 }  // namespace kofft
+
+#if defined(KOFFT_RF_STAMPS)
+extern "C" int kofft_hip_exp_rf_stamps_f64(void *out, size_t bytes)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(kofft::g_rf_stamps), bytes) == hipSuccess ? 0 : -1;
+}
+#endif
