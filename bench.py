@@ -49,7 +49,13 @@ WORKLOADS = {
     "rfft2048": "batched 2^20 x 2048-pt f32 rfft + Hann (BASELINE config #3)",
     "stft1024": "STFT 28.8M-sample f32 stream, 1024-pt Hann, hop 256 (BASELINE config #4, frames sharded)",
     "c64_2p20": "batched 1024 x 2^20-pt Complex64 forward FFT (BASELINE config #5)",
+    # built, parity-tested; measured here with the same protocol (N = 1)
+    "istft1024": "ISTFT of config #4's spectra: 112500 x 1024-pt c32 frames, Hann, hop 256 (stft.rs:117-156, SURVEY 8f row 1)",
+    "magnitudes1024": "stft_magnitudes of config #4's stream: 1024-pt Hann, hop 256, 512 bins per frame (visual/spectrogram.rs:52-76, 8f row 2)",
+    "fft2d_4096": "fft2d_inplace of one 4096 x 4096 Complex32 image (ndfft.rs:74-101, 8f row 3)",
+    "bluestein1000": "batched 65536 x 1000-pt Complex32 forward FFT, Bluestein arm (fft.rs:1088-1132, 8f row 4)",
 }
+F_ROWS = ("istft1024", "magnitudes1024", "fft2d_4096", "bluestein1000")
 
 
 def parse(argv=None):
@@ -334,6 +340,7 @@ class Workload:
         import kofft_amd
 
         self.name = name
+        self.prep = None  # untimed per-step restore of an input the call consumes (istft)
         gen = torch.Generator(device=dev)
         gen.manual_seed(0x6B6F666674 + 2 + rank)
         self.allgather = None
@@ -378,6 +385,85 @@ class Workload:
                         "passes_over_hbm": 2}
             self.dtype, self.scaling = "f64", "weak"
             self.kernels_per_step = None  # several kernels per step: see roofline.kernels_per_step in the line
+        elif name in ("istft1024", "magnitudes1024"):
+            total_len, win_len, hop = 28_800_000, 1024, 256
+            frames = -(-total_len // hop)
+            sgen = torch.Generator(device=dev)
+            sgen.manual_seed(0x6B6F666674 + 4)
+            t = torch.arange(total_len, dtype=torch.float32, device=dev)
+            sig = 0.5 * torch.sin(2 * np.pi * 440.0 * t / 48000.0) + 0.25 * torch.empty_like(t).uniform_(-1, 1, generator=sgen)
+            del t
+            self.dtype, self.scaling, self.kernels_per_step = "f32", "weak", None
+            if name == "istft1024":
+                win = torch.from_numpy(kofft_amd.hann(win_len)).to(dev)
+                spec = torch.empty((frames, win_len, 2), dtype=torch.float32, device=dev)
+                fft32.stft_dev(sig.data_ptr(), total_len, win.data_ptr(), win_len, hop, spec.data_ptr(), 0, frames)
+                out_len = (frames - 1) * hop + win_len
+                out = torch.zeros(out_len, dtype=torch.float32, device=dev)
+                scratch = torch.zeros(out_len, dtype=torch.float32, device=dev)
+                work = spec.clone()
+
+                def prep():  # untimed: istft transforms its frames in place and accumulates into `output` (stft.rs:141-155)
+                    work.copy_(spec)
+                    out.zero_()
+                self.prep = prep
+                self.units_per_step = frames * win_len           # spectrum points in
+                # compulsory traffic: frames read and written back (the reference leaves the time-domain frames in the caller's
+                # buffer), output and window-square sums written
+                self.alg_bytes = 2 * 8 * self.units_per_step + 2 * 4 * out_len
+                self.unit = "GPoints/s"
+                self.metric = "ISTFT 1024-pt Hann hop-256 throughput (spectrum points in)"
+                self.launch = lambda: fft32.istft_dev(work.data_ptr(), frames, win.data_ptr(), win_len, hop, out.data_ptr(), out_len,
+                                                      scratch.data_ptr())
+                self.cfg = {"workload": WORKLOADS[name], "frames": frames, "win_len": win_len, "hop": hop, "out_len": out_len,
+                            "kernels": "batched in-place ifft of the frames + ordered overlap-add (no atomics)"}
+                self._keep = (sig, win, spec, work, out, scratch)
+            else:
+                bins = win_len // 2
+                mags = torch.empty((frames, bins), dtype=torch.float32, device=dev)
+                mx = torch.zeros(1, dtype=torch.float32, device=dev)
+                self.units_per_step = frames * bins               # magnitudes out
+                self.alg_bytes = 4 * total_len + 4 * self.units_per_step
+                self.unit = "GMagnitudes/s"
+                self.metric = "stft_magnitudes 1024-pt Hann hop-256 throughput (magnitudes out)"
+                self.launch = lambda: fft32.stft_magnitudes_dev(sig.data_ptr(), total_len, win_len, hop, mags.data_ptr(), frames, mx.data_ptr())
+                self.cfg = {"workload": WORKLOADS[name], "signal_len": total_len, "win_len": win_len, "hop": hop, "frames": frames,
+                            "bins_per_frame": bins, "kernels": "one: STFT with the magnitude and the running maximum fused into the store"}
+                self.kernels_per_step = 1
+                self._keep = (sig, mags, mx)
+            return
+        elif name == "fft2d_4096":
+            rows = cols = 4096
+            img = torch.empty((rows, cols, 2), dtype=torch.float32, device=dev).uniform_(-1.0, 1.0, generator=gen)
+            self.units_per_step = rows * cols
+            self.alg_bytes = 16 * self.units_per_step            # the image read once and written once
+            self.unit = "GPoints/s"
+            self.metric = "fft2d_inplace 4096 x 4096 c32 throughput"
+            state = {"inv": False}
+
+            def launch2d():  # forward and inverse alternate so that the in-place values stay bounded; both directions cost the same
+                fft32.fftnd_dev(img.data_ptr(), 1, rows, cols, state["inv"])
+                state["inv"] = not state["inv"]
+            self.launch = launch2d
+            self.cfg = {"workload": WORKLOADS[name], "rows": rows, "cols": cols, "direction": "forward / inverse alternating, in place",
+                        "passes_over_hbm": "rows: 1; columns: see DESIGN 5.7"}
+            self.dtype, self.scaling, self.kernels_per_step = "f32", "weak", None
+            self._keep = (img,)
+            return
+        elif name == "bluestein1000":
+            n, batch = 1000, batch_override or 65536
+            src = torch.empty((batch, n, 2), dtype=torch.float32, device=dev).uniform_(-1.0, 1.0, generator=gen)
+            dst = torch.empty_like(src)
+            self.units_per_step = batch * n
+            self.alg_bytes = 16 * self.units_per_step
+            self.unit = "GPoints/s"
+            self.metric = "batched 1000-pt c32 FFT (Bluestein arm) throughput"
+            self.launch = lambda: fft32.fft_dev_oop(src.data_ptr(), dst.data_ptr(), n, batch, False)
+            self.cfg = {"workload": WORKLOADS[name], "n": n, "m": 2048, "batch_per_gpu": batch,
+                        "kernels": "one: both 2048-pt transforms and the three pointwise products in registers + LDS"}
+            self.dtype, self.scaling, self.kernels_per_step = "f32", "weak", 1
+            self._keep = (src, dst)
+            return
         else:
             total_len, win_len, hop = 28_800_000, 1024, 256
             from kofft_amd.dist import frames_required, shard_range
@@ -403,6 +489,29 @@ class Workload:
             self.kernels_per_step = 1
             self._gather = (frames_total, win_len, count, dst)
         self._keep = (src, dst) if name != "stft1024" else (sig, win, dst)
+
+    def time_inplace(self, fft32, stream, dev, steps=10):
+        """fft4096 only: the same batch transformed IN PLACE -- what FftImpl::fft(&mut [Complex<T>]) is (fft.rs:1054; SURVEY 8d states
+        config #2 in place).  The timed steps of the headline write a second buffer because repeated in-place forward transforms of
+        O(1) data overflow f32 after ~10 steps; here the data start at 1e-18 and grow by ~64x (sqrt n) per step over 2 + `steps`
+        steps, so every value stays a normal f32.  Same kernel, same bytes; HIP events on the launch stream."""
+        import torch
+
+        src, dst = self._keep
+        n, batch = self.cfg["n"], self.cfg["batch_per_gpu"]
+        torch.mul(src, 1e-18, out=dst)
+        for _ in range(2):
+            fft32.fft_dev(dst.data_ptr(), n, batch, False)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(steps):
+            fft32.fft_dev(dst.data_ptr(), n, batch, False)
+        e1.record(stream)
+        torch.cuda.synchronize(dev)
+        ms = e0.elapsed_time(e1) / steps
+        finite = bool(torch.isfinite(dst[:64]).all().item())
+        return {"inplace_ms_per_step": ms, "inplace_frac": self.alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "steps": steps,
+                "values_finite": finite}
 
     def shard_kernel_ms(self, fft32, stream, dev, worlds=(1, 2, 4, 8), reps=200):
         """Kernel time of rank 0's frame shard for each world size, on THIS one GPU: what compute-only strong scaling of
@@ -470,10 +579,14 @@ def measure(w: Workload, steps, warmup, ramp_ms, min_seconds, dev, stream, barri
     t_ramp = time.perf_counter()
     while (time.perf_counter() - t_ramp) * 1e3 < ramp_ms:  # clock ramp (untimed, not counted as warm-up steps)
         for _ in range(8):
+            if w.prep is not None:
+                w.prep()
             w.launch()
             launches += 1
         torch.cuda.synchronize(dev)
     for _ in range(warmup):
+        if w.prep is not None:
+            w.prep()
         w.launch()
         launches += 1
     torch.cuda.synchronize(dev)
@@ -487,6 +600,8 @@ def measure(w: Workload, steps, warmup, ramp_ms, min_seconds, dev, stream, barri
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for i in range(steps):
+            if w.prep is not None:
+                w.prep()               # restores an input the call consumes: outside the event pair
             starts[i].record(stream)   # HIP events on the stream the kernels are launched on
             w.launch()
             ends[i].record(stream)
@@ -506,6 +621,8 @@ def measure(w: Workload, steps, warmup, ramp_ms, min_seconds, dev, stream, barri
     kern_ms = kern_ms_all[mid]
     total_units = reduce_sum(float(w.units_per_step)) * steps
     avg_kernel_s = float(np.mean(kern_ms)) / 1e3
+    if w.prep is not None:
+        elapsed = avg_kernel_s * steps  # the block's wall time contains the untimed restores: the steps' own HIP-event time instead
     achieved = w.alg_bytes / avg_kernel_s / 1e9
     traffic, traffic_from, traffic_stale = None, None, None
     tfile = ROOT / "profiles" / f"traffic_{w.name}.json"
@@ -617,6 +734,12 @@ def run_rank(args) -> None:
     w = Workload(args.workload, args, rank, world, dev, stream, fft32, fft64, args.batch)
     head = measure(w, args.steps, args.warmup, args.ramp_ms, args.min_seconds, dev, stream, barrier, reduce_max, reduce_sum, launches)
     allgather = w.time_allgather(dist, dev, world, barrier) if (args.workload == "stft1024" and world > 1) else None
+    inplace = None
+    if args.workload == "fft4096" and not args.inplace and not args.batch:
+        try:
+            inplace = w.time_inplace(fft32, stream, dev)
+        except Exception as e:  # informational: never at the cost of the line
+            inplace = {"error": f"{type(e).__name__}: {e}"}
     del w
     torch.cuda.empty_cache()
 
@@ -626,6 +749,8 @@ def run_rank(args) -> None:
         # every BASELINE config at every N: #3 and #5 shard by batch with no collective (weak), #4 by frames (strong; its
         # all-gather timed apart).  stft1024 first: should the watchdog fire during a later extra, nothing is lost but it.
         extra_names = [k for k in ("stft1024", "rfft2048", "c64_2p20") if k != args.workload]
+        if world == 1:
+            extra_names += list(F_ROWS)  # one GPU, same protocol
     # The headline exists from here on.  The extra workloads (at N > 1: the RCCL all-gather of config 4) must never cost the
     # line: if they have not finished after --extras-timeout seconds (a collective that hangs cannot be caught as an
     # exception), rank 0 prints the headline alone and the process ends -- still exactly one JSON line.
@@ -636,6 +761,7 @@ def run_rank(args) -> None:
             "vs_baseline": None, "dtype": head["dtype"], "data": "synthetic", "config": head["config"], "roofline": head["roofline"],
             "blocks": head["blocks"], "blocks_ms_per_step": head["blocks_ms_per_step"], "launches_total": launches[0],
             "launcher": "self" if os.environ.get("KOFFT_BENCH_LAUNCHED") else ("torchrun" if world > 1 else "single"),
+            **({"inplace": inplace} if inplace is not None else {}),
             **({"rehearsal": "every rank on cuda:0, gloo process group: NOT a measurement"} if args.rehearse_one_card else {}),
         }
 
@@ -659,7 +785,7 @@ def run_rank(args) -> None:
     for name in extra_names:
         try:
             we = Workload(name, args, rank, world, dev, stream, fft32, fft64)
-            steps_e = max(5, min(args.steps, 20)) if name == "c64_2p20" else args.steps
+            steps_e = max(5, min(args.steps, 20)) if name in ("c64_2p20", "istft1024") else args.steps
             r = measure(we, steps_e, min(args.warmup, 5), args.ramp_ms, min(args.min_seconds, 1.0), dev, stream, barrier, reduce_max, reduce_sum)
             r["steps"] = steps_e
             if name == "stft1024" and world > 1:

@@ -158,6 +158,8 @@ int launch_sub(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, int LS, size_
     switch (LS) {
     // 16 (c32) / 8 (c64) adjacent columns or rows per workgroup = 128-byte segments while the tile fits the LDS budget
     // (sub-transforms up to 2^9 points; 2^10: 8; larger ones fewer still -- big_block).
+    case 5: return launch_wg<T, 5, EPI_STORE, IO, big_block<T, IO, 5>()>(ctx, io, tw, units);  // (ndfft's two-pass axes only)
+    case 6: return launch_wg<T, 6, EPI_STORE, IO, big_block<T, IO, 6>()>(ctx, io, tw, units);
     case 7: return launch_sub_one_tile<T, 7, IO>(ctx, io, tw, units);
     case 8: return launch_sub_one_tile<T, 8, IO>(ctx, io, tw, units);
     case 9: return launch_sub_one_tile<T, 9, IO>(ctx, io, tw, units);
@@ -190,6 +192,68 @@ int launch_mid(kofft_hip_ctx *ctx, const BigMidIO<T> &io, const cpx<T> *tw, int 
     case 9: return launch_wg<T, 9, EPI_STORE, BigMidIO<T>, big_block<T, BigMidIO<T>, 9>()>(ctx, io, tw, units);
     default: return KOFFT_ERR_UNSUPPORTED;
     }
+}
+
+// ndfft's long strided axes (ndfft.rs:89-98, 131-151) in two column-tile passes: see AxisLastIO (fft_big.hip.h).
+// blocks dense [2^LT][2^I] arrays, in place through the context's real_tmp scratch.
+template <typename T, bool INVERSE>
+int fft_axis2_core(kofft_hip_ctx *ctx, cpx<T> *data, int LT, int I, size_t blocks, int L1)
+{
+    const size_t len = size_t(1) << LT, block_elems = len << I, block_bytes = block_elems * sizeof(cpx<T>);
+    const cpx<T> *tw = nullptr;
+    int rc = get_table<T>(ctx, Kind<T>::tw, len, &tw);
+    if (rc) return rc;
+    size_t chunk = (size_t(512) << 20) / block_bytes;
+    if (chunk < 1) chunk = 1;
+    if (chunk > blocks) chunk = blocks;
+    rc = ensure_real_tmp(ctx, chunk * block_bytes);
+    if (rc) return rc;
+    cpx<T> *mid = static_cast<cpx<T> *>(ctx->real_tmp);
+    const int LS = LT - L1;
+    const T scale = (T)1 / (T)(float)len;
+    for (size_t b0 = 0; b0 < blocks; b0 += chunk) {
+        const size_t nb = blocks - b0 < chunk ? blocks - b0 : chunk;
+        cpx<T> *blk = data + b0 * block_elems;
+        BigColsIO<T, INVERSE> a{blk, mid, LS + I, LS, block_elems};
+        rc = launch_sub<T>(ctx, a, tw, L1, nb << (LS + I), ctx->big_persist);
+        if (rc) return rc;
+        AxisLastIO<T, INVERSE> m{mid, blk, L1, LS, I, LT - LS, LT - 1 - L1, block_elems, scale};
+        const size_t units = nb << (L1 + I);
+        rc = KOFFT_ERR_UNSUPPORTED;
+        if (ctx->big_persist && units >= (size_t)ctx->num_cus * ctx->big_persist_min_units) {
+            switch (LS) {
+            case 7: rc = launch_tile_persist<T, 7, AxisLastIO<T, INVERSE>>(ctx, m, tw, units); break;
+            case 8: rc = launch_tile_persist<T, 8, AxisLastIO<T, INVERSE>>(ctx, m, tw, units); break;
+            default: break;
+            }
+        }
+        if (rc == KOFFT_ERR_UNSUPPORTED) {
+            switch (LS) {
+#define KOFFT_CASE(LL) \
+    case LL: rc = launch_wg<T, LL, EPI_STORE, AxisLastIO<T, INVERSE>, big_block<T, AxisLastIO<T, INVERSE>, LL>()>(ctx, m, tw, units); break;
+                KOFFT_CASE(5)
+                KOFFT_CASE(6)
+                KOFFT_CASE(7)
+                KOFFT_CASE(8)
+#undef KOFFT_CASE
+            default: break;
+            }
+        }
+        if (rc) return rc;
+    }
+    return KOFFT_OK;
+}
+
+template <typename T>
+int fft_axis2_dev(kofft_hip_ctx *ctx, T *d_data, int LT, int I, size_t blocks, int inverse)
+{
+    // 2^12 = 2^7 x 2^5, 2^13 = 2^7 x 2^6, 2^14 = 2^7 x 2^7: the first pass on the persistent prefetching tile kernel (4096 x 4096 c32,
+    // same box: transposes 0.224 ms, 2^5 x 2^7 0.169-0.173, 2^6 x 2^6 0.178, 2^7 x 2^5 0.149; KOFFT_HIP_ND_TWO_PASS_L1 overrides: A/B)
+    int L1 = 7;
+    if (ctx->nd_two_pass_l1 >= 5 && ctx->nd_two_pass_l1 <= 8 && LT - ctx->nd_two_pass_l1 >= 5 && LT - ctx->nd_two_pass_l1 <= 8) L1 = ctx->nd_two_pass_l1;
+    if (L1 < 5 || L1 > 8 || LT - L1 < 5 || LT - L1 > 8) return KOFFT_ERR_UNSUPPORTED;
+    cpx<T> *data = reinterpret_cast<cpx<T> *>(d_data);
+    return inverse ? fft_axis2_core<T, true>(ctx, data, LT, I, blocks, L1) : fft_axis2_core<T, false>(ctx, data, LT, I, blocks, L1);
 }
 
 template <typename T>

@@ -268,6 +268,65 @@ struct BigMidIO {
     }
 };
 
+// ndfft's long strided axes in TWO column-tile passes (round 4): a dense [2^LT][2^I] block, every column a stand-alone 2^LT-point
+// transform with ITS table T_{2^LT} (what fft_strided's gather / fft / scatter computes, ndfft.rs:89-98, 131-151).  Stages
+// 0 .. L1-1 are BigColsIO above with LB = (LT - L1) + I untouched low bits and the table shift LT - L1; the remaining LS = LT - L1
+// stages are this policy: BigMidIO's index algebra -- [K : S = L1][c : LS][j : JB = I] -> [q : LS][K][j], entries
+// T[(idx_local << (LT - LS)) + (K << (LT - 1 - S - s_local))] -- as the LAST pass: ifft's conj, * 1/len on the way out
+// (fft.rs:1168-1172) and streaming stores.  Three passes over the image for a 2-D transform instead of four (transpose, rows,
+// transpose), 128-byte segments in each.
+template <typename T, bool INVERSE>
+struct AxisLastIO {
+    static constexpr bool kStreams = false;
+    static constexpr bool kPersist = false;
+    static constexpr bool kSlotMinor = true;
+    static constexpr bool kPairXcd = true;
+    static constexpr bool kSplitLds = sizeof(T) == 8;
+    static constexpr int kMinWaves = sizeof(T) == 8 ? 4 : 1;
+    const cpx<T> *__restrict__ in;
+    cpx<T> *__restrict__ out;
+    int S, LS, JB;
+    int shift;  // LT - LS
+    int kbase;  // LT - 1 - S
+    size_t n;   // elements per block: 2^(LT + I)
+    T scale;    // 1 / (len as f32 as T)
+    static constexpr bool nt = true;
+    __device__ __forceinline__ TwSub tw_map(size_t xf) const { return TwSub{shift, (int)((xf >> JB) & ((size_t(1) << S) - 1)), kbase}; }
+    static constexpr bool kConjIn = false, kConjScaleOut = INVERSE, kNtOut = true;
+    static constexpr bool kTileInvariantTw = false;
+    static constexpr bool kTileGroupTw = true;
+    int tpg = 1;
+    __device__ __forceinline__ bool nt_in() const { return true; }
+    __device__ __forceinline__ T out_scale() const { return scale; }
+    __device__ __forceinline__ size_t xf_transform(size_t xf) const { return xf >> (S + JB); }
+    __device__ __forceinline__ unsigned in_off(size_t xf) const
+    {
+        const size_t K = (xf >> JB) & ((size_t(1) << S) - 1), j = xf & ((size_t(1) << JB) - 1);
+        return (unsigned)((K << (LS + JB)) + j);
+    }
+    __device__ __forceinline__ int in_sl() const { return JB; }
+    __device__ __forceinline__ unsigned out_off(size_t xf) const
+    {
+        const size_t K = (xf >> JB) & ((size_t(1) << S) - 1), j = xf & ((size_t(1) << JB) - 1);
+        return (unsigned)((K << JB) + j);
+    }
+    __device__ __forceinline__ int out_sl() const { return S + JB; }
+    __device__ __forceinline__ cpx<T> load(size_t xf, int c) const
+    {
+        const size_t b = xf >> (S + JB), K = (xf >> JB) & ((size_t(1) << S) - 1), j = xf & ((size_t(1) << JB) - 1);
+        return ld_stream(in + b * n + (K << (LS + JB)) + ((size_t)c << JB) + j);
+    }
+    __device__ __forceinline__ void store(size_t xf, int q, cpx<T> v) const
+    {
+        const size_t b = xf >> (S + JB), K = (xf >> JB) & ((size_t(1) << S) - 1), j = xf & ((size_t(1) << JB) - 1);
+        if (INVERSE) {  // conj, then scale (fft.rs:1168-1172)
+            const T im = -v.im;
+            v = mk<T>(v.re * scale, im * scale);
+        }
+        st_stream(out + b * n + ((size_t)q << (S + JB)) + (K << JB) + j, v);
+    }
+};
+
 // ---- persistent, prefetching form of the factor kernels --------------------------------------------------------------
 // One workgroup per CU walks the tiles (a tile = XPB adjacent units = XPB adjacent columns / rows of ONE transform) with a
 // stride of the grid.  The next tile's loads are issued into a second register set before the current tile is computed,

@@ -15,6 +15,13 @@ int fft_axis_dev(kofft_hip_ctx *ctx, T *d_data, size_t len, size_t lines, size_t
     // on it, transpose back -- four coalesced passes instead of two scattered ones (4096 x 4096 c32: 0.45 -> 0.2x ms).
     // Every line still goes through the same 1-D transform, so the results are unchanged.
     // ... and the only route for axis lengths the strided kernel does not cover (non-powers of two: Bluestein; beyond 2^14)
+    // Power-of-two axes of 2^12 .. 2^14 points (2^13 in f64) over a power-of-two number of adjacent lines: two column-tile passes
+    // with the axis's own table instead of transpose -> rows -> transpose (round 4: one pass over the data less; AxisLastIO).
+    if (stride == inner && ctx->nd_two_pass && fused_len_ok<T>(len) && len >= 4096 && is_pow2(inner) &&
+        inner >= (size_t)KOFFT_BIG_XPB(T) && lines % inner == 0 && (lines == inner || outer_stride == len * inner) &&
+        lines * len * sizeof(cpx<T>) >= (size_t(16) << 20) && len * inner * sizeof(cpx<T>) <= (size_t(1) << 31)) {  // (32-bit buffer descriptors per block)
+        return fft_axis2_dev<T>(ctx, d_data, ilog2(len), ilog2(inner), lines / inner, inverse);
+    }
     if (stride == inner && (!fused_len_ok<T>(len) || (ctx->nd_transpose && len >= (size_t)ctx->nd_transpose_min && lines * len * sizeof(cpx<T>) >= (size_t(16) << 20)))) {
         const size_t outer = lines / inner;  // dense [len][inner] blocks, outer_stride apart
         const size_t cap = size_t(1) << 30, col_bytes = len * sizeof(cpx<T>);

@@ -507,6 +507,8 @@ int kofft_hip_create(int device, kofft_hip_ctx **out)
     if (const char *e = getenv("KOFFT_HIP_BIG_MID_GROUP")) ctx->big_mid_group = !(e[0] == '0');
     if (const char *e = getenv("KOFFT_HIP_BIG_FIRST11")) ctx->big_first11 = !(e[0] == '0');
     if (const char *e = getenv("KOFFT_HIP_BIG_NARROW_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 16) ctx->big_narrow_per_cu = v; }
+    if (const char *e = getenv("KOFFT_HIP_ND_TWO_PASS")) ctx->nd_two_pass = !(e[0] == '0');
+    if (const char *e = getenv("KOFFT_HIP_ND_TWO_PASS_L1")) ctx->nd_two_pass_l1 = atoi(e);
     if (const char *e = getenv("KOFFT_HIP_ND_TRANSPOSE_MIN")) ctx->nd_transpose_min = atoi(e);
     if (const char *e = getenv("KOFFT_HIP_HOST_CHUNKS")) ctx->host_chunks = atoi(e);
     if (const char *e = getenv("KOFFT_HIP_BIG_BLOCKED")) ctx->big_blocked = !(e[0] == '0');
