@@ -84,6 +84,9 @@ def parse(argv=None):
                          "N-rank protocol (launcher, barriers, reductions, sharding, gather) can run on a one-GPU box")
     ap.add_argument("--dry-launch", action="store_true",
                     help="launcher self-test: every rank prints its rendezvous environment and exits without touching a GPU")
+    ap.add_argument("--dry-protocol", action="store_true",
+                    help="with --dry-launch: the ranks also rendezvous (gloo, CPU), run the barrier / all-reduce steps of the timing "
+                         "protocol, and rank 0 prints ONE line with the real line's keys (values null): the N-rank contract without a GPU")
     return ap.parse_args(argv)
 
 
@@ -191,10 +194,50 @@ def launch_ranks(n: int, argv: list[str]) -> int:
     return 0
 
 
-def dry_rank() -> None:
-    """--dry-launch: what this rank was given, no GPU call, no torch import."""
-    print(json.dumps({"dry_launch": True, **{k: os.environ.get(k) for k in RANK_ENV},
-                      "pid": os.getpid(), "torch_imported": "torch" in sys.modules}), flush=True)
+def extra_workload_names(workload: str, world: int) -> list[str]:
+    """The workloads a default run carries beside the headline: every other BASELINE config at every N (#3 and #5 shard by batch with no
+    collective, #4 by frames with its all-gather timed apart; stft1024 first: should the watchdog fire during a later extra, nothing is
+    lost but it), and at N = 1 the SURVEY 8(f) rows."""
+    names = [k for k in ("stft1024", "rfft2048", "c64_2p20") if k != workload]
+    if world == 1:
+        names += list(F_ROWS)
+    return names
+
+
+def dry_rank(args) -> None:
+    """--dry-launch: what this rank was given, no GPU call, no torch import.  With --dry-protocol the ranks then meet for real (gloo on
+    127.0.0.1), run the collective steps of the protocol, and rank 0 prints the line's skeleton."""
+    info = {"dry_launch": True, **{k: os.environ.get(k) for k in RANK_ENV}, "pid": os.getpid(), "torch_imported": "torch" in sys.modules}
+    if not args.dry_protocol:
+        print(json.dumps(info), flush=True)
+        return
+    import torch
+    import torch.distributed as dist
+
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    n_seen = 1
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        ones = torch.ones(1, dtype=torch.float64)
+        dist.all_reduce(ones)
+        n_seen = int(round(float(ones.item())))
+        dist.barrier()
+        t = torch.tensor([float(rank)], dtype=torch.float64)  # the MAX-over-ranks reduction of the timing protocol
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert int(t.item()) == world - 1
+    if rank == 0:
+        extras_on = args.extras if args.extras is not None else (args.workload == "fft4096" and not args.batch and not args.inplace)
+        line = {"metric": None, "value": None, "unit": None, "n_gpus": n_seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+                "higher_is_better": True, "scaling": None, "vs_baseline": None, "dtype": None, "data": "synthetic",
+                "config": {"workload": WORKLOADS[args.workload]}, "roofline": None,
+                "launcher": "self" if os.environ.get("KOFFT_BENCH_LAUNCHED") else ("torchrun" if world > 1 else "single"),
+                "workloads": {k: None for k in extra_workload_names(args.workload, world)} if extras_on else None,
+                "cpu_baseline": None, "dry_protocol": True, **info}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -748,9 +791,7 @@ def run_rank(args) -> None:
     if extras_on:
         # every BASELINE config at every N: #3 and #5 shard by batch with no collective (weak), #4 by frames (strong; its
         # all-gather timed apart).  stft1024 first: should the watchdog fire during a later extra, nothing is lost but it.
-        extra_names = [k for k in ("stft1024", "rfft2048", "c64_2p20") if k != args.workload]
-        if world == 1:
-            extra_names += list(F_ROWS)  # one GPU, same protocol
+        extra_names = extra_workload_names(args.workload, world)
     # The headline exists from here on.  The extra workloads (at N > 1: the RCCL all-gather of config 4) must never cost the
     # line: if they have not finished after --extras-timeout seconds (a collective that hangs cannot be caught as an
     # exception), rank 0 prints the headline alone and the process ends -- still exactly one JSON line.
@@ -830,7 +871,7 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(launch_ranks(args.gpus, argv))  # the parent: no torch, no GPU call
     if args.dry_launch:
-        dry_rank()
+        dry_rank(args)
         return
     run_rank(args)
 

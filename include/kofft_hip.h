@@ -276,6 +276,15 @@ int kofft_hip_multi_stft_slice(const kofft_hip_multi *m, size_t len, size_t win_
 int kofft_hip_multi_context(const kofft_hip_multi *m, int rank, kofft_hip_ctx **ctx, void **hip_stream);
 int kofft_hip_multi_synchronize(kofft_hip_multi *m);
 int kofft_hip_multi_last_timing(const kofft_hip_multi *m, float *compute_ms, float *gather_ms);
+/* The exchange of the STFT spectra (BASELINE config #4; the device analogue of collecting stft::parallel's frames, stft.rs:232-263)
+ * has two forms over the same partition and the same buffers: RCCL (one grouped in-place ncclAllGather per device) and DIRECT
+ * (every device pushes its slot to every peer with hipMemcpyPeerAsync on a stream per peer: no RCCL needed, and the direct
+ * pattern on point-to-point xGMI whatever RCCL would choose).  Default RCCL, or KOFFT_HIP_MULTI_GATHER=direct at creation;
+ * `last` = the form the last call ran (0: it had no exchange). */
+#define KOFFT_MULTI_GATHER_RCCL 1
+#define KOFFT_MULTI_GATHER_DIRECT 2
+int kofft_hip_multi_set_gather(kofft_hip_multi *m, int mode);
+int kofft_hip_multi_gather_mode(const kofft_hip_multi *m, int *configured, int *last);
 int kofft_hip_multi_last_timing_ex(const kofft_hip_multi *m, float *upload_ms, float *kernel_ms, float *gather_ms,
                                    float *download_ms, float *wall_ms);
 int kofft_hip_multi_stft_f32(kofft_hip_multi *m, const float *signal, size_t len, const float *window, size_t win_len,

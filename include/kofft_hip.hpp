@@ -563,6 +563,14 @@ public:
         kofft_hip_multi_last_timing_ex(h_, &t.upload_ms, &t.kernel_ms, &t.gather_ms, &t.download_ms, &t.wall_ms);
         return t;
     }
+    // the exchange form: KOFFT_MULTI_GATHER_RCCL (grouped ncclAllGather) or KOFFT_MULTI_GATHER_DIRECT (peer copies on per-peer streams)
+    Result set_gather(int mode) { return st(kofft_hip_multi_set_gather(h_, mode)); }
+    int last_gather() const
+    {
+        int last = 0;
+        kofft_hip_multi_gather_mode(h_, nullptr, &last);
+        return last;
+    }
     kofft_hip_multi *raw() const { return h_; }
 
 private:

@@ -57,6 +57,8 @@ extern "C" {
     fn kofft_hip_multi_synchronize(m: *mut KofftHipMulti) -> c_int;
     fn kofft_hip_multi_last_timing_ex(m: *const KofftHipMulti, upload_ms: *mut f32, kernel_ms: *mut f32, gather_ms: *mut f32,
                                       download_ms: *mut f32, wall_ms: *mut f32) -> c_int;
+    fn kofft_hip_multi_set_gather(m: *mut KofftHipMulti, mode: c_int) -> c_int;
+    fn kofft_hip_multi_gather_mode(m: *const KofftHipMulti, configured: *mut c_int, last: *mut c_int) -> c_int;
     // device-resident twins: one device pointer per device, asynchronous
     fn kofft_hip_multi_fft_c32_dev(m: *mut KofftHipMulti, d_data_per_gpu: *const *mut f32, n: usize, batch: usize, inverse: c_int) -> c_int;
     fn kofft_hip_multi_fft_c64_dev(m: *mut KofftHipMulti, d_data_per_gpu: *const *mut f64, n: usize, batch: usize, inverse: c_int) -> c_int;
@@ -422,6 +424,16 @@ impl HipMulti {
     }
     pub fn synchronize(&self) -> Result<(), FftError> {
         self.check(unsafe { kofft_hip_multi_synchronize(self.h) })
+    }
+    /// 1 = RCCL (grouped in-place ncclAllGather), 2 = direct (peer copies on a stream per peer)
+    pub fn set_gather(&self, mode: i32) -> Result<(), FftError> {
+        self.check(unsafe { kofft_hip_multi_set_gather(self.h, mode as c_int) })
+    }
+    /// the form the last call's exchange ran (0: it had none)
+    pub fn last_gather(&self) -> i32 {
+        let mut last: c_int = 0;
+        unsafe { kofft_hip_multi_gather_mode(self.h, std::ptr::null_mut(), &mut last) };
+        last as i32
     }
     pub fn last_timing(&self) -> MultiTiming {
         let mut t = MultiTiming::default();

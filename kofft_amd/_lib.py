@@ -98,6 +98,8 @@ SIGNATURES = {
     "kofft_hip_multi_context": (C.c_int, [_ctx, C.c_int, C.POINTER(_ctx), C.POINTER(C.c_void_p)]),
     "kofft_hip_multi_synchronize": (C.c_int, [_ctx]),
     "kofft_hip_multi_last_timing_ex": (C.c_int, [_ctx] + [C.POINTER(C.c_float)] * 5),
+    "kofft_hip_multi_set_gather": (C.c_int, [_ctx, C.c_int]),
+    "kofft_hip_multi_gather_mode": (C.c_int, [_ctx, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
 }
 
 _lib = None

@@ -328,6 +328,7 @@ __device__ __forceinline__ void persist_transform(const typename persist_raw<IO,
             constexpr int LINE = 128 / (int)sizeof(cpx<T>);
             constexpr int ROW = N + 1;
             constexpr int SLOT = persist_slot_elems(L);
+            static_assert(NBUF == 1, "the group's slots are addressed SLOT apart (gy + r * SLOT): with NBUF buffers per slot they would be NBUF * SLOT apart");
             constexpr int S = (GRP * ROW + LINE - 1 + 63) / 64;
             const int a = io.row_misalign(xf0) & (LINE - 1);  // wave-uniform
             const rsrc_t od = io.out_desc_back_n(xf0, cnt, LINE);

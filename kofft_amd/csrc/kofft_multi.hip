@@ -125,6 +125,13 @@ class Workers {
 public:
     bool start(const std::vector<int> &devices)
     {
+        {   // a failed start() ran stop(): begin from a clean state, or the new threads would see quit_ and leave at once
+            std::lock_guard<std::mutex> lk(mu_);
+            quit_ = false;
+            generation_ = 0;
+            pending_ = 0;
+            job_ = nullptr;
+        }
         n_ = (int)devices.size();
         rc_.assign(n_, 0);
         try {
@@ -168,7 +175,10 @@ public:
 private:
     void loop(int r, int device)
     {
-        (void)hipSetDevice(device);  // thread-local: the caller's current device is never touched by a worker
+        // thread-local: the caller's current device is never touched by a worker.  If it fails, every job of this worker fails
+        // (its HIP calls would land on another device).
+        const bool device_ok = hipSetDevice(device) == hipSuccess;
+        if (!device_ok) (void)hipGetLastError();
         unsigned long long seen = 0;
         for (;;) {
             const std::function<int(int)> *job;
@@ -181,7 +191,7 @@ private:
             }
             int rc;
             try {
-                rc = (*job)(r);
+                rc = device_ok ? (*job)(r) : KOFFT_ERR_HIP;
             } catch (...) {
                 rc = KOFFT_ERR_ALLOC;
             }
@@ -213,7 +223,13 @@ struct kofft_hip_multi {
     std::vector<hipStream_t> stream;
     std::vector<DevBuf> sig, win, out;       // per-device input (slice / rows), window, output (shard or gathered)
     std::vector<hipEvent_t> ev[5];           // t0 .. t4 of the header comment
-    std::vector<nccl_comm_t> comms;          // created at the first gather
+    std::vector<nccl_comm_t> comms;          // created at the first RCCL gather
+    // the exchange of the STFT spectra: 1 = one grouped in-place ncclAllGather per device, 2 = direct: every device pushes its slot
+    // to every peer with hipMemcpyPeerAsync on its own per-peer stream (KOFFT_HIP_MULTI_GATHER=direct / kofft_hip_multi_set_gather)
+    int gather_mode = 1, last_gather = 0;
+    std::vector<hipStream_t> peer_stream;    // [r * ngpu + p], on device r; created at the first direct gather
+    std::vector<hipEvent_t> peer_done;       // [r * ngpu + p]: the copy r -> p has finished
+    bool peers_up = false;
     std::vector<std::string> dev_error;      // written by worker r only
     std::string last_error;
     Workers workers;
@@ -317,6 +333,8 @@ int ensure_workers(kofft_hip_multi *m)
 // host buffers: drain every stream first (errors of the drain itself are ignored, the first error is the one reported).
 void drain_all(kofft_hip_multi *m)
 {
+    for (hipStream_t ps : m->peer_stream)
+        if (ps) (void)hipStreamSynchronize(ps);
     for (int r = 0; r < m->ngpu; ++r)
         if (m->stream[r]) (void)hipStreamSynchronize(m->stream[r]);
     (void)hipGetLastError();
@@ -339,6 +357,7 @@ void begin_call(kofft_hip_multi *m, bool upload, bool gather, bool download)
     m->had_gather = gather;
     m->had_download = download;
     m->wall_ms = 0.0f;
+    m->last_gather = 0;
     m->last_error.clear();
     for (std::string &s : m->dev_error) s.clear();
 }
@@ -357,6 +376,67 @@ int gather_all(kofft_hip_multi *m, float *const *base, size_t per_floats)
         return KOFFT_ERR_RCCL;
     }
     return KOFFT_OK;
+}
+
+// The same exchange without RCCL: device r PUSHES its slot into every peer's buffer, the G - 1 copies of a device concurrent on
+// G - 1 streams of their own (xGMI is point to point: seven links per device, one per peer; SURVEY 8e: ~0.75 ms for config #4's
+// 115 MB slots against ~5 ms for a ring).  Ordering is by events only: a copy starts behind its source's kernels (ev[2][r]), and
+// device p's stream goes on (ev[3][p], the download) behind every copy into AND out of p's buffer.
+int ensure_peers(kofft_hip_multi *m)
+{
+    if (m->peers_up) return KOFFT_OK;
+    const int G = m->ngpu;
+    m->peer_stream.assign((size_t)G * G, nullptr);
+    m->peer_done.assign((size_t)G * G, nullptr);
+    for (int r = 0; r < G; ++r) {
+        KOFFT_MULTI_TRY(m, hipSetDevice(m->devices[r]));
+        for (int p = 0; p < G; ++p) {
+            if (p == r) continue;
+            if (m->devices[p] != m->devices[r]) {  // (logical devices on one card: nothing to enable)
+                const hipError_t e = hipDeviceEnablePeerAccess(m->devices[p], 0);
+                if (e != hipSuccess) (void)hipGetLastError();  // already enabled, or no direct path: the copy is then staged by the runtime
+            }
+            KOFFT_MULTI_TRY(m, hipStreamCreateWithFlags(&m->peer_stream[(size_t)r * G + p], hipStreamNonBlocking));
+            KOFFT_MULTI_TRY(m, hipEventCreateWithFlags(&m->peer_done[(size_t)r * G + p], hipEventDisableTiming));
+        }
+    }
+    m->peers_up = true;
+    return KOFFT_OK;
+}
+
+int gather_direct(kofft_hip_multi *m, float *const *base, size_t per_floats)
+{
+    const int G = m->ngpu;
+    const size_t bytes = per_floats * sizeof(float);
+    int rc = ensure_peers(m);
+    if (rc) return rc;
+    for (int r = 0; r < G; ++r) {
+        KOFFT_MULTI_TRY(m, hipSetDevice(m->devices[r]));
+        for (int p = 0; p < G; ++p) {
+            if (p == r) continue;
+            hipStream_t ps = m->peer_stream[(size_t)r * G + p];
+            KOFFT_MULTI_TRY(m, hipStreamWaitEvent(ps, m->ev[2][r], 0));  // behind r's kernels (and the zero fill of a short slot)
+            KOFFT_MULTI_TRY(m, hipMemcpyPeerAsync(base[p] + (size_t)r * per_floats, m->devices[p], base[r] + (size_t)r * per_floats,
+                                                  m->devices[r], bytes, ps));
+            KOFFT_MULTI_TRY(m, hipEventRecord(m->peer_done[(size_t)r * G + p], ps));
+        }
+    }
+    for (int p = 0; p < G; ++p) {
+        KOFFT_MULTI_TRY(m, hipSetDevice(m->devices[p]));
+        for (int r = 0; r < G; ++r) {
+            if (r == p) continue;
+            KOFFT_MULTI_TRY(m, hipStreamWaitEvent(m->stream[p], m->peer_done[(size_t)r * G + p], 0));  // into p's buffer
+            KOFFT_MULTI_TRY(m, hipStreamWaitEvent(m->stream[p], m->peer_done[(size_t)p * G + r], 0));  // out of p's buffer
+        }
+    }
+    return KOFFT_OK;
+}
+
+// the exchange in the handle's mode; records which form ran
+int gather_any(kofft_hip_multi *m, float *const *base, size_t per_floats)
+{
+    m->last_gather = m->gather_mode;
+    return m->gather_mode == 2 ? gather_direct(m, base, per_floats) : gather_all(m, base, per_floats);
 }
 
 int record_all(kofft_hip_multi *m, int which)
@@ -397,7 +477,7 @@ int multi_stft_host(kofft_hip_multi *m, const float *signal, size_t len, const f
     const size_t frame_bytes = win_len * 2 * sizeof(float);
     int rc = ensure_workers(m);
     if (rc) return rc;
-    if (allgather) {
+    if (allgather && m->gather_mode == 1) {
         DeviceGuard guard;  // ncclCommInitAll walks the devices
         rc = ensure_comms(m);
         if (rc) return rc;
@@ -459,7 +539,7 @@ int multi_stft_host(kofft_hip_multi *m, const float *signal, size_t len, const f
             DeviceGuard guard;
             std::vector<float *> base(G);
             for (int r = 0; r < G; ++r) base[r] = static_cast<float *>(m->out[r].p);
-            rc = gather_all(m, base.data(), per * win_len * 2);
+            rc = gather_any(m, base.data(), per * win_len * 2);
             if (rc == KOFFT_OK) rc = record_all(m, 3);
         }
         if (rc == KOFFT_OK) rc = m->workers.run(finish);
@@ -603,7 +683,24 @@ int kofft_hip_multi_create(int ngpu, const int *devices, kofft_hip_multi **out)
             return rc;
         }
     }
+    if (const char *e = getenv("KOFFT_HIP_MULTI_GATHER")) m->gather_mode = (e[0] == 'd' || e[0] == '2') ? 2 : 1;
     *out = m;
+    return KOFFT_OK;
+}
+
+int kofft_hip_multi_set_gather(kofft_hip_multi *m, int mode)
+{
+    if (!m) return KOFFT_ERR_NULL;
+    if (mode != KOFFT_MULTI_GATHER_RCCL && mode != KOFFT_MULTI_GATHER_DIRECT) return KOFFT_ERR_INVALID_VALUE;
+    m->gather_mode = mode;
+    return KOFFT_OK;
+}
+
+int kofft_hip_multi_gather_mode(const kofft_hip_multi *m, int *configured, int *last)
+{
+    if (!m) return KOFFT_ERR_NULL;
+    if (configured) *configured = m->gather_mode;
+    if (last) *last = m->last_gather;
     return KOFFT_OK;
 }
 
@@ -618,6 +715,14 @@ int kofft_hip_multi_destroy(kofft_hip_multi *m)
         Rccl &r = rccl();
         for (nccl_comm_t c : m->comms)
             if (c && r.CommDestroy) (void)r.CommDestroy(c);
+    }
+    for (size_t i = 0; i < m->peer_stream.size(); ++i) {
+        (void)hipSetDevice(m->devices[i / (size_t)m->ngpu]);
+        if (m->peer_stream[i]) {
+            (void)hipStreamSynchronize(m->peer_stream[i]);
+            (void)hipStreamDestroy(m->peer_stream[i]);
+        }
+        if (m->peer_done[i]) (void)hipEventDestroy(m->peer_done[i]);
     }
     for (size_t r = 0; r < m->ctx.size(); ++r) {
         (void)hipSetDevice(m->devices[r]);
@@ -730,29 +835,51 @@ int kofft_hip_multi_stft_f32_dev(kofft_hip_multi *m, const float *const *d_signa
     const int G = m->ngpu;
     const size_t per = ceil_div(frames, (size_t)G);
     const size_t frame_floats = win_len * 2;
-    if (allgather) {
+    // every per-device argument is checked, and every buffer exists, BEFORE anything is enqueued: an error return must not leave
+    // earlier devices writing the caller's buffers
+    for (int r = 0; r < G; ++r) {
+        size_t f0, f1, lo, hi;
+        shard_range(frames, r, G, &f0, &f1);
+        slice_range(len, win_len, hop, f0, f1, &lo, &hi);
+        if (hi > lo && !d_signal_per_gpu[r]) return KOFFT_ERR_NULL;
+    }
+    if (allgather && m->gather_mode == 1) {
         const int rc = ensure_comms(m);
         if (rc) return rc;
     }
     std::vector<float *> base(G);
     for (int r = 0; r < G; ++r) {
-        size_t f0, f1, lo, hi;
+        size_t f0, f1;
         shard_range(frames, r, G, &f0, &f1);
-        slice_range(len, win_len, hop, f0, f1, &lo, &hi);
-        const size_t count = f1 - f0;
-        if (hi > lo && !d_signal_per_gpu[r]) return KOFFT_ERR_NULL;
-        KOFFT_MULTI_TRY(m, hipSetDevice(m->devices[r]));
         if (!d_out_per_gpu[r]) {  // no caller buffer: the handle's
-            const int rc = ensure(m->last_error, m->out[r], (allgather ? (size_t)G * per : count) * frame_floats * sizeof(float));
+            KOFFT_MULTI_TRY(m, hipSetDevice(m->devices[r]));
+            const int rc = ensure(m->last_error, m->out[r], (allgather ? (size_t)G * per : f1 - f0) * frame_floats * sizeof(float));
             if (rc) return rc;
             d_out_per_gpu[r] = static_cast<float *>(m->out[r].p);
         }
         base[r] = d_out_per_gpu[r];
+    }
+    // from here on work is in flight: every error exit drains the streams first
+#define KOFFT_MULTI_TRY_DRAIN(m, expr)                                                            \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            (m)->last_error = std::string(#expr) + ": " + hipGetErrorString(e_);                  \
+            drain_all(m);                                                                         \
+            return KOFFT_ERR_HIP;                                                                 \
+        }                                                                                         \
+    } while (0)
+    for (int r = 0; r < G; ++r) {
+        size_t f0, f1, lo, hi;
+        shard_range(frames, r, G, &f0, &f1);
+        slice_range(len, win_len, hop, f0, f1, &lo, &hi);
+        const size_t count = f1 - f0;
+        KOFFT_MULTI_TRY_DRAIN(m, hipSetDevice(m->devices[r]));
         hipStream_t s = m->stream[r];
         float *dst = base[r] + (allgather ? (size_t)r * per * frame_floats : 0);
-        KOFFT_MULTI_TRY(m, hipEventRecord(m->ev[1][r], s));
+        KOFFT_MULTI_TRY_DRAIN(m, hipEventRecord(m->ev[1][r], s));
         if (allgather && count < per)
-            KOFFT_MULTI_TRY(m, hipMemsetAsync(dst + count * frame_floats, 0, (per - count) * frame_floats * sizeof(float), s));
+            KOFFT_MULTI_TRY_DRAIN(m, hipMemsetAsync(dst + count * frame_floats, 0, (per - count) * frame_floats * sizeof(float), s));
         if (count) {
             const int rc = kofft_hip_stft_f32_dev(m->ctx[r], d_signal_per_gpu[r], hi - lo, d_window_per_gpu[r], win_len, hop, dst, 0, count);
             if (rc) {
@@ -761,10 +888,11 @@ int kofft_hip_multi_stft_f32_dev(kofft_hip_multi *m, const float *const *d_signa
                 return rc;
             }
         }
-        KOFFT_MULTI_TRY(m, hipEventRecord(m->ev[2][r], s));
+        KOFFT_MULTI_TRY_DRAIN(m, hipEventRecord(m->ev[2][r], s));
     }
+#undef KOFFT_MULTI_TRY_DRAIN
     if (allgather) {
-        int rc = gather_all(m, base.data(), per * frame_floats);
+        int rc = gather_any(m, base.data(), per * frame_floats);
         if (rc == KOFFT_OK) rc = record_all(m, 3);
         if (rc) {
             drain_all(m);

@@ -64,3 +64,24 @@ def test_parent_never_imports_torch():
     assert main_src.index("launch_ranks(") < main_src.index("run_rank(args)")
     top = src[:src.index("def parse(")]
     assert "import torch" not in top and "import kofft_amd" not in top and "import numpy" not in top
+
+
+def test_dry_protocol_eight_ranks_one_line_with_every_workload_key():
+    """The N = 8 contract without a GPU: the launcher starts eight fresh ranks, they rendezvous on 127.0.0.1 (gloo),
+    run the barrier / all-reduce steps of the timing protocol, and exactly ONE JSON line comes back, carrying every key of the real line
+    and the workloads an 8-rank run measures (BASELINE configs #3, #4, #5; the 8(f) rows are N = 1 only)."""
+    res = _run(["--gpus", "8", "--dry-launch", "--dry-protocol"], timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out_lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(out_lines) == 1
+    line = json.loads(out_lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline", "workloads"):
+        assert key in line, key
+    assert line["n_gpus"] == 8 and line["WORLD_SIZE"] == "8" and line["launcher"] == "self"
+    assert list(line["workloads"]) == ["stft1024", "rfft2048", "c64_2p20"]
+    # one rank: the SURVEY 8(f) rows ride along
+    res1 = _run(["--dry-launch", "--dry-protocol"], timeout=300)
+    assert res1.returncode == 0, res1.stderr[-2000:]
+    line1 = json.loads([ln for ln in res1.stdout.splitlines() if ln.startswith("{")][-1])
+    assert list(line1["workloads"]) == ["stft1024", "rfft2048", "c64_2p20", "istft1024", "magnitudes1024", "fft2d_4096", "bluestein1000"]

@@ -39,7 +39,7 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-def _worker(rank: int, world: int, port: int, length: int, hop: int, win_len: int, q):
+def _worker(rank: int, world: int, port: int, length: int, hop: int, win_len: int, q, extra: int = 1):
     sys.path.insert(0, str(ROOT))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -51,7 +51,7 @@ def _worker(rank: int, world: int, port: int, length: int, hop: int, win_len: in
         rng = np.random.default_rng(1234)  # same signal on every rank (replicated input)
         signal = rng.uniform(-1, 1, length).astype(np.float32)
         window = ko.hann(win_len)
-        frames = frames_required(length, hop) + 1  # one extra, fully zero-padded frame
+        frames = frames_required(length, hop) + extra  # (default) one extra, fully zero-padded frame
 
         def compute(first, count):
             out = ko.stft_range(signal, window, hop, first, count)
@@ -85,3 +85,24 @@ def test_stft_sharded_allgather_gloo(world, length, hop, win_len):
         assert p.exitcode == 0
     assert sorted(r for r, _, _ in results) == list(range(world))
     assert all(ok for _, ok, _ in results), results
+
+
+def test_stft_sharded_world8_config4_frame_count():
+    """BASELINE config #4's partition for real: 28.8 M samples at hop 256 = 112 500 frames over 8 ranks -- 14 063 frames on ranks
+    0..6, 14 059 on the last, whose all-gather slot is padded with four zero frames (SURVEY 8e).  A short window keeps it cheap;
+    every rank checks the whole gathered spectrogram and its own block against the oracle."""
+    world, length, hop, win_len = 8, 28_800_000, 256, 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, length, hop, win_len, q, 0)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in results), results
+    blocks = dict((r, b) for r, _, b in results)
+    assert [blocks[r][1] - blocks[r][0] for r in range(world)] == [14_063] * 7 + [14_059]
+    assert blocks[7] == (98_441, 112_500)

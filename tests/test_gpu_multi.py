@@ -232,6 +232,68 @@ def test_multi_device_resident_forms(oracle, g):
     m.close()
 
 
+@pytest.mark.parametrize("g", [1, 2, 3, 5, 8])
+def test_multi_direct_gather_on_one_card(oracle, g):
+    """Round 4: the exchange without RCCL -- every device pushes its slot to every peer (hipMemcpyPeerAsync on a stream per peer,
+    ordered by events only).  G logical devices on card 0 (peer = self is an ordinary device copy): host form and device form,
+    EVERY device's gathered buffer checked incl. the zero padding of the short last slot; at G = 1 both forms byte for byte; the
+    handle reports which form ran."""
+    import torch
+
+    import kofft_amd
+
+    dev = torch.device("cuda", 0)
+    sig = _signal(61_007 + 13 * g, seed=21 + g)
+    win = kofft_amd.hann(512)
+    hop = 128
+    frames = -(-sig.size // hop) + 1
+    want = oracle.stft(sig, win, hop, frames)
+    per = -(-frames // g)
+    m = kofft_amd.HipMulti(g, devices=[0] * g)
+    assert m.gather_mode() == {"configured": "rccl", "last": None}
+    m.set_gather("direct")
+    got, ptrs = m.stft(sig, win, hop, frames, allgather=True, want_device_ptrs=True)
+    assert bits_equal(got, want)
+    assert m.gather_mode() == {"configured": "direct", "last": "direct"}
+    t = m.last_timing_ex()
+    assert t["kernel_ms"] > 0.0 and (t["gather_ms"] > 0.0 or g == 1)
+    # device form, caller's buffers pre-filled with a sentinel: every logical device ends up with the whole spectrogram
+    dw = torch.from_numpy(win).to(dev)
+    slices, outs = [], []
+    for r in range(g):
+        first, count = m.stft_slice(sig.size, 512, hop, frames, r)
+        slices.append(torch.from_numpy(sig[first:first + count].copy()).to(dev))
+        outs.append(torch.full((g * per, 512, 2), 7.0, dtype=torch.float32, device=dev))
+    torch.cuda.synchronize(dev)
+    m.stft_dev([t_.data_ptr() for t_ in slices], sig.size, [dw.data_ptr()] * g, 512, hop, frames, allgather=True,
+               d_out=[t_.data_ptr() for t_ in outs])
+    m.synchronize()
+    pad = np.zeros((g * per - frames, 512), np.complex64)
+    for r in range(g):
+        have = outs[r].cpu().numpy().view(np.complex64).reshape(g * per, 512)
+        assert bits_equal(have[:frames], want), f"logical device {r}: gathered spectrogram differs"
+        assert bits_equal(have[frames:], pad), f"logical device {r}: slot padding not zero"
+    # a call without an exchange says so
+    m.stft(sig, win, hop, frames, allgather=False)
+    assert m.gather_mode()["last"] is None
+    if g == 1:  # both forms on the one rank RCCL accepts here
+        m.set_gather("rccl")
+        again = m.stft(sig, win, hop, frames, allgather=True)
+        assert m.gather_mode()["last"] == "rccl" and bits_equal(again, got)
+    with pytest.raises(kofft_amd.FftError):
+        m.set_gather(3)
+    m.close()
+
+
+def test_multi_gather_mode_from_the_environment(monkeypatch):
+    import kofft_amd
+
+    monkeypatch.setenv("KOFFT_HIP_MULTI_GATHER", "direct")
+    m = kofft_amd.HipMulti(1)
+    assert m.gather_mode()["configured"] == "direct"
+    m.close()
+
+
 def _ndev():
     import kofft_amd
 
@@ -283,6 +345,24 @@ def test_multi_all_cards_of_the_box_with_rccl(oracle):
         have = outs[r].cpu().numpy().view(np.complex64).reshape(g * per, 1024)
         assert bits_equal(have[:frames], want), f"device {r}: gathered spectrogram differs"
         assert bits_equal(have[frames:], pad), f"device {r}: slot padding not zero"
+    # the same exchange as peer copies (no RCCL): the A/B the first multi-card run should carry (direct ~0.75 ms vs ring ~5 ms)
+    t_rccl = m.last_timing_ex()
+    m.set_gather("direct")
+    for o in outs:
+        o.fill_(7.0)
+    for r in range(g):
+        torch.cuda.synchronize(torch.device("cuda", r))
+    m.stft_dev([t_.data_ptr() for t_ in slices], sig.size, [t_.data_ptr() for t_ in wins], 1024, hop, frames, allgather=True,
+               d_out=[t_.data_ptr() for t_ in outs])
+    m.synchronize()
+    t_direct = m.last_timing_ex()
+    assert m.gather_mode()["last"] == "direct"
+    for r in range(g):
+        have = outs[r].cpu().numpy().view(np.complex64).reshape(g * per, 1024)
+        assert bits_equal(have[:frames], want), f"device {r}: direct gather differs"
+        assert bits_equal(have[frames:], pad), f"device {r}: slot padding not zero (direct)"
+    print(f"all-gather over {g} cards: rccl {t_rccl['gather_ms']:.3f} ms, direct {t_direct['gather_ms']:.3f} ms")
+    m.set_gather("rccl")
     # collective-free batched forms over the real devices
     x = rand_c(seeded(79), (8 * g + 3, 4096))
     y = x.copy()

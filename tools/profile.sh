@@ -9,6 +9,8 @@ TAG=$1; shift
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
+# provenance of the counters: the kernel sources and the library that actually ran, recorded NOW (summarize_profile.py copies these)
+python3 -c "import bench, hashlib, json; print(json.dumps({'csrc_sha16': bench.csrc_sha16(), 'lib_sha16': hashlib.sha256(open('kofft_amd/lib/libkofft_hip.so','rb').read()).hexdigest()[:16]}))" > $OUT/provenance.json
 cd $PWD
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-cpu-baseline --no-extra-workloads --min-seconds 0 "$@" > $OUT/trace_bench.log 2>&1
 echo "trace rc=$?" >> $OUT/trace_bench.log

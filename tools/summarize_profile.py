@@ -27,6 +27,15 @@ def newest(pattern):
     return files[-1:]
 
 
+def provenance(src: Path) -> dict:
+    """The source / library hashes recorded by tools/profile.sh WHEN the counters were collected.  A directory without the record
+    (collected by an older script) gets the current source hash and says so."""
+    f = src / "provenance.json"
+    if f.exists():
+        return json.loads(f.read_text())
+    return {"csrc_sha16": csrc_sha16(), "provenance": "hash taken at summary time: this directory has no provenance.json"}
+
+
 def main():
     src, name, workload = Path(sys.argv[1]), sys.argv[2], sys.argv[3]
     out_dir = Path(__file__).resolve().parent.parent / "profiles"
@@ -108,7 +117,7 @@ def main():
                   f"read {fetch / 1e9:.4f} GB + write {write / 1e9:.4f} GB = **{(fetch + write) / 1e9:.4f} GB**"]
         (out_dir / f"traffic_{workload}.json").write_text(json.dumps(
             {"workload": workload, "hbm_bytes_per_step": fetch + write, "read_bytes": fetch, "write_bytes": write,
-             "kernels_per_step": len(agg["FETCH_SIZE"]) / nf, "from": f"profiles/{name}.md", "csrc_sha16": csrc_sha16()}) + "\n")
+             "kernels_per_step": len(agg["FETCH_SIZE"]) / nf, "from": f"profiles/{name}.md", **provenance(src)}) + "\n")
     if "SQ_LDS_BANK_CONFLICT" in agg:
         lines += ["", f"LDS bank-conflict cycles / LDS active cycles: {summary['pmc']['SQ_LDS_BANK_CONFLICT']:.0f} / "
                   f"{summary['pmc'].get('SQ_LDS_IDX_ACTIVE', 0):.0f}"]
