@@ -155,22 +155,14 @@ struct persist_depth { static constexpr int value = 1; };
 template <class CFG>
 struct persist_depth<CFG, decltype((void)CFG::DEPTH)> { static constexpr int value = CFG::DEPTH; };
 
-// CFG::kSpread (round 3, measurement): the next transform's loads ride between the current transform's passes, four at a time,
-// instead of going out as one burst of 16 before it (tools/ubench_seg.hip: a pure copy of the 8192-point shape gains 5 % from
-// that; the 4096-point shape with two workgroups per CU does not care).
-template <class CFG, class = void>
-struct persist_spread { static constexpr bool value = false; };
-template <class CFG>
-struct persist_spread<CFG, decltype((void)CFG::kSpread)> { static constexpr bool value = CFG::kSpread; };
+// (Measured in round 3 and removed in round 4: the next transform's loads riding between the current transform's passes, four at a
+// time, instead of one burst before it -- n = 4096 with two workgroups per CU 0.673 against 0.700.)
 // CFG::kTwGlobal (f64, n = 8192): no pass keeps its table entries in registers (15 x 4 VGPRs per pass) or in LDS (the exchange
 // buffer fills it): every pass after the first reads them from the table in global memory, as fft_wg_kernel does (L2 hits).
 template <class CFG, class = void>
 struct persist_tw_global { static constexpr bool value = false; };
 template <class CFG>
 struct persist_tw_global<CFG, decltype((void)CFG::kTwGlobal)> { static constexpr bool value = CFG::kTwGlobal; };
-struct PersistNoMid {
-    __device__ __forceinline__ void operator()(int) const {}
-};
 
 // Everything a thread keeps across transforms.
 // CFG (kofft_hip.hip: PersistCfg<L, IO>) carries the per-size, per-policy choices: BLOCK, NBUF, MINW and where the
@@ -217,12 +209,12 @@ struct persist_acc { using type = NoAcc; };
 template <class IO>
 struct persist_acc<IO, true> { using type = typename IO::Acc; };
 
-template <typename T, int L, int RL, int EPI, class CFG, class IO, class Mid = PersistNoMid>
+template <typename T, int L, int RL, int EPI, class CFG, class IO>
 __device__ __forceinline__ void persist_transform(const typename persist_raw<IO, ((1 << L) >> RL)>::type *raw,
                                                   const PersistState<T, L, RL, EPI, IO, CFG> &st,
                                                   const IO &io, const cpx<T> *__restrict__ tw, cpx<T> *buf0, cpx<T> *buf1,
                                                   const size_t xf0, const int cnt, const int sub, const int tau,
-                                                  typename persist_acc<IO>::type &acc, const Mid &mid = Mid{})
+                                                  typename persist_acc<IO>::type &acc)
 {
     // The wavefront's group: cnt (0 .. G) valid transforms starting at xf0; this lane belongs to number `sub`.
     constexpr int NBUF = CFG::NBUF;
@@ -267,9 +259,7 @@ __device__ __forceinline__ void persist_transform(const typename persist_raw<IO,
         }
     }
 
-    mid(0);
     persist_compute_p0<T, L, RL>(cur, tw);
-    mid(1);
     if (NBUF == 1) exchange_sync<WAVE>();  // the previous transform's last LDS gathers are done
     persist_lds_scatter<T, L, RL, 0>(cur, buf0, st.sc);
     exchange_sync<WAVE>();
@@ -282,7 +272,6 @@ __device__ __forceinline__ void persist_transform(const typename persist_raw<IO,
     if constexpr (St::TWG) wg_compute<T, L, RL, 1>(cur, io, tw, xf, tau_tw);
     else if constexpr (NP == 2 && CFG::kTwLastInLds) wg_compute<T, L, RL, 1>(cur, io, st.tw_lds, xf, tau);
     else persist_compute<T, L, RL, 1>(cur, st.tw1);
-    mid(2);
     if constexpr (NP >= 3) {
         if (NBUF == 1) exchange_sync<WAVE>();
         persist_lds_scatter<T, L, RL, 1>(cur, buf1, st.sc);
@@ -292,7 +281,6 @@ __device__ __forceinline__ void persist_transform(const typename persist_raw<IO,
         else if constexpr (NP == 3 && CFG::kTwLastInLds) wg_compute<T, L, RL, 2>(cur, io, st.tw_lds, xf, tau);
         else persist_compute<T, L, RL, 2>(cur, st.tw2);
     }
-    mid(3);
     if constexpr (NP == 4) {  // n = 8192 (NBUF == 1)
         exchange_sync<WAVE>();
         persist_lds_scatter<T, L, RL, 2>(cur, buf0, st.sc);
@@ -493,14 +481,6 @@ __global__ __launch_bounds__(CFG::BLOCK, CFG::MINW) void fft_persist_kernel(cons
             for (int u = 0; u < R; ++u) dst[u] = io.fetch_d(d, in_lane_bytes, FirstG::in_index(0, u), in_row_off);
         }
     };
-    auto issue_chunk = [&](Raw *dst, const size_t b, const int chunk) {  // kSpread: loads 4 * chunk .. 4 * chunk + 3 (plain policies only)
-        if constexpr (!RawSel::pair && !RawSel::pair_lds) {
-            const rsrc_t d = io.in_desc_n(b + wslot, group_cnt(b));
-#pragma unroll
-            for (int u = 0; u < R; ++u)
-                if (u / (R / 4) == chunk) dst[u] = io.fetch_d(d, in_lane_bytes, FirstG::in_index(0, u), in_row_off);
-        }
-    };
     issue(ra, base);
     typename persist_acc<IO>::type acc{};
     if constexpr (io_has_acc<IO>::value) acc = io.acc_init();
@@ -514,18 +494,9 @@ __global__ __launch_bounds__(CFG::BLOCK, CFG::MINW) void fft_persist_kernel(cons
     {                                                                                                                \
         const size_t nbase = base + step;                                                                            \
         const bool more = nbase < batch; /* workgroup-uniform */                                                     \
-        if constexpr (persist_spread<CFG>::value && !RawSel::pair && !RawSel::pair_lds) {                            \
-            persist_transform<T, L, RL, EPI, CFG>(CUR, st, io, tw, buf0, buf1, base + wslot, group_cnt(base), sub, tau, acc, \
-                                                  [&](int c) {                                                       \
-                                                      __builtin_amdgcn_sched_barrier(0);                             \
-                                                      issue_chunk(NXT, nbase, c);                                    \
-                                                      __builtin_amdgcn_sched_barrier(0);                             \
-                                                  });                                                                \
-        } else {                                                                                                     \
-            issue(NXT, nbase);                                                                                       \
-            __builtin_amdgcn_sched_barrier(0); /* keep the prefetch ahead of CUR's first use */                      \
-            persist_transform<T, L, RL, EPI, CFG>(CUR, st, io, tw, buf0, buf1, base + wslot, group_cnt(base), sub, tau, acc); \
-        }                                                                                                            \
+        issue(NXT, nbase);                                                                                           \
+        __builtin_amdgcn_sched_barrier(0); /* keep the prefetch ahead of CUR's first use */                          \
+        persist_transform<T, L, RL, EPI, CFG>(CUR, st, io, tw, buf0, buf1, base + wslot, group_cnt(base), sub, tau, acc); \
         if (!more) LEAVE;                                                                                            \
         base = nbase;                                                                                                \
     }

@@ -111,51 +111,7 @@ struct SplitState {
     typename IO::Inv inv[16];
     int cA, gA1, cB, gB1;  // LDS byte bases: phase A scatters, A1 gather, phase B block gather + B0 scatter, B1 gather
     int tauA, tauB;
-    bool young;  // the second wavefront on its SIMD (wave-uniform)
 };
-
-// KOFFT_SPLIT_FINE: memory instructions two at a time between the STAGES of the passes (8 slots per phase) instead of four
-// at a time between the passes (4 slots).
-#ifndef KOFFT_SPLIT_FINE
-#define KOFFT_SPLIT_FINE 0
-#endif
-// reg_pass (pass A0: compile-time table indices) with a callback after every stage
-template <typename T, int L, int Q, class TwMap, class Cb>
-__device__ __forceinline__ void split_pass0_cb(cpx<T> *v, const cpx<T> *__restrict__ tw, const TwMap map, const Cb &cb)
-{
-#pragma unroll
-    for (int t = 0; t < Q; ++t) {
-        const int pos = Q - 1 - t;
-#pragma unroll
-        for (int b = 0; b < (1 << (Q - 1)); ++b) {  // butterfly b of the stage: group h, position lo
-            const int h = b >> pos, lo = b & ((1 << pos) - 1);
-            const int idx = bitrev(h, t) << (L - 1 - t);
-            const cpx<T> w = tw[map(idx, t)];
-            const int c = (h << (pos + 1)) | lo;
-            bfly<T, true>(v[c], v[c | (1 << pos)], w);
-            if (KOFFT_SPLIT_FINE >= 2 && b == (1 << (Q - 2)) - 1) cb(t);  // half way through the stage
-        }
-        cb(t);
-    }
-}
-// reg_pass_r over G groups, stage by stage across the groups, with a callback after every stage
-template <typename T, int Q, class Cb>
-__device__ __forceinline__ void split_compute_cb(cpx<T> *v, const cpx<T> *twr, const Cb &cb)
-{
-#pragma unroll
-    for (int t = 0; t < Q; ++t) {
-        const int pos = Q - 1 - t;
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {  // the stage's 8 butterflies: group g, twiddle h, position lo
-            const int g = b >> (Q - 1), r = b & ((1 << (Q - 1)) - 1), h = r >> pos, lo = r & ((1 << pos) - 1);
-            const cpx<T> w = twr[g * ((1 << Q) - 1) + (1 << t) - 1 + h];
-            const int c = (g << Q) | (h << (pos + 1)) | lo;
-            bfly(v[c], v[c | (1 << pos)], w);
-            if (KOFFT_SPLIT_FINE >= 2 && b == 3) cb(t);
-        }
-        cb(t);
-    }
-}
 
 template <typename T, int Q>
 __device__ __forceinline__ void split_compute(cpx<T> *v, const cpx<T> *twr)
@@ -196,24 +152,15 @@ struct SplitLds {
     }
 };
 
-#ifndef KOFFT_SPLIT_PIN
-#define KOFFT_SPLIT_PIN 1
-#endif
 __device__ __forceinline__ void split_pin()  // keeps a chunk of memory instructions where it is written
 {
-#if KOFFT_SPLIT_PIN
     __builtin_amdgcn_sched_barrier(0);
-#endif
 }
 
 // Phase A of transform xf (inputs in raw[]): stages 0 .. LA-1, results scattered to cells (K, j) of buffer BUF.
-struct SplitNoHook {
-    __device__ __forceinline__ void operator()() const {}
-};
-template <typename T, int LA, int LB, int BUF, class IO, class LoadChunk, class BeforeLds = SplitNoHook, class AfterScatter = SplitNoHook>
+template <typename T, int LA, int LB, int BUF, class IO, class LoadChunk>
 __device__ __forceinline__ void split_phase_a(const typename IO::Raw *raw, const SplitState<T, LA, LB, IO> &st, const IO &io,
-                                              const cpx<T> *__restrict__ tw, const size_t xf, const LoadChunk &load_chunk,
-                                              const BeforeLds &before_lds = BeforeLds{}, const AfterScatter &after_scatter = AfterScatter{})
+                                              const cpx<T> *__restrict__ tw, const size_t xf, const LoadChunk &load_chunk)
 {
     using Gm = SplitGeom<LA, LB>;
     using Lds = SplitLds<T, LA, LB, IO>;
@@ -234,22 +181,11 @@ __device__ __forceinline__ void split_phase_a(const typename IO::Raw *raw, const
         for (int u = 0; u < R; ++u) cur[u] = io.finish(xf, u * Gm::TPT + st.tauA, raw[u], st.inv[u]);
     }
     KOFFT_SPLIT_STAMP(1)
-#if KOFFT_SPLIT_FINE
-    // slots: after finish, after stages 0..3 of A0, after the gather, after stages 0..1 of A1 = 8 slots x 2 loads
-    int slot = 0;
-    constexpr int NSLOT = KOFFT_SPLIT_FINE >= 2 ? 16 : 8;  // load_chunk(100 + i): loads 2i, 2i+1; load_chunk(200 + i): load i
-    auto half_chunk = [&] { if (slot < NSLOT) { split_pin(); load_chunk((NSLOT == 16 ? 200 : 100) + slot); ++slot; split_pin(); } };
-    half_chunk();
-    split_pass0_cb<T, LA, 4>(cur, tw, TwSubFirst{LB}, [&](int) { half_chunk(); });
-    KOFFT_SPLIT_STAMP(2)
-#else
     split_pin(); load_chunk(0); split_pin();
     // stages 0 .. 3 (k = 0: table indices are compile-time constants -> scalar loads) ...
     reg_pass<T, LA, 0, 4, true>(cur, 0, tw, TwSubFirst{LB});
     KOFFT_SPLIT_STAMP(2)
     split_pin(); load_chunk(1); split_pin();
-#endif
-    before_lds();  // (counter mode: every wavefront has left the reads of the transform that used this buffer last)
     // ... wave-local exchange (this wavefront's columns only) ...
 #pragma unroll
     for (int u = 0; u < R; ++u) Lds::st(cA ^ (Gm::a0_out_reg(u) ^ BOFF), cur[u]);
@@ -257,32 +193,20 @@ __device__ __forceinline__ void split_phase_a(const typename IO::Raw *raw, const
 #pragma unroll
     for (int u = 0; u < R; ++u) cur[u] = Lds::ld(gA1 ^ (Gm::a1_in_reg(u) ^ BOFF));
     KOFFT_SPLIT_STAMP(3)
-#if KOFFT_SPLIT_FINE
-    half_chunk();
-    split_compute_cb<T, Gm::QA1>(cur, st.twA1, [&](int) { half_chunk(); });
-#pragma unroll
-    for (int i = 0; i < 16; ++i) half_chunk();  // whatever is left
-    KOFFT_SPLIT_STAMP(4)
-#else
     split_pin(); load_chunk(2); split_pin();
     // ... stages 4 .. LA-1
-#ifndef KOFFT_SPLIT_COPY_ONLY
     split_compute<T, Gm::QA1>(cur, st.twA1);
-#endif
     KOFFT_SPLIT_STAMP(4)
     split_pin(); load_chunk(3); split_pin();
-#endif
     exchange_sync<true>();  // the gathers above are done before the cells are overwritten (same wavefront: order only)
 #pragma unroll
     for (int u = 0; u < R; ++u) Lds::st(cA ^ (Gm::a1_out_reg(u) ^ BOFF), cur[u]);
-    after_scatter();
     KOFFT_SPLIT_STAMP(5)
 }
 
 // Phase B (after the block-wide barrier): stages LA .. L-1 of this thread's row K out of buffer BUF; results left in cur[].
-template <typename T, int LA, int LB, int BUF, class IO, class StoreChunk, class AfterGathers = SplitNoHook>
-__device__ __forceinline__ void split_phase_b(cpx<T> *cur, const SplitState<T, LA, LB, IO> &st, const size_t xf, const StoreChunk &store_chunk,
-                                              const AfterGathers &after_gathers = AfterGathers{})
+template <typename T, int LA, int LB, int BUF, class IO, class StoreChunk>
+__device__ __forceinline__ void split_phase_b(cpx<T> *cur, const SplitState<T, LA, LB, IO> &st, const size_t xf, const StoreChunk &store_chunk)
 {
     using Gm = SplitGeom<LA, LB>;
     using Lds = SplitLds<T, LA, LB, IO>;
@@ -295,47 +219,23 @@ __device__ __forceinline__ void split_phase_b(cpx<T> *cur, const SplitState<T, L
 #pragma unroll
     for (int u = 0; u < R; ++u) cur[u] = Lds::ld(cB ^ (Gm::b0_in_reg(u) ^ BOFF));
     KOFFT_SPLIT_STAMP(7)
-#if KOFFT_SPLIT_FINE
-    int slot = 0;
-    constexpr int NSLOT = KOFFT_SPLIT_FINE >= 2 ? 16 : 8;
-    auto half_chunk = [&] { if (slot < NSLOT) { split_pin(); store_chunk((NSLOT == 16 ? 200 : 100) + slot); ++slot; split_pin(); } };
-    half_chunk();
-    split_compute_cb<T, 4>(cur, st.twB0, [&](int) { half_chunk(); });
-    KOFFT_SPLIT_STAMP(8)
-#else
     split_pin(); store_chunk(0); split_pin();
     // stages LA .. LA+3 of row K ...
-#ifndef KOFFT_SPLIT_COPY_ONLY
     reg_pass_r<T, 4>(cur, st.twB0);
-#endif
     KOFFT_SPLIT_STAMP(8)
     split_pin(); store_chunk(1); split_pin();
-#endif
-#ifndef KOFFT_SPLIT_COPY_ONLY
     exchange_sync<true>();
 #pragma unroll
     for (int u = 0; u < R; ++u) Lds::st(cB ^ (Gm::b0_out_reg(u) ^ BOFF), cur[u]);
     exchange_sync<true>();
 #pragma unroll
     for (int u = 0; u < R; ++u) cur[u] = Lds::ld(gB1 ^ (Gm::b1_in_reg(u) ^ BOFF));
-#endif
-    after_gathers();
     KOFFT_SPLIT_STAMP(9)
-#if KOFFT_SPLIT_FINE
-    half_chunk();
-    split_compute_cb<T, Gm::QB1>(cur, st.twB1, [&](int) { half_chunk(); });
-#pragma unroll
-    for (int i = 0; i < 16; ++i) half_chunk();  // whatever is left
-    KOFFT_SPLIT_STAMP(10)
-#else
     split_pin(); store_chunk(2); split_pin();
     // ... and the rest
-#ifndef KOFFT_SPLIT_COPY_ONLY
     split_compute<T, Gm::QB1>(cur, st.twB1);
-#endif
     KOFFT_SPLIT_STAMP(10)
     split_pin(); store_chunk(3); split_pin();
-#endif
     KOFFT_SPLIT_STAMP(11)
 }
 
@@ -349,34 +249,10 @@ __device__ __forceinline__ void split_phase_b(cpx<T> *cur, const SplitState<T, L
 // Measured (tools/ubench_split, one box, 8192 x 8192-point c32): same order 0.599 / 0.608 of the roofline, opposite orders
 // 0.591 / 0.592 -- the older wavefront of a SIMD wins every issue conflict, so the younger four crawl through their phase A
 // while the older four finish both phases and then idle at the barrier; the SIMD is work-conserving either way and the step
-// time does not move.  The same-order loop is the default (201 VGPRs against 233).
-#ifndef KOFFT_SPLIT_ALTERNATE
-#define KOFFT_SPLIT_ALTERNATE 0
-#endif
-// KOFFT_SPLIT_COUNTERS: the s_barrier replaced by two LDS counters (a split barrier): `arrived` counts phase-A scatters,
-// `done` counts phase-B gathers.  Every wavefront runs A(t+1) BEFORE B(t), so between its own arrival for transform t and
-// its wait for everyone's there is a whole phase of work: a wavefront only ever stops when another one is more than a
-// phase behind, and the waves drift apart instead of hitting the LDS pipe and the memory queue together after every
-// barrier.  LDS operations of one wavefront execute in order, so the counter update is behind the accesses it publishes.
-#ifndef KOFFT_SPLIT_COUNTERS
-#define KOFFT_SPLIT_COUNTERS 0
-#endif
-typedef __attribute__((address_space(3))) unsigned split_lds_u32;
-__device__ __forceinline__ void split_signal(const int counter_bytes)
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add((split_lds_u32 *)(size_t)(unsigned)counter_bytes, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ void split_wait(const int counter_bytes, const unsigned target)
-{
-    for (;;) {
-        const unsigned v = __builtin_amdgcn_readfirstlane(
-            __hip_atomic_load((split_lds_u32 *)(size_t)(unsigned)counter_bytes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-        if ((int)(v - target) >= 0) break;
-        __builtin_amdgcn_s_sleep(1);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
+// time does not move.  The same-order loop is what is left (201 VGPRs against 233; the other removed in round 4).
+// (Measured on top of this loop and removed in round 4 -- git history before it has the code: the s_barrier replaced by two LDS
+// counters, a split barrier: 0.585 / 0.582 against 0.591 / 0.583; memory instructions two or one at a time between the STAGES of
+// the passes instead of four at a time between the passes: 0.602-0.634 against 0.607-0.618; no sched_barrier pins: 0.578-0.588.)
 template <typename T, int LA, int LB, class IO>
 __global__ __launch_bounds__((SplitGeom<LA, LB>::TPT), (SplitGeom<LA, LB>::TPT / 256)) void fft_split_persist_kernel(const IO io, const cpx<T> *__restrict__ tw,
                                                                                         const size_t batch)
@@ -387,10 +263,6 @@ __global__ __launch_bounds__((SplitGeom<LA, LB>::TPT), (SplitGeom<LA, LB>::TPT /
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     if ((unsigned)(size_t)(__attribute__((address_space(3))) char *)smem_raw != 0u) __builtin_trap();  // SplitLds's addressing
     const int tid = threadIdx.x;
-#if KOFFT_SPLIT_COUNTERS
-    if (tid < 2) *(split_lds_u32 *)(size_t)(unsigned)(2 * Gm::N * (int)sizeof(cpx<T>) + 4 * tid) = 0u;
-    __syncthreads();
-#endif
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int ja = lane / Gm::CA, x = lane % Gm::CA;  // phase A: thread ja of column x of this wavefront
@@ -398,7 +270,6 @@ __global__ __launch_bounds__((SplitGeom<LA, LB>::TPT), (SplitGeom<LA, LB>::TPT /
     const int col = w * Gm::CA + x, K = w * Gm::RB + y;
 
     SplitState<T, LA, LB, IO> st;
-    st.young = w >= Gm::W / 2;  // wavefronts w and w + W/2 share a SIMD (round-robin placement)
     st.tauA = (ja << LB) | col;
     st.tauB = (jb << LA) | K;
     st.cA = Gm::cell_bytes(ja, col);
@@ -449,17 +320,15 @@ __global__ __launch_bounds__((SplitGeom<LA, LB>::TPT), (SplitGeom<LA, LB>::TPT /
     typename persist_acc<IO>::type acc{};
     if constexpr (io_has_acc<IO>::value) acc = io.acc_init();
     // 4 loads of a transform, through a descriptor that is EMPTY when there is no such transform (fft_persist.hip.h)
-    auto loads = [&](const rsrc_t d, const int chunk) {  // chunk < 4: loads 4c .. 4c+3; chunk = 100 + i: loads 2i, 2i+1
-        const int u0 = chunk >= 200 ? chunk - 200 : chunk >= 100 ? 2 * (chunk - 100) : 4 * chunk;
-        const int u1 = chunk >= 200 ? u0 + 1 : chunk >= 100 ? u0 + 2 : u0 + 4;
+    auto loads = [&](const rsrc_t d, const int chunk) {  // loads 4c .. 4c+3
+        const int u0 = 4 * chunk, u1 = u0 + 4;
 #pragma unroll
         for (int u = 0; u < R; ++u)
             if (u >= u0 && u < u1) raw[u] = io.fetch_d(d, in_lane_bytes, u * Gm::TPT, 0);
     };
     // 4 stores of a finished transform (an empty descriptor drops them: the first transform has no predecessor)
     auto stores = [&](const cpx<T> *src, const rsrc_t d, const int chunk) {
-        const int u0 = chunk >= 200 ? chunk - 200 : chunk >= 100 ? 2 * (chunk - 100) : 4 * chunk;
-        const int u1 = chunk >= 200 ? u0 + 1 : chunk >= 100 ? u0 + 2 : u0 + 4;
+        const int u0 = 4 * chunk, u1 = u0 + 4;
 #pragma unroll
         for (int u = 0; u < R; ++u) {
             if (u < u0 || u >= u1) continue;
@@ -477,8 +346,7 @@ __global__ __launch_bounds__((SplitGeom<LA, LB>::TPT), (SplitGeom<LA, LB>::TPT /
     // One step = the barrier that completes transform t's block exchange, then B(t) and A(t+1) in this wavefront's order.
     // (Two separate loops, not one loop with a branch inside: with both orders in one loop body the register allocator has
     // to reconcile the two paths at every merge -- 256 VGPRs and spills against ~200.)
-    auto run = [&](auto alt_tag) {
-        constexpr bool ALT = decltype(alt_tag)::value;
+    {
         bool have_prev = false;
         size_t prev = base;
         //   ONEW: receives the results of t      OPREV: results of t-1, stored during B(t)
@@ -489,13 +357,8 @@ __global__ __launch_bounds__((SplitGeom<LA, LB>::TPT), (SplitGeom<LA, LB>::TPT /
         const rsrc_t n2d = io.in_desc_n(nbase + step, nbase + step < batch ? 1 : 0);                                 \
         const rsrc_t pod = io.out_desc_n(prev, have_prev ? 1 : 0);                                                   \
         __syncthreads(); /* the transform's only s_barrier */                                                        \
-        if constexpr (ALT) {                                                                                         \
-            if (more) split_phase_a<T, LA, LB, 1 - BUF>(raw, st, io, tw, nbase, [&](int c) { loads(n2d, c); });      \
-            split_phase_b<T, LA, LB, BUF, IO>(ONEW, st, base, [&](int c) { stores(OPREV, pod, c); });                \
-        } else {                                                                                                     \
-            split_phase_b<T, LA, LB, BUF, IO>(ONEW, st, base, [&](int c) { stores(OPREV, pod, c); });                \
-            if (more) split_phase_a<T, LA, LB, 1 - BUF>(raw, st, io, tw, nbase, [&](int c) { loads(n2d, c); });      \
-        }                                                                                                            \
+        split_phase_b<T, LA, LB, BUF, IO>(ONEW, st, base, [&](int c) { stores(OPREV, pod, c); });                    \
+        if (more) split_phase_a<T, LA, LB, 1 - BUF>(raw, st, io, tw, nbase, [&](int c) { loads(n2d, c); });          \
         have_prev = true;                                                                                            \
         prev = base;                                                                                                 \
         if (!more) {                                                                                                 \
@@ -510,70 +373,13 @@ __global__ __launch_bounds__((SplitGeom<LA, LB>::TPT), (SplitGeom<LA, LB>::TPT /
             KOFFT_SPLIT_STEP(oa, ob, 1, break)
         }
 #undef KOFFT_SPLIT_STEP
-    };
-#if KOFFT_SPLIT_COUNTERS
-    (void)run;
-    {
-        constexpr int ARRIVED = 2 * Gm::N * (int)sizeof(cpx<T>), DONE = ARRIVED + 4;
-        constexpr unsigned W = Gm::W;
-        bool have_prev = false;
-        size_t prev = base;
-        unsigned t = 0;  // this workgroup's transform counter
-        split_signal(ARRIVED);  // the prologue's A(0)
-#define KOFFT_SPLIT_STEP(OPREV, ONEW, BUF, LEAVE)                                                                    \
-    {                                                                                                                \
-        const size_t nbase = base + step;                                                                            \
-        const bool more = nbase < batch; /* workgroup-uniform */                                                     \
-        const rsrc_t n2d = io.in_desc_n(nbase + step, nbase + step < batch ? 1 : 0);                                 \
-        const rsrc_t pod = io.out_desc_n(prev, have_prev ? 1 : 0);                                                   \
-        if (more)                                                                                                    \
-            split_phase_a<T, LA, LB, 1 - BUF>(raw, st, io, tw, nbase, [&](int c) { loads(n2d, c); },                 \
-                                              [&] { split_wait(DONE, W * t); }, [&] { split_signal(ARRIVED); });     \
-        split_wait(ARRIVED, W * (t + 1));                                                                            \
-        split_phase_b<T, LA, LB, BUF, IO>(ONEW, st, base, [&](int c) { stores(OPREV, pod, c); },                     \
-                                          [&] { split_signal(DONE); });                                              \
-        have_prev = true;                                                                                            \
-        prev = base;                                                                                                 \
-        ++t;                                                                                                         \
-        if (!more) {                                                                                                 \
-            const rsrc_t od = io.out_desc_n(base, 1);                                                                \
-            _Pragma("unroll") for (int c = 0; c < 4; ++c) stores(ONEW, od, c);                                       \
-            LEAVE;                                                                                                   \
-        }                                                                                                            \
-        base = nbase;                                                                                                \
     }
-        for (;;) {
-            KOFFT_SPLIT_STEP(ob, oa, 0, break)
-            KOFFT_SPLIT_STEP(oa, ob, 1, break)
-        }
-#undef KOFFT_SPLIT_STEP
-    }
-#else
-    if (KOFFT_SPLIT_ALTERNATE && st.young) run(std::true_type{});
-    else run(std::false_type{});
-#endif
     if constexpr (io_has_acc<IO>::value) io.acc_finish(acc);
 }
 
-// ---- n = 2^14 (f32): the same decomposition with ONE buffer --------------------------------------------------------------
-// 16384 points are 128 KiB: one buffer fills the CU's LDS, and 1024 threads (16 wavefronts, 4 per SIMD) leave 128 registers
-// per thread.  Against the kernel above:
-//   * one LDS buffer, two s_barriers per transform: before a wavefront's first LDS write of phase A (every wave has left the
-//     previous transform's phase B reads) and between the phases; sixteen wavefronts hide each other's waits instead;
-//   * the table entries of passes A1 (16 x (2^QA1 - 1): they depend on the position k only) and B0 (2^LA rows x 15: they
-//     depend on the row K only) live in LDS beside the buffer, built once per workgroup; pass B1's entries depend on
-//     both and are re-read from the table in global memory (L2) at the start of every phase B -- kept in registers across
-//     the transform they put the kernel 10..20 registers over its 128 (scratch);
-//   * results are stored as each group of pass B1 completes (no second result set); the next transform's loads are issued
-//     into the input registers right after `finish` has consumed them.
-template <typename T, int LA, int LB, class IO>
-struct Split1State {
-    using Gm = SplitGeom<LA, LB>;
-    typename IO::Inv inv[16];
-    int cA, gA1, cB, gB1;
-    int tauA, tauB;
-    int twA1_off, twB0_off;  // LDS byte offsets of this thread's first table entries
-};
+// (Round 3 had a single-buffer form of this kernel for n = 2^14, fft_split1_persist_kernel: 1024 threads, 16 points per thread, the
+// table entries of passes A1 / B0 in LDS.  fft_split_wide.hip.h replaced it at 2^14 (0.43 -> 0.555-0.575) and as two workgroups per CU
+// at 2^13 it lost to the kernel above (0.52-0.53 against 0.61-0.63): removed in round 4, git history has it.)
 
 // Q stages on 2^Q values with the entries read from LDS (entry (1 << t) - 1 + h at table + 8 * that).
 template <typename T, int Q, class Lds, bool STAGED = false>
@@ -595,167 +401,5 @@ __device__ __forceinline__ void reg_pass_lds(cpx<T> *v, const int table_bytes)
     }
 }
 
-template <typename T, int LA, int LB, class IO>
-__global__ __launch_bounds__((SplitGeom<LA, LB>::TPT), 4) void fft_split1_persist_kernel(const IO io, const cpx<T> *__restrict__ tw, const size_t batch)
-{
-    using Gm = SplitGeom<LA, LB>;
-    using Lds = SplitLds<T, LA, LB, IO>;
-    constexpr int R = 16;
-    constexpr int EA = (1 << Gm::QA1) - 1, EB1 = (1 << Gm::QB1) - 1;
-    constexpr int TABLE_A = Gm::N * (int)sizeof(cpx<T>);              // [k < 16][EA]
-    constexpr int TABLE_B = TABLE_A + 16 * EA * (int)sizeof(cpx<T>);  // [K < 2^LA][15]
-    static_assert(sizeof(cpx<T>) == 8, "8-byte cells");
-    using Raw = typename IO::Raw;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    if ((unsigned)(size_t)(__attribute__((address_space(3))) char *)smem_raw != 0u) __builtin_trap();  // SplitLds's addressing
-    const int tid = threadIdx.x;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63;
-    const int ja = lane / Gm::CA, x = lane % Gm::CA;
-    const int jb = lane / Gm::RB, y = lane % Gm::RB;
-    const int col = w * Gm::CA + x, K = w * Gm::RB + y;
-
-    // ---- tables in LDS, built once: the same indices the register version above loads (TwSubFirst / TwSub)
-    for (int e = tid; e < 16 * EA; e += Gm::TPT) {
-        const int k = e / EA, i = e % EA;
-        int t = 0;
-        while (((2 << t) - 1) <= i) ++t;  // i = (1 << t) - 1 + h
-        const int h = i - ((1 << t) - 1);
-        int hr = 0;
-        for (int b = 0; b < t; ++b) hr |= ((h >> b) & 1) << (t - 1 - b);
-        Lds::st(TABLE_A + e * (int)sizeof(cpx<T>), tw[((k << (LA - 1 - 4 - t)) + (hr << (LA - 1 - t))) << LB]);
-    }
-    for (int e = tid; e < (1 << LA) * 15; e += Gm::TPT) {
-        const int row = e / 15, i = e % 15;
-        int t = 0;
-        while (((2 << t) - 1) <= i) ++t;
-        const int h = i - ((1 << t) - 1);
-        int hr = 0;
-        for (int b = 0; b < t; ++b) hr |= ((h >> b) & 1) << (t - 1 - b);
-        Lds::st(TABLE_B + e * (int)sizeof(cpx<T>), tw[((hr << (LB - 1 - t)) << LA) + (row << (LB - 1 - t))]);
-    }
-
-    Split1State<T, LA, LB, IO> st;
-    st.tauA = (ja << LB) | col;
-    st.tauB = (jb << LA) | K;
-    st.cA = Gm::cell_bytes(ja, col);
-    st.gA1 = Gm::cell_bytes(ja << Gm::QA1, col);
-    st.cB = Gm::cell_bytes(K, jb);
-    st.gB1 = Gm::cell_bytes(K, jb << Gm::QB1);
-    st.twA1_off = TABLE_A + ja * EA * (int)sizeof(cpx<T>);  // group g: + g * TA * EA entries
-    st.twB0_off = TABLE_B + K * 15 * (int)sizeof(cpx<T>);
-    // pass B1's entries: T[(tauB << (LB-5-t)) + ((g*TB) << (L-5-t)) + (rev_t(h) << (L-1-t))] -- one per-thread byte offset per
-    // stage t, the rest a constant that rides in the instruction's scalar offset
-    const rsrc_t twd = make_rsrc(tw, (unsigned)(Gm::N / 2) * (unsigned)sizeof(cpx<T>));
-#pragma unroll
-    for (int u = 0; u < R; ++u) st.inv[u] = io.invariant(u * Gm::TPT + st.tauA);
-    __syncthreads();  // tables complete
-
-    const size_t step = gridDim.x;
-    size_t base = blockIdx.x;
-    if (base >= batch) return;
-
-    Raw raw[R];
-    const int in_lane_bytes = st.tauA * IO::kRawBytes;
-    const int out_lane_bytes = st.tauB * (int)sizeof(cpx<T>);
-    typename persist_acc<IO>::type acc{};
-    if constexpr (io_has_acc<IO>::value) acc = io.acc_init();
-    auto loads = [&](const rsrc_t d, const int chunk) {
-#pragma unroll
-        for (int u = 4 * chunk; u < 4 * chunk + 4; ++u) raw[u] = io.fetch_d(d, in_lane_bytes, u * Gm::TPT, 0);
-    };
-    {
-        const rsrc_t d0 = io.in_desc_n(base, 1);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) loads(d0, c);
-    }
-    for (;;) {
-        const size_t nbase = base + step;
-        const bool more = nbase < batch;  // workgroup-uniform
-        const rsrc_t nd = io.in_desc_n(nbase, more ? 1 : 0);
-        const size_t xf = base;
-        int cA = st.cA, gA1 = st.gA1, cB = st.cB, gB1 = st.gB1, tA = st.twA1_off, tB = st.twB0_off;
-        asm volatile("" : "+v"(cA), "+v"(gA1), "+v"(cB), "+v"(gB1), "+v"(tA), "+v"(tB));  // (no hoisting of 96 addresses: see above)
-        cpx<T> cur[R];
-        KOFFT_SPLIT_STAMP(0)
-        if (io.inside(xf)) {
-#pragma unroll
-            for (int u = 0; u < R; ++u) cur[u] = io.finish_in(raw[u], st.inv[u]);
-        } else {
-#pragma unroll
-            for (int u = 0; u < R; ++u) cur[u] = io.finish(xf, u * Gm::TPT + st.tauA, raw[u], st.inv[u]);
-        }
-        split_pin(); loads(nd, 0); loads(nd, 1); split_pin();
-        KOFFT_SPLIT_STAMP(1)
-        reg_pass<T, LA, 0, 4, true>(cur, 0, tw, TwSubFirst{LB});
-        split_pin(); loads(nd, 2); loads(nd, 3); split_pin();
-        KOFFT_SPLIT_STAMP(2)
-        __syncthreads();  // every wavefront has read the previous transform out of the buffer
-        KOFFT_SPLIT_STAMP(3)
-#pragma unroll
-        for (int u = 0; u < R; ++u) Lds::st(cA ^ Gm::a0_out_reg(u), cur[u]);
-        exchange_sync<true>();
-#pragma unroll
-        for (int u = 0; u < R; ++u) cur[u] = Lds::ld(gA1 ^ Gm::a1_in_reg(u));
-        KOFFT_SPLIT_STAMP(4)
-#pragma unroll
-        for (int g = 0; g < (16 >> Gm::QA1); ++g)
-            reg_pass_lds<T, Gm::QA1, Lds>(cur + g * (1 << Gm::QA1), tA + g * Gm::TA * EA * (int)sizeof(cpx<T>));
-        KOFFT_SPLIT_STAMP(5)
-        exchange_sync<true>();
-#pragma unroll
-        for (int u = 0; u < R; ++u) Lds::st(cA ^ Gm::a1_out_reg(u), cur[u]);
-        KOFFT_SPLIT_STAMP(6)
-        __syncthreads();  // the block-wide exchange
-        KOFFT_SPLIT_STAMP(7)
-        // pass B1's entries are requested HERE, while the memory pipeline holds nothing but the next transform's (long issued)
-        // loads: requested after pass B0 they queued behind the older wavefronts' result stores -- 128 KiB draining at HBM's
-        // rate -- and the younger wavefronts sat 9 000 .. 18 000 clocks in that exchange (s_memtime stamps).
-        cpx<T> twb[(16 >> Gm::QB1) * EB1];
-        auto load_twb = [&](const int g) {
-#pragma unroll
-            for (int t = 0; t < Gm::QB1; ++t)
-#pragma unroll
-                for (int h = 0; h < (1 << t); ++h)
-                    twb[g * EB1 + (1 << t) - 1 + h] = buf_load_cpx<T, AUX_DEFAULT>(
-                        twd, (st.tauB << (LB - 5 - t)) * (int)sizeof(cpx<T>),
-                        (((g * Gm::TB) << (Gm::L - 5 - t)) + (bitrev(h, t) << (Gm::L - 1 - t))) * (int)sizeof(cpx<T>));
-        };
-        load_twb(0);  // (the other groups after pass B0: all 14 entries beside B0's own put the kernel 10 registers into scratch)
-        split_pin();
-#pragma unroll
-        for (int u = 0; u < R; ++u) cur[u] = Lds::ld(cB ^ Gm::b0_in_reg(u));
-        KOFFT_SPLIT_STAMP(8)
-        reg_pass_lds<T, 4, Lds, true>(cur, tB);  // staged: one stage's entries at a time
-        KOFFT_SPLIT_STAMP(9)
-        split_pin();
-#pragma unroll
-        for (int g = 1; g < (16 >> Gm::QB1); ++g) load_twb(g);
-        split_pin();
-        exchange_sync<true>();
-#pragma unroll
-        for (int u = 0; u < R; ++u) Lds::st(cB ^ Gm::b0_out_reg(u), cur[u]);
-        exchange_sync<true>();
-#pragma unroll
-        for (int u = 0; u < R; ++u) cur[u] = Lds::ld(gB1 ^ Gm::b1_in_reg(u));
-        KOFFT_SPLIT_STAMP(10)
-        const rsrc_t od = io.out_desc_n(xf, 1);
-#pragma unroll
-        for (int g = 0; g < (16 >> Gm::QB1); ++g) {
-            reg_pass_r<T, Gm::QB1>(cur + g * (1 << Gm::QB1), twb + g * EB1);
-            split_pin();
-#pragma unroll
-            for (int u = g << Gm::QB1; u < ((g + 1) << Gm::QB1); ++u) {
-                if constexpr (io_has_acc<IO>::value) io.store_d_acc(od, out_lane_bytes, Gm::out_reg(u), cur[u], 0, acc);
-                else io.store_d(od, out_lane_bytes, Gm::out_reg(u), cur[u], 0);
-            }
-            split_pin();
-        }
-        KOFFT_SPLIT_STAMP(11)
-        if (!more) break;
-        base = nbase;
-    }
-    if constexpr (io_has_acc<IO>::value) io.acc_finish(acc);
-}
 
 }  // namespace kofft

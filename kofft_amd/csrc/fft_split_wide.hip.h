@@ -13,8 +13,8 @@
 //            thread AND the row, one per butterfly in the last stage; they are loaded once and stay in registers across
 //            transforms.  (QB0 = 5 would need 31 entries per row in LDS: 31.7 KiB beside the 128 KiB buffer do not fit.)
 // Measured on one box each (c32, n = 16384, fraction of the roofline): fft_split1 0.43 -> this kernel 0.50..0.52 with the next
-// transform's loads in two halves around pass A0, 0.555..0.575 in four quarters spread over phase A (KOFFT_SPLITW_LOADS = 2,
-// the default; eight slots of four: the same), 0.50 all at once; pass B1's entries re-read per transform -2 %; QB0 = 3 (results
+// transform's loads in two halves around pass A0, 0.555..0.575 in four quarters spread over phase A (eight slots of
+// four: the same), 0.50 all at once; pass B1's entries re-read per transform -2 %; QB0 = 3 (results
 // stored in two halves) the same.  STFT 16384 +1..3 % (compute-limited).  At n = 8192 the same kernel (256 threads, two
 // workgroups per CU; <7,6,2>, <7,6,1>, <6,7,2>: 0.57..0.59) loses to the double-buffered fft_split_persist_kernel (0.59..0.62).
 // Index maps, table indices and the swizzle: tools/split_model.py (Geom(LA, LB, rlog=5, qa0=5, qb0=QB0)), checked against
@@ -113,16 +113,6 @@ constexpr size_t split_wide_lds_bytes()
     return (size_t)Gm::N * 8 + (size_t)(1 << Gm::QA0) * ((1 << Gm::QA1) - 1) * 8 + (size_t)(1 << Gm::LA) * ((1 << Gm::QB0) - 1) * 8;
 }
 
-#ifndef KOFFT_SPLITW_LOADS
-#define KOFFT_SPLITW_LOADS 2
-#endif
-#ifndef KOFFT_SPLITW_PAIRED_TWB_RELOAD
-#define KOFFT_SPLITW_PAIRED_TWB_RELOAD 0
-#endif
-#ifndef KOFFT_SPLITW_TWB_RESIDENT
-#define KOFFT_SPLITW_TWB_RESIDENT 1
-#endif
-
 // EPI_RFFT (IO = RfftIO<float>): the real-FFT
 // post-pass (rfft.rs:450-463) on the transform's results before they leave the CU.  Every thread puts its results Y[o],
 // o = q * 2^LA + K, back into its OWN row's cells (K, q) -- wave-local, so only the wavefront's own earlier gathers have to be
@@ -204,7 +194,7 @@ __global__ __launch_bounds__((SplitWideGeom<LA, LB, QB0>::TPT), 2) void fft_spli
                         twd, (tauB << (LB - 1 - Gm::QB0 - t)) * (int)sizeof(cpx<T>),
                         (((g * Gm::TB) << (Gm::L - 1 - Gm::QB0 - t)) + (bitrev(h, t) << (Gm::L - 1 - t))) * (int)sizeof(cpx<T>));
     };
-    constexpr bool TWB_RES = KOFFT_SPLITW_TWB_RESIDENT && !(PAIRED && KOFFT_SPLITW_PAIRED_TWB_RELOAD);  // (paired input: re-reading them per transform measured 0.363 against 0.383 resident)
+    constexpr bool TWB_RES = true;  // pass B1's entries stay in registers across transforms (re-read per transform: -2 %; paired input 0.363 against 0.383)
     if (TWB_RES) load_twb();
     typename IO::Inv inv[(EPI == EPI_RFFT || PAIRED) ? 1 : R];
     if constexpr (EPI != EPI_RFFT && !PAIRED) {
@@ -299,37 +289,23 @@ __global__ __launch_bounds__((SplitWideGeom<LA, LB, QB0>::TPT), 2) void fft_spli
 #pragma unroll
             for (int u = 0; u < R; ++u) cur[u] = io.finish(xf, u * Gm::TPT + tauA, raw[u], inv[u]);
         }
-        // the next transform's loads, into the registers `finish` has just consumed.  KOFFT_SPLITW_LOADS: 0 = two halves around
-        // pass A0, 1 = all at once, 2 = four quarters spread over phase A
-        auto loads4 = [&](const int c4) {  // KOFFT_SPLITW_LOADS == 3: eight slots of four
-            split_pin();
-#pragma unroll
-            for (int u = 4 * c4; u < 4 * c4 + 4; ++u) raw[u] = fetch1(nd, u);
-            if constexpr (PAIRED)
-                if (c4 == 7) raw_m = buf_load_cpx<T, AUX_NT>(nd, 0, Gm::N * (int)sizeof(cpx<T>));
-            split_pin();
-        };
-        if (KOFFT_SPLITW_LOADS == 3) {
-            loads4(0);
-            split_pass0_cb<T, LA, Gm::QA0>(cur, tw, TwSubFirst{LB}, [&](int t) { loads4(1 + t); });  // slots 1 .. 5
-        } else {
-        split_pin(); loads(nd, 0); if (KOFFT_SPLITW_LOADS < 2) loads(nd, 1); if (KOFFT_SPLITW_LOADS == 1) { loads(nd, 2); loads(nd, 3); } split_pin();
+        // the next transform's loads, into the registers `finish` has just consumed: the 32 loads in four quarters spread over phase A
+        // (0.555-0.575 of the roofline; in two halves around pass A0 0.50-0.52, all at once 0.50, eight slots of four the same as four
+        // of eight -- round 3, one box)
+        split_pin(); loads(nd, 0); split_pin();
         reg_pass<T, LA, 0, Gm::QA0, true>(cur, 0, tw, TwSubFirst{LB});
-        split_pin(); if (KOFFT_SPLITW_LOADS == 0) { loads(nd, 2); loads(nd, 3); } if (KOFFT_SPLITW_LOADS == 2) loads(nd, 1); split_pin();
-        }
+        split_pin(); loads(nd, 1); split_pin();
         __syncthreads();  // every wavefront has read the previous transform out of the buffer
 #pragma unroll
         for (int u = 0; u < R; ++u) Lds::st(cA ^ Gm::a0_out_reg(u), cur[u]);
         exchange_sync<true>();
 #pragma unroll
         for (int u = 0; u < R; ++u) cur[u] = Lds::ld(gA1 ^ Gm::a1_in_reg(u));
-        split_pin(); if (KOFFT_SPLITW_LOADS == 2) loads(nd, 2); split_pin();
-        if (KOFFT_SPLITW_LOADS == 3) loads4(6);
+        split_pin(); loads(nd, 2); split_pin();
 #pragma unroll
         for (int g = 0; g < (R >> Gm::QA1); ++g)
             reg_pass_lds<T, Gm::QA1, Lds>(cur + g * (1 << Gm::QA1), tA + g * Gm::TA * EA * (int)sizeof(cpx<T>));
-        split_pin(); if (KOFFT_SPLITW_LOADS == 2) loads(nd, 3); split_pin();
-        if (KOFFT_SPLITW_LOADS == 3) loads4(7);
+        split_pin(); loads(nd, 3); split_pin();
         exchange_sync<true>();
 #pragma unroll
         for (int u = 0; u < R; ++u) Lds::st(cA ^ Gm::a1_out_reg(u), cur[u]);

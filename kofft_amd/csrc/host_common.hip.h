@@ -63,8 +63,6 @@ struct kofft_hip_ctx {
     bool rfft13_persist = true; // KOFFT_HIP_RFFT13_PERSIST=0: rfft / irfft n = 16384 on the generic kernel
     int persist64 = 1;         // KOFFT_HIP_PERSIST64=0: c64 n = 4096 / 8192 on the generic kernel (A/B measurements)
     bool persist_small = true; // KOFFT_HIP_PERSIST_SMALL=0: n = 128, 256 on the generic kernels (A/B measurements)
-    int split14 = 2;           // KOFFT_HIP_SPLIT14=1: n = 16384 on the 16-points-per-thread kernel (fft_split1) instead of the 32-points one (fft_split_wide.hip.h)
-    int split13 = 1;           // KOFFT_HIP_SPLIT13=2: n = 8192 as TWO independent single-buffer workgroups per CU (fft_split1) instead of one
                                // double-buffered one (measured, same box: c32 0.52-0.53 against 0.61-0.63, STFT 0.41 against 0.43)
     bool use_regfile = true;   // KOFFT_HIP_REGFILE=0: c32 2^15 / c64 2^14 on the two-factor path instead of the register-file-resident kernel (A/B)
     bool use_split = true;     // KOFFT_HIP_SPLIT=0: n = 8192 on the block-synchronised persistent kernel instead of the wave-split one (A/B)
@@ -282,13 +280,7 @@ template <bool INV> struct PersistCfg<12, ComplexIO<double, INV>> {
     static constexpr int BLOCK = 256, NBUF = 1, RL = 4, MINW = 2, WG_PER_CU = 2;
     static constexpr bool kInvInLds = false, kTwLastInLds = false, kTwGlobal = true;
 };
-#ifndef KOFFT_PERSIST12_SPREAD
-#define KOFFT_PERSIST12_SPREAD false
-#endif
-template <class IO> struct PersistCfg<12, IO> : PersistCfgBase<IO> {
-    static constexpr int BLOCK = 256, MINW = 2, WG_PER_CU = 2;
-    static constexpr bool kSpread = KOFFT_PERSIST12_SPREAD;  // next transform's loads between the passes instead of one burst (A/B)
-};
+template <class IO> struct PersistCfg<12, IO> : PersistCfgBase<IO> { static constexpr int BLOCK = 256, MINW = 2, WG_PER_CU = 2; };
 template <class IO> struct PersistCfg<11, IO> : PersistCfgBase<IO> { static constexpr int BLOCK = 256, MINW = 2, WG_PER_CU = 2; };
 template <class IO> struct PersistCfg<10, IO> : PersistCfgBase<IO> {
     static constexpr int BLOCK = 256, MINW = IO::kLeanRegisters ? 3 : 2, WG_PER_CU = MINW;
@@ -444,28 +436,6 @@ int launch_split(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t batc
     return KOFFT_OK;
 }
 
-// n = 2^14: the single-buffer, 16-wavefront form of the same kernel (tables for passes A1 / B0 beside the buffer)
-template <typename T, int LA, int LB, class IO>
-int launch_split1(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t batch)
-{
-    using Gm = SplitGeom<LA, LB>;
-    constexpr size_t lds = ((size_t)Gm::N + 16 * ((1 << Gm::QA1) - 1) + (size_t(1) << LA) * 15) * sizeof(cpx<T>);
-    static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = fft_split1_persist_kernel<T, LA, LB, IO>;
-    {
-        static std::atomic<unsigned long long> attr_done{0};
-        const int arc = set_dyn_lds_once(ctx, attr_done, reinterpret_cast<const void *>(kern), lds);
-        if (arc) return arc;
-    }
-    // 16 wavefronts per CU either way: one 1024-thread workgroup (n = 16384) or two INDEPENDENT 512-thread ones (n = 8192)
-    size_t blocks = (size_t)ctx->num_cus * (1024 / Gm::TPT);
-    if (ctx->persist_grid_pct > 0) blocks = blocks * (size_t)ctx->persist_grid_pct / 100;
-    if (blocks < 1) blocks = 1;
-    if (blocks > batch) blocks = batch;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Gm::TPT), lds, ctx->stream, io, tw, batch);
-    KOFFT_HIP_TRY(ctx, hipGetLastError());
-    return KOFFT_OK;
-}
 
 // n = 2^14 with 32 points per thread (fft_split_wide.hip.h): 512 threads, one workgroup per CU, 128-byte runs both ways
 template <typename T, int LA, int LB, int QB0, class IO>
@@ -599,16 +569,10 @@ int dispatch(kofft_hip_ctx *ctx, const IO &io, size_t n, size_t batch)
     if constexpr (sizeof(T) == 4 && IO::kPersist) if (ctx->use_persist) {
         // streaming sizes: enough transforms to give every resident workgroup several iterations
         if constexpr (EPI == EPI_STORE && io_split_ok<IO>::value) {
-            if (L == 14 && ctx->use_split && ctx->split14 == 2 && batch >= (size_t)ctx->num_cus * 4) return launch_split_wide<T, 7, 7, 2>(ctx, io, tw, batch);
-            if (L == 14 && ctx->use_split && batch >= (size_t)ctx->num_cus * 4) return launch_split1<T, 7, 7>(ctx, io, tw, batch);
+            if (L == 14 && ctx->use_split && batch >= (size_t)ctx->num_cus * 4) return launch_split_wide<T, 7, 7, 2>(ctx, io, tw, batch);
         }
         if constexpr (EPI == EPI_STORE && IO::kPersistMaxLog2 >= 13) {
             if constexpr (io_split_ok<IO>::value) {
-                if (L == 13 && ctx->use_split && ctx->split13 == 2 && batch >= (size_t)ctx->num_cus * 8) return launch_split1<T, 7, 6>(ctx, io, tw, batch);
-#ifdef KOFFT_EXP_WIDE13  // measurement builds: the 32-points-per-thread kernel at n = 8192 (two 256-thread workgroups per CU): 0.58 against 0.63
-                if (L == 13 && ctx->use_split && ctx->split13 == 3 && batch >= (size_t)ctx->num_cus * 8) return launch_split_wide<T, 7, 6, 2>(ctx, io, tw, batch);
-                if (L == 13 && ctx->use_split && ctx->split13 == 5 && batch >= (size_t)ctx->num_cus * 8) return launch_split_wide<T, 6, 7, 2>(ctx, io, tw, batch);
-#endif
                 if (L == 13 && ctx->use_split && batch >= (size_t)ctx->num_cus * 4) return launch_split<T, 7, 6>(ctx, io, tw, batch);
             }
             if (L == 13 && batch >= (size_t)ctx->num_cus * 4) return launch_persist<T, 13, EPI>(ctx, io, tw, batch);

@@ -119,3 +119,19 @@ def test_multi_gpu_entry_validates_without_a_device(hiplib):
     assert hiplib.kofft_hip_multi_fft_c32(None, p, sz(8), sz(0), 0) == 0
     assert hiplib.kofft_hip_multi_fft_c32(None, p, sz(8), sz(1), 0) == -3
     assert b"RCCL" in hiplib.kofft_hip_strerror(-5)
+
+
+def test_every_route_switch_of_the_library_has_a_gpu_test_row():
+    """tests/test_gpu_knobs.py flips every KOFFT_HIP_* switch kofft_hip_create reads; the table there must list exactly those."""
+    import re
+    import sys
+    from pathlib import Path
+
+    ROOT = Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(ROOT / "tests"))
+    from test_gpu_knobs import KNOBS
+
+    src = (ROOT / "kofft_amd" / "csrc" / "kofft_hip.hip").read_text()
+    in_source = set(re.findall(r'getenv\("(KOFFT_HIP_[A-Z0-9_]+)"\)', src))
+    in_table = {k for k, _, _ in KNOBS}
+    assert in_source == in_table, (sorted(in_source - in_table), sorted(in_table - in_source))

@@ -1,0 +1,214 @@
+"""Every KOFFT_HIP_* route switch of the library (kofft_hip.hip: kofft_hip_create), each in its NON-DEFAULT setting, against the oracle
+(a switch that no test flips is a wrong-answer path one `export` away).  The switches are read when a context is
+created, so every case makes its own contexts.  The table is checked against the source on CPU (tests/test_abi_symbols.py): a new getenv without a row fails there."""
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from conftest import bits_equal, rand_c, seeded
+
+pytestmark = pytest.mark.gpu
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _complex(oracle, dtype, n, batch, seed, check=None, inverse=True):
+    import kofft_amd
+
+    cdt = np.complex64 if dtype == "c32" else np.complex128
+    f = kofft_amd.HipFftImpl(np.float32 if dtype == "c32" else np.float64)
+    x = rand_c(seeded(seed), (batch, n), cdt)
+    y = x.copy()
+    f.fft_batch(y)
+    pick = sorted(set(check if check is not None else range(batch)))
+    want = oracle.fft(x[pick])
+    assert bits_equal(y[pick], want), f"{dtype} n={n} batch={batch}: forward differs"
+    if inverse:
+        f.fft_batch(y, inverse=True)
+        assert bits_equal(y[pick], oracle.ifft(want)), f"{dtype} n={n} batch={batch}: inverse differs"
+
+
+def _edges(batch):
+    return [0, 1, batch // 2, batch - 2, batch - 1]
+
+
+def case_no_persist(oracle):
+    import kofft_amd
+
+    _complex(oracle, "c32", 4096, 1300, 11, check=_edges(1300))
+    f = kofft_amd.HipFftImpl(np.float32)
+    rows = seeded(12).uniform(-1, 1, (2100, 2048)).astype(np.float32)
+    win = kofft_amd.hann(2048)
+    pick = _edges(2100)
+    assert bits_equal(f.rfft_batch(rows, win)[pick], oracle.rfft(rows[pick], win))
+    sig = seeded(13).uniform(-1, 1, 300_000).astype(np.float32)
+    w1k = kofft_amd.hann(1024)
+    frames = -(-sig.size // 256)
+    assert bits_equal(f.stft_into(sig, w1k, 256, frames), oracle.stft(sig, w1k, 256, frames))
+
+
+def case_grid_pct(oracle):
+    _complex(oracle, "c32", 4096, 1300, 21, check=_edges(1300))
+    _complex(oracle, "c64", 1 << 16, 300, 22, check=_edges(300), inverse=False)
+
+
+def case_three_min_high(oracle):  # 2^22 as TWO factors
+    _complex(oracle, "c32", 1 << 22, 2, 31)
+
+
+def case_three_min_low(oracle):  # 2^21 as THREE factors
+    _complex(oracle, "c32", 1 << 21, 3, 32)
+    _complex(oracle, "c64", 1 << 21, 2, 33, inverse=False)
+
+
+def case_small32(oracle):
+    _complex(oracle, "c32", 32, 5000, 41)
+
+
+def case_big_persist(oracle):
+    _complex(oracle, "c64", 1 << 16, 300, 51, check=_edges(300))
+    _complex(oracle, "c32", 1 << 17, 200, 52, check=_edges(200))
+
+
+def case_rfft_wide(oracle):  # rfft / irfft of 32768 and 16384 reals
+    import kofft_amd
+
+    f = kofft_amd.HipFftImpl(np.float32)
+    for n, batch in ((32768, 1100), (16384, 1100)):
+        rows = seeded(61 + n).uniform(-1, 1, (batch, n)).astype(np.float32)
+        pick = _edges(batch)
+        got = f.rfft_batch(rows)
+        assert bits_equal(got[pick], oracle.rfft(rows[pick])), f"rfft {n}"
+        assert bits_equal(f.irfft_batch(got, n)[pick], oracle.irfft(got[pick], n)), f"irfft {n}"
+
+
+def case_persist64(oracle):
+    _complex(oracle, "c64", 4096, 1100, 71, check=_edges(1100))
+    _complex(oracle, "c64", 8192, 1100, 72, check=_edges(1100))
+
+
+def case_persist_small(oracle):
+    import kofft_amd
+
+    f = kofft_amd.HipFftImpl(np.float32)
+    sig = seeded(81).uniform(-1, 1, 700_000).astype(np.float32)
+    for win_len in (64, 128, 256):
+        win = kofft_amd.hann(win_len)
+        hop = win_len // 4
+        frames = -(-sig.size // hop)
+        assert bits_equal(f.stft_into(sig, win, hop, frames), oracle.stft(sig, win, hop, frames)), f"stft {win_len}"
+    spec = rand_c(seeded(82), (9000, 129))
+    spec[:, 0].imag = 0
+    spec[:, -1].imag = 0
+    assert bits_equal(f.irfft_batch(spec, 256), oracle.irfft(spec, 256))
+
+
+def case_split(oracle):
+    _complex(oracle, "c32", 8192, 1100, 91, check=_edges(1100))
+    _complex(oracle, "c32", 16384, 1100, 92, check=_edges(1100))
+
+
+def case_regfile(oracle):
+    _complex(oracle, "c32", 32768, 520, 101, check=_edges(520))
+    _complex(oracle, "c64", 16384, 520, 102, check=_edges(520))
+
+
+def case_host_pipeline(oracle):
+    _complex(oracle, "c32", 4096, 5000, 111, check=_edges(5000), inverse=False)  # 160 MB: the chunked host path otherwise
+
+
+def case_zero_copy(oracle):
+    import kofft_amd
+
+    f = kofft_amd.HipFftImpl(np.float32)
+    x = rand_c(seeded(121), (1024,))
+    y = x.copy()
+    f.fft(y)
+    assert bits_equal(y, oracle.fft(x[None])[0])
+    f.ifft(y)
+    assert bits_equal(y, oracle.ifft(oracle.fft(x[None]))[0])
+
+
+def _nd(oracle, dtype, depth, rows, cols, seed):
+    import kofft_amd
+
+    cdt = np.complex64 if dtype == "c32" else np.complex128
+    f = kofft_amd.HipFftImpl(np.float32 if dtype == "c32" else np.float64)
+    x = rand_c(seeded(seed), (depth, rows, cols), cdt)
+
+    def axis(a, ax):
+        moved = np.ascontiguousarray(np.moveaxis(a, ax, -1))
+        out = oracle.fft(moved.reshape(-1, moved.shape[-1])).reshape(moved.shape)
+        return np.ascontiguousarray(np.moveaxis(out, -1, ax))
+    want = axis(axis(x, 2), 1) if depth == 1 else axis(axis(axis(x, 0), 1), 2)
+    data = x.reshape(-1).copy()
+    f.fftnd(data, depth, rows, cols)
+    assert bits_equal(data.reshape(depth, rows, cols), want), f"fftnd {depth}x{rows}x{cols} {dtype}"
+
+
+def case_nd_transpose(oracle):  # 4096-point axis over 520 (not a power of two) adjacent lines: transposes by default, strided kernel here
+    _nd(oracle, "c32", 1, 4096, 520, 131)
+
+
+def case_nd_two_pass(oracle):  # power-of-two line counts: two column-tile passes by default, transposes here
+    _nd(oracle, "c32", 1, 4096, 512, 141)
+    _nd(oracle, "c64", 2, 4096, 128, 142)
+
+
+def case_bluestein(oracle):
+    _complex(oracle, "c32", 1000, 700, 151)      # one launch by default
+    _complex(oracle, "c32", 12345, 40, 152)      # fused into the transforms' loads / stores by default
+    _complex(oracle, "c64", 40000, 9, 153, inverse=False)  # folded into the factor kernels by default
+
+
+def case_big_narrow(oracle):
+    _complex(oracle, "c32", 1 << 17, 1, 161)
+    _complex(oracle, "c64", 1 << 18, 2, 162)
+
+
+def case_first11(oracle):
+    _complex(oracle, "c32", 1 << 21, 11, 171, check=[0, 5, 10])
+    _complex(oracle, "c64", 1 << 21, 5, 172, check=[0, 4], inverse=False)
+
+
+def case_blocked(oracle):
+    _complex(oracle, "c64", 1 << 17, 40, 181, check=_edges(40))
+
+
+def case_chunk(oracle):  # several chunks, the last one short
+    _complex(oracle, "c64", 1 << 20, 10, 191, check=[0, 3, 4, 9], inverse=False)
+    _complex(oracle, "c32", 1 << 19, 40, 192, check=[0, 15, 16, 39], inverse=False)
+
+
+KNOBS = [
+    ("KOFFT_HIP_NO_PERSIST", "1", case_no_persist),
+    ("KOFFT_HIP_PERSIST_GRID_PCT", "50", case_grid_pct),
+    ("KOFFT_HIP_BIG_THREE_MIN", "23", case_three_min_high),
+    ("KOFFT_HIP_BIG_THREE_MIN", "21", case_three_min_low),
+    ("KOFFT_HIP_SMALL32", "0", case_small32),
+    ("KOFFT_HIP_BIG_PERSIST", "0", case_big_persist),
+    ("KOFFT_HIP_RFFT14_WIDE", "0", case_rfft_wide),
+    ("KOFFT_HIP_RFFT13_PERSIST", "0", case_rfft_wide),
+    ("KOFFT_HIP_PERSIST64", "0", case_persist64),
+    ("KOFFT_HIP_PERSIST_SMALL", "0", case_persist_small),
+    ("KOFFT_HIP_SPLIT", "0", case_split),
+    ("KOFFT_HIP_REGFILE", "0", case_regfile),
+    ("KOFFT_HIP_HOST_PIPELINE", "0", case_host_pipeline),
+    ("KOFFT_HIP_ZERO_COPY", "0", case_zero_copy),
+    ("KOFFT_HIP_ND_TRANSPOSE", "0", case_nd_transpose),
+    ("KOFFT_HIP_ND_TWO_PASS", "0", case_nd_two_pass),
+    ("KOFFT_HIP_BLUESTEIN_FUSED", "0", case_bluestein),
+    ("KOFFT_HIP_BLUESTEIN_ONE", "0", case_bluestein),
+    ("KOFFT_HIP_BIG_NARROW", "0", case_big_narrow),
+    ("KOFFT_HIP_BIG_FIRST11", "0", case_first11),
+    ("KOFFT_HIP_BIG_BLOCKED", "0", case_blocked),
+    ("KOFFT_HIP_BIG_CHUNK_MB", "64", case_chunk),
+]
+
+
+@pytest.mark.parametrize("name,value,case", KNOBS, ids=[f"{k}={v}" for k, v, _ in KNOBS])
+def test_route_switch_in_its_non_default_setting(oracle, monkeypatch, name, value, case):
+    monkeypatch.setenv(name, value)
+    case(oracle)
