@@ -47,7 +47,7 @@ def main():
              "## Kernel stats (--kernel-trace --stats)", "", "| kernel | calls | avg us | min us | max us | % |", "|---|---|---|---|---|---|"]
     for f in newest(str(src / "trace" / "**" / "*_kernel_stats.csv")):
         for r in csv.DictReader(open(f)):
-            k = {"name": short(r["Name"]), "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
+            k = {"name": short(r["Name"]), "ours": "kofft::" in r["Name"], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
                  "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"]), "pct": float(r["Percentage"])}
             if "kofft" in r["Name"] or k["pct"] > 1.0:
                 summary["kernels"].append(k)
@@ -132,7 +132,7 @@ def main():
                           f"(HIP events) -- compare with the --stats average above."]
                 # the same fraction from both clocks: --stats average of the kofft kernels of one step against the HIP events
                 alg = b["roofline"].get("algorithmic_bytes_per_launch")
-                kk = [k for k in summary["kernels"] if "kofft" in k["name"] or "fft_" in k["name"]]
+                kk = [k for k in summary["kernels"] if k.get("ours")]  # every kernel of namespace kofft (istft_ola_kernel, bluestein_wg_kernel ...)
                 steps_total = b.get("launches_total")
                 if alg and kk and steps_total:
                     step_ns = sum(k["avg_ns"] * k["calls"] for k in kk) / steps_total
