@@ -354,9 +354,9 @@ int fft_big_core(kofft_hip_ctx *ctx, const cpx<T> *in_base, size_t in_row, cpx<T
         // Both factors on their persistent kernels (the conditions of launch_sub and of the rows branch below): the intermediate
         // is then block-interleaved -- see BigColsIO::out_lane.
         const bool rows_resident = last_mode == 2 && (nb << (L - L3)) >= persist_units && L3 >= 7 && L3 <= 10;
-        // c64 only (same box, tools/sweep.py, 512 MiB per launch): c64 2^14 .. 2^20 0.338-0.353 -> 0.349-0.395, config 5 12.01 -> 11.91 ms on
-        // a box in the last factor's fast mode, its slow mode 222-231 -> 206 us per chunk; c32 2^18 .. 2^20 LOSES 4-6 % (0.324 / 0.315 /
-        // 0.284 -> 0.305 / 0.295 / 0.269; with streaming loads of the 512-byte runs 0.27) and keeps the natural layout.
+        // c64 only.  On identical buffers (tools/exp_c64_blocked.py, profiles/r04_c64_blocked_ab.txt): equal where the intermediate's
+        // placement is fast, last factor 218-223 -> 203-207 us per chunk where it is slow, never slower.  c32 2^18 .. 2^20
+        // lost 4-6 % in process-level A/Bs (0.324 / 0.315 / 0.284 -> 0.305 / 0.295 / 0.269) and keeps the natural layout.
         if (sizeof(T) == 8 && ctx->big_blocked && !three && first_persist && (nb << (L - L1)) >= persist_units && L1 >= 7 && L1 <= 10 && rows_resident) {
             a.blk_c = ilog2((size_t)tile_persist_xpb<T>(L1));
             a.blk_r = ilog2((size_t)rows_persist_xpb<T>(L3));

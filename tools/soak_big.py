@@ -73,6 +73,35 @@ def main():
             x = rng.uniform(-1, 1, (batch, n)).astype(np.float32)
             win = rng.uniform(0, 1, n).astype(np.float32) if rng.random() < 0.5 else None
             check(bits_equal(f32.rfft_batch(x, win), oracle.rfft(x, win)), ("rfft", n, batch, win is not None))
+        # round 4: the register-file-resident kernels (batches from two transforms per CU; the threshold itself, 512, and around it:
+        # the two-factor route below it), rfft / irfft of 65536 reals through them, the block-interleaved c64 intermediate and the
+        # two-pass ndfft axes
+        for dt, n, cdt in (("c32", 32768, np.complex64), ("c64", 16384, np.complex128)):
+            impl = f32 if dt == "c32" else f64
+            for batch in (int(rng.integers(512, 900)), int(rng.choice([510, 511, 512, 513]))):
+                x = rand_c(rng, (batch, n), cdt)
+                y = x.copy()
+                inv = bool(rng.random() < 0.5)
+                impl.fft_batch(y, inverse=inv)
+                check(bits_equal(y, oracle.ifft(x) if inv else oracle.fft(x)), (dt, n, batch, inv))
+        batch = int(rng.integers(512, 700))
+        x = rng.uniform(-1, 1, (batch, 65536)).astype(np.float32)
+        got = f32.rfft_batch(x)
+        check(bits_equal(got, oracle.rfft(x)), ("rfft", 65536, batch))
+        check(bits_equal(f32.irfft_batch(got, 65536), oracle.irfft(got, 65536)), ("irfft", 65536, batch))
+        for log2n in (14, 15, 16, 18):
+            n = 1 << log2n
+            batch = int(rng.integers((8192 >> (log2n // 2)) + 1, (8192 >> (log2n // 2)) + 40))  # just above the persistent factors' threshold
+            x = rand_c(rng, (batch, n), np.complex128)
+            y = x.copy()
+            f64.fft_batch(y)
+            check(bits_equal(y, oracle.fft(x)), ("c64 blocked", n, batch))
+        for rows, cols in ((4096, int(rng.choice([512, 1024]))), (8192, 256)):
+            x = rand_c(rng, (rows, cols))
+            want = oracle.fft(np.ascontiguousarray(oracle.fft(x).T)).T  # rows, then columns
+            data = x.reshape(-1).copy()
+            f32.fftnd(data, 1, rows, cols)
+            check(bits_equal(data.reshape(rows, cols), np.ascontiguousarray(want)), ("fft2d two-pass", rows, cols))
         print(f"round {r}: {n_cases} cases, {bad} failures", flush=True)
     print("soak done, failures:", bad)
     sys.exit(1 if bad else 0)
