@@ -357,7 +357,10 @@ int fft_big_core(kofft_hip_ctx *ctx, const cpx<T> *in_base, size_t in_row, cpx<T
         // c64 only.  On identical buffers (tools/exp_c64_blocked.py, profiles/r04_c64_blocked_ab.txt): equal where the intermediate's
         // placement is fast, last factor 218-223 -> 203-207 us per chunk where it is slow, never slower.  c32 2^18 .. 2^20
         // lost 4-6 % in process-level A/Bs (0.324 / 0.315 / 0.284 -> 0.305 / 0.295 / 0.269) and keeps the natural layout.
-        if (sizeof(T) == 8 && ctx->big_blocked && !three && first_persist && (nb << (L - L1)) >= persist_units && L1 >= 7 && L1 <= 10 && rows_resident) {
+#ifndef KOFFT_BLOCKED_C32
+#define KOFFT_BLOCKED_C32 0 /* measurement builds: the block-interleaved intermediate for c32 too */
+#endif
+        if ((sizeof(T) == 8 || KOFFT_BLOCKED_C32) && ctx->big_blocked && !three && first_persist && (nb << (L - L1)) >= persist_units && L1 >= 7 && L1 <= 10 && rows_resident) {
             a.blk_c = ilog2((size_t)tile_persist_xpb<T>(L1));
             a.blk_r = ilog2((size_t)rows_persist_xpb<T>(L3));
         }
@@ -382,7 +385,11 @@ int fft_big_core(kofft_hip_ctx *ctx, const cpx<T> *in_base, size_t in_row, cpx<T
         // to 2^9 points) a load is sixteen 32-byte pieces, the rest of each line is wanted by the neighbouring wavefronts a
         // moment later, and a streaming load does not keep it for them (measured, 2 GiB batches: c32 2^15..2^18 0.275-0.295 ->
         // 0.304-0.314 with plain loads, 2^22 0.190 -> 0.198; c32 2^19..2^21 and every c64 size lose 3-10 % without the hint).
+#if KOFFT_BLOCKED_C32 == 2 /* ... with streaming loads of its 512-byte runs */
+        const size_t load_piece = (size_t)(b.blk_r != 0 ? 64 : 64 / big_rows_per_wg<T>(L3)) * sizeof(cpx<T>);
+#else
         const size_t load_piece = (size_t)(64 / big_rows_per_wg<T>(L3)) * sizeof(cpx<T>);
+#endif
         b.nt_load = ctx->big_mid_nt >= 0 ? ctx->big_mid_nt != 0 : (nb * xf_bytes > (size_t(192) << 20) && load_piece >= 64);
         rc = KOFFT_ERR_UNSUPPORTED;
         // last factor: 2 = rows resident (table entries per row tile in LDS), 1 = the generic persistent tile kernel, 0 = one tile

@@ -16,12 +16,17 @@ sys.path.insert(0, str(Path(__file__).resolve().parent))
 import exp_c64_place as P  # noqa: E402
 
 
+def _chk(rc):
+    assert rc == 0, rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--lib", default="kofft_amd/lib_exp/libkofft_hip.so")
     ap.add_argument("--log2n", type=int, default=20)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--pairs", type=int, default=8)
+    ap.add_argument("--f32", action="store_true", help="Complex32 transforms (a -DKOFFT_BLOCKED_C32 build)")
     ap.add_argument("--out", default="gpurun_out/exp11/cells.json")
     args = ap.parse_args()
     import torch
@@ -31,10 +36,11 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     CH = args.batch
-    chunk_bytes = CH * P.N * 16
+    ES = 8 if args.f32 else 16
+    chunk_bytes = CH * P.N * ES
     chunks = 4
     src = torch.empty(chunks * chunk_bytes, dtype=torch.uint8, device=dev)
-    v = src.view(torch.float64)
+    v = src.view(torch.float32 if args.f32 else torch.float64)
     g = torch.Generator(device=dev)
     g.manual_seed(0x6B6F666674 + 5)
     for i in range(0, v.numel(), 1 << 27):
@@ -48,6 +54,10 @@ def main():
     for name, env in (("blocked", "1"), ("natural", "0")):
         os.environ["KOFFT_HIP_BIG_BLOCKED"] = env
         lib = P.Lib(args.lib)
+        if args.f32:
+            lib.lib.kofft_hip_fft_c32_dev_oop.argtypes = lib.lib.kofft_hip_fft_c64_dev_oop.argtypes
+            fn = lib.lib.kofft_hip_fft_c32_dev_oop
+            lib.fft = (lambda L, f: (lambda s_, d_, b_: _chk(f(L.ctx, C.c_void_p(s_), C.c_void_p(d_), P.N, b_, 0))))(lib, fn)
         lib.set_stream(stream.cuda_stream)
         lib.lib.kofft_hip_exp_set_big_tmp.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         libs[name] = lib
