@@ -16,10 +16,17 @@ sys.path.insert(0, str(Path(__file__).resolve().parent))
 from exp_c64_place import N, Lib  # noqa: E402
 
 
+def _chk(rc):
+    assert rc == 0, rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("libs", nargs="+")
     ap.add_argument("--tries", type=int, default=10)
+    ap.add_argument("--f32", action="store_true", help="Complex32 transforms")
+    ap.add_argument("--log2n", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--chunks", type=int, default=4)
     ap.add_argument("--out", default="gpurun_out/exp6/cells.json")
     args = ap.parse_args()
@@ -28,10 +35,13 @@ def main():
     dev = torch.device("cuda", 0)
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
-    CH = 32
-    chunk_bytes = CH * N * 16
+    import exp_c64_place as P
+    P.N = 1 << args.log2n
+    NN = P.N
+    CH = args.batch
+    chunk_bytes = CH * NN * (8 if args.f32 else 16)
     src = torch.empty(args.chunks * chunk_bytes, dtype=torch.uint8, device=dev)
-    v = src.view(torch.float64)
+    v = src.view(torch.float32 if args.f32 else torch.float64)
     g = torch.Generator(device=dev)
     g.manual_seed(0x6B6F666674 + 5)
     for i in range(0, v.numel(), 1 << 27):
@@ -46,6 +56,9 @@ def main():
     for spec in args.libs:
         name, path = spec.split("=", 1)
         lib = Lib(path)
+        if args.f32:
+            lib.lib.kofft_hip_fft_c32_dev_oop.argtypes = lib.lib.kofft_hip_fft_c64_dev_oop.argtypes
+            lib.fft = (lambda L: (lambda s_, d_, b_: _chk(L.lib.kofft_hip_fft_c32_dev_oop(L.ctx, C.c_void_p(s_), C.c_void_p(d_), NN, b_, 0))))(lib)
         lib.set_stream(stream.cuda_stream)
         lib.lib.kofft_hip_exp_set_big_tmp.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         libs[name] = lib
