@@ -256,6 +256,13 @@ int fft_axis2_dev(kofft_hip_ctx *ctx, T *d_data, int LT, int I, size_t blocks, i
     return inverse ? fft_axis2_core<T, true>(ctx, data, LT, I, blocks, L1) : fft_axis2_core<T, false>(ctx, data, LT, I, blocks, L1);
 }
 
+// c32 last factor on ROW PAIRS (round 4): BigRowsIO<float, INV, POST_NONE> -> BigRowsIO<f32x2, INV, POST_NONE> in pair units
+template <class RowsIO> struct rows_pair_io { static constexpr bool ok = false; };
+template <bool INV> struct rows_pair_io<BigRowsIO<float, INV, POST_NONE>> {
+    static constexpr bool ok = true;
+    using type = BigRowsIO<f32x2, INV, POST_NONE>;
+};
+
 template <typename T>
 inline int big_rows_per_wg(int LB) { return LB <= 9 ? KOFFT_BIG_XPB(T) : LB == 10 ? 8 : LB == 11 ? 4 : LB == 12 ? 2 : 1; }
 
@@ -360,6 +367,18 @@ int fft_big_core(kofft_hip_ctx *ctx, const cpx<T> *in_base, size_t in_row, cpx<T
 #ifndef KOFFT_BLOCKED_C32
 #define KOFFT_BLOCKED_C32 0 /* measurement builds: the block-interleaved intermediate for c32 too */
 #endif
+        // c32: the last factor on PAIRS of adjacent rows (BigRowsIO<f32x2>: two Complex<f32> values as one 16-byte value through the c64
+        // kernel's structure -- 16-row tiles at 512 threads, 128-byte runs on both sides) when its policy has no folded pointwise factor; the
+        // first factor then interleaves the rows of a pair (blk_r = 1: 256-byte runs per wavefront store).
+        bool rows_pairs = false;
+        if constexpr (rows_pair_io<RowsIO>::ok) {
+            rows_pairs = ctx->big_row_pairs && !three && first_persist && (nb << (L - L1)) >= persist_units && L1 >= 7 &&
+                         (L1 <= 10 || (L1 == 11 && first11)) && rows_resident;
+            if (rows_pairs) {
+                a.blk_r = 1;
+                a.blk_c = 0;
+            }
+        }
         if ((sizeof(T) == 8 || KOFFT_BLOCKED_C32) && ctx->big_blocked && !three && first_persist && (nb << (L - L1)) >= persist_units && L1 >= 7 && L1 <= 10 && rows_resident) {
             a.blk_c = ilog2((size_t)tile_persist_xpb<T>(L1));
             a.blk_r = ilog2((size_t)rows_persist_xpb<T>(L3));
@@ -377,6 +396,27 @@ int fft_big_core(kofft_hip_ctx *ctx, const cpx<T> *in_base, size_t in_row, cpx<T
         const int LP = L - L3;
         RowsIO b{last_in, dst, LP, L3, L - L3, L - 1 - LP, n, scale, big_rows_per_wg<T>(L3) * sizeof(cpx<T>) >= 64};
         fix_rows(b);
+        if constexpr (rows_pair_io<RowsIO>::ok) {
+            if (rows_pairs) {  // everything in units of one pair (16 bytes): a 2^(LP-1) x 2^L3 matrix in the natural layout
+                using PairIO = typename rows_pair_io<RowsIO>::type;
+                f32x2 sc;
+                sc.x = scale;
+                sc.y = scale;
+                PairIO bp{reinterpret_cast<const cpx<f32x2> *>(last_in), reinterpret_cast<cpx<f32x2> *>(dst), LP - 1, L3, L - L3, L - 1 - LP, n / 2, sc, true};
+                bp.nt_load = nb * xf_bytes > (size_t(192) << 20);
+                const cpx<f32x2> *twp = reinterpret_cast<const cpx<f32x2> *>(tw);  // (only ever read through tw_at: the Complex<f32> table)
+                rc = KOFFT_ERR_UNSUPPORTED;
+                switch (L3) {
+                case 7: rc = launch_rows_persist<f32x2, 7>(ctx, bp, twp, nb); break;
+                case 8: rc = launch_rows_persist<f32x2, 8>(ctx, bp, twp, nb); break;
+                case 9: rc = launch_rows_persist<f32x2, 9>(ctx, bp, twp, nb); break;
+                case 10: rc = launch_rows_persist<f32x2, 10>(ctx, bp, twp, nb); break;
+                default: break;
+                }
+                if (rc) return rc;
+                continue;
+            }
+        }
         b.blk_r = a.blk_r;
         b.blk_c = a.blk_c;
         // an intermediate small enough to stay in the 256 MiB Infinity Cache is read with plain loads (measured on a

@@ -654,6 +654,24 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 1024 ? 4 : 2)) void fft_tile_persi
 // registers.  No global load but the data prefetch is left inside the loop.
 // Work split: `groups` workgroups per row tile when the grid has at least one per tile (each takes every groups-th
 // transform), otherwise every workgroup walks several row tiles and reloads the tables when it moves on.
+// Table entry of a last-factor butterfly.  Row pairs (T = f32x2: rows 2 K and 2 K + 1, K = map.K the PAIR's index): each row its own entry
+// of the Complex<f32> table -- (idx << shift) + (row << (kbase - s)) -- side by side.
+template <typename T>
+__device__ __forceinline__ cpx<T> tw_at(const cpx<T> *__restrict__ tw, const TwSub map, const int idx, const int s)
+{
+    if constexpr (std::is_same<T, f32x2>::value) {
+        const cpx<float> *t = reinterpret_cast<const cpx<float> *>(tw);
+        const int i0 = (idx << map.shift) + ((2 * map.K) << (map.kbase - s));
+        const cpx<float> a = t[i0], b = t[i0 + (1 << (map.kbase - s))];
+        f32x2 re, im;
+        re.x = a.re; re.y = b.re;
+        im.x = a.im; im.y = b.im;
+        return mk<T>(re, im);
+    } else {
+        return tw[map(idx, s)];
+    }
+}
+
 template <typename T, int Q, int STRIDE>
 __device__ __forceinline__ void reg_pass_lds(cpx<T> *v, const cpx<T> *tl)
 {
@@ -680,7 +698,7 @@ __device__ __forceinline__ void load_pass_twiddles_map(cpx<T> *twr, const int k,
 #pragma unroll
         for (int h = 0; h < (1 << t); ++h) {
             const int idx = (k << (L - 1 - S0 - t)) + (bitrev(h, t) << (L - 1 - t));
-            twr[(1 << t) - 1 + h] = tw[map(idx, S0 + t)];
+            twr[(1 << t) - 1 + h] = tw_at<T>(tw, map, idx, S0 + t);
         }
     }
 }
@@ -765,7 +783,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 1024 ? 4 : 2)) void fft_rows_persi
 #pragma unroll
             for (int h = 0; h < (1 << t); ++h) {
                 const int idx = (k << (L - 1 - S0 - t)) + (bitrev(h, t) << (L - 1 - t));
-                cells[((1 << t) - 1 + h) * XPB] = tw[map(idx, S0 + t)];
+                cells[((1 << t) - 1 + h) * XPB] = tw_at<T>(tw, map, idx, S0 + t);
             }
         }
     };

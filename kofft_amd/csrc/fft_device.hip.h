@@ -21,6 +21,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace kofft {
 
 template <typename T>
@@ -84,11 +86,24 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void *base, unsigned bytes)
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
 }
 
+// Two Complex<f32> values of ADJACENT ROWS as one 16-byte value (round 4: the c32 last factor on row pairs, fft_big.hip.h): the "scalar"
+// is a 2-vector of f32, every arithmetic operation is elementwise (v_pk_*_f32: the same IEEE operations on each row's value with that
+// row's table entry).  In memory such a value is {row0.re, row0.im, row1.re, row1.im}; in registers {re: {row0, row1}, im: {row0, row1}}.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 // NOTE: the loaded vector is bit-cast as a WHOLE.  Extracting .x/.y from the <2 x i32> result and casting
 // each to float makes hipcc (ROCm 7.2) narrow the load to one dword and duplicate it.
 template <typename T, int AUX>
 __device__ __forceinline__ cpx<T> buf_load_cpx(rsrc_t r, int voff, int coff)
 {
+    if constexpr (std::is_same<T, f32x2>::value) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f f4 = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, voff, coff, AUX));
+        f32x2 re, im;
+        re.x = f4.x; re.y = f4.z;
+        im.x = f4.y; im.y = f4.w;
+        return mk<T>(re, im);
+    } else {
     typedef T vec2 __attribute__((ext_vector_type(2)));
     vec2 f;
     if constexpr (sizeof(T) == 4) {
@@ -101,6 +116,7 @@ __device__ __forceinline__ cpx<T> buf_load_cpx(rsrc_t r, int voff, int coff)
         f = __builtin_bit_cast(vec2, v);
     }
     return mk<T>(f.x, f.y);
+    }
 }
 
 #ifndef KOFFT_STORE_AUX
@@ -125,6 +141,14 @@ __device__ __forceinline__ void buf_store_cpx(cpx<T> c, rsrc_t r, int voff, int 
 template <typename T, int AUX>
 __device__ __forceinline__ void buf_store_cpx_aux(cpx<T> c, rsrc_t r, int voff, int coff)
 {
+    if constexpr (std::is_same<T, f32x2>::value) {
+        typedef unsigned v4u __attribute__((ext_vector_type(4)));
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        v4f f4;
+        f4.x = c.re.x; f4.y = c.im.x; f4.z = c.re.y; f4.w = c.im.y;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, f4), r, voff, coff, AUX);
+        return;
+    } else {
     typedef T vec2 __attribute__((ext_vector_type(2)));
     vec2 f;
     f.x = c.re;
@@ -135,6 +159,7 @@ __device__ __forceinline__ void buf_store_cpx_aux(cpx<T> c, rsrc_t r, int voff, 
     } else {
         typedef unsigned v4u __attribute__((ext_vector_type(4)));
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, f), r, voff, coff, AUX);
+    }
     }
 }
 

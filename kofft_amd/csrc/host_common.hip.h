@@ -76,6 +76,7 @@ struct kofft_hip_ctx {
     // intermediate of the two-factor large-n path (fft_big.hip.h): `big_chunk` transforms at a time
     void *big_tmp = nullptr;
     size_t big_tmp_bytes = 0;
+    bool big_row_pairs = true;       // KOFFT_HIP_BIG_ROW_PAIRS=0: c32 last factor one row per thread slot (8-row tiles) instead of row pairs (A/B)
     bool big_blocked = true;         // KOFFT_HIP_BIG_BLOCKED=0: natural layout of the two-factor intermediate (A/B)
     bool big_tmp_external = false;  // KOFFT_EXP_API builds only: the intermediate belongs to the experiment script
     // small host-pointer calls (one frame, one transform): a pinned, device-mapped buffer the kernels read and write

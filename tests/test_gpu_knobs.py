@@ -204,6 +204,7 @@ KNOBS = [
     ("KOFFT_HIP_BIG_NARROW", "0", case_big_narrow),
     ("KOFFT_HIP_BIG_FIRST11", "0", case_first11),
     ("KOFFT_HIP_BIG_BLOCKED", "0", case_blocked),
+    ("KOFFT_HIP_BIG_ROW_PAIRS", "0", case_big_persist),
     ("KOFFT_HIP_BIG_CHUNK_MB", "64", case_chunk),
 ]
 

@@ -463,6 +463,34 @@ def test_regfile_resident_kernels_every_transform(oracle, dtype, log2n, batch, m
     assert_parity(outs[0][1], oracle.ifft(want), f"regfile inverse {dtype} 2^{log2n} x {batch}", tol)
 
 
+@pytest.mark.parametrize("log2n,batch", [(15, 40), (16, 40), (17, 33), (18, 20), (19, 18), (20, 10), (21, 9)])
+def test_c32_last_factor_on_row_pairs(oracle, log2n, batch, monkeypatch):
+    """Round 4: the c32 last factor of the two-factor path runs on PAIRS of adjacent rows -- two Complex<f32> values as one 16-byte value
+    (f32x2 "scalars": every operation elementwise, each row with its own table entry) through the c64 kernel's structure, 16-row tiles,
+    128-byte runs on both sides; the first factor interleaves the rows of a pair in the intermediate (blk_r = 1).
+    KOFFT_HIP_BIG_ROW_PAIRS=0 keeps one row per thread slot.  EVERY transform of the batch byte for byte between the two routes, forward
+    and inverse; first / middle / last against the oracle."""
+    import kofft_amd
+
+    n = 1 << log2n
+    x = rand_c(seeded(4500 + log2n), (batch, n))
+    outs = []
+    for pairs in ("1", "0"):
+        monkeypatch.setenv("KOFFT_HIP_BIG_ROW_PAIRS", pairs)  # read when the context is created
+        monkeypatch.setenv("KOFFT_HIP_REGFILE", "0")          # (2^15: keep it on the factor path whatever the batch)
+        f = kofft_amd.HipFftImpl(np.float32)
+        y = x.copy()
+        f.fft_batch(y)
+        z = y.copy()
+        f.fft_batch(z, inverse=True)
+        outs.append((y, z))
+    assert bits_equal(outs[0][0], outs[1][0]) and bits_equal(outs[0][1], outs[1][1])
+    pick = [0, batch // 2, batch - 1]
+    want = oracle.fft(x[pick])
+    assert_parity(outs[0][0][pick], want, f"row pairs c32 2^{log2n}", REL_TOL_F32)
+    assert_parity(outs[0][1][pick], oracle.ifft(want), f"row pairs inverse c32 2^{log2n}", REL_TOL_F32)
+
+
 @pytest.mark.parametrize("log2n,batch", [(14, 70), (15, 33), (17, 40), (19, 20), (20, 10)])
 def test_c64_factor_intermediate_layouts_agree(oracle, log2n, batch, monkeypatch):
     """Round 4: between the two persistent factor kernels the c64 intermediate is block-interleaved (BigColsIO::out_lane: one
