@@ -552,6 +552,57 @@ int launch_bluestein_wg(kofft_hip_ctx *ctx, const cpx<T> *in, cpx<T> *out, const
     return KOFFT_OK;
 }
 
+// The same arm as a persistent kernel (bluestein_persist_kernel): batches that give every workgroup several transforms.
+// workgroups per CU: what the registers allow (f32, 16 points per thread: 166-208 VGPRs; 8: 94-100; 4: 57-59)
+// (8 points per thread from m = 1024 on -- four passes, three or four workgroups per CU -- measured: m = 2048 -3 %, m = 1024 +5 %, m = 4096 +11 % of time)
+constexpr int blue_persist_rl(int L) { return rl_for(L); }
+constexpr int blue_persist_block(int L) { return block_for(L); }
+template <typename T>
+constexpr int blue_persist_wg(int L)
+{
+    return sizeof(T) == 4 ? (blue_persist_rl(L) >= 4 ? 2 : blue_persist_rl(L) == 3 ? 4 : 6) : (blue_persist_rl(L) >= 3 ? 2 : 4);
+}
+#ifndef KOFFT_BLUE_PERSIST_MIN_ITERS
+#define KOFFT_BLUE_PERSIST_MIN_ITERS 4
+#endif
+template <typename T, int L>
+constexpr bool blue_persist_ok()
+{
+    // f64 with 16 points per thread: the twiddles alone are 176 registers
+    return sizeof(T) == 4 ? (L >= 5 && L <= 12) : (L >= 5 && L <= 10 && rl_for(L) <= 3);
+}
+template <typename T, int L, bool INVERSE>
+int launch_bluestein_persist(kofft_hip_ctx *ctx, const cpx<T> *in, cpx<T> *out, const cpx<T> *chirp, const cpx<T> *bfft, const cpx<T> *tw,
+                             size_t n, size_t batch, T scale_m, T scale_n)
+{
+    constexpr int RL = blue_persist_rl(L);
+    constexpr int BLOCK = blue_persist_block(L);
+    constexpr int TPT = (1 << L) >> RL;
+    constexpr int XPB = BLOCK / TPT;
+    constexpr size_t lds = (size_t)XPB * lds_elems(1 << L) * sizeof(cpx<T>);
+    static_assert(lds * blue_persist_wg<T>(L) <= 160 * 1024, "LDS budget");
+    auto kern = bluestein_persist_kernel<T, L, RL, BLOCK, blue_persist_wg<T>(L), INVERSE>;
+    {
+        static std::atomic<unsigned long long> attr_done{0};
+        const int arc = set_dyn_lds_once(ctx, attr_done, reinterpret_cast<const void *>(kern), lds);
+        if (arc) return arc;
+    }
+    size_t blocks = (size_t)ctx->num_cus * blue_persist_wg<T>(L);
+    if (ctx->persist_grid_pct > 0) blocks = blocks * (size_t)ctx->persist_grid_pct / 100;
+    if (blocks < 1) blocks = 1;
+    const size_t need = (batch + XPB - 1) / XPB;
+    if (blocks > need) blocks = need;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BLOCK), lds, ctx->stream, in, out, chirp, bfft, tw, (int)n, scale_m, scale_n, batch);
+    KOFFT_HIP_TRY(ctx, hipGetLastError());
+    return KOFFT_OK;
+}
+template <typename T, int L>
+bool blue_persist_pays(const kofft_hip_ctx *ctx, size_t batch)
+{
+    constexpr int XPB = blue_persist_block(L) / ((1 << L) >> blue_persist_rl(L));
+    return ctx->blue_persist && batch >= (size_t)ctx->num_cus * blue_persist_wg<T>(L) * XPB * KOFFT_BLUE_PERSIST_MIN_ITERS;
+}
+
 template <typename T, bool INVERSE>
 int fft_bluestein_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t batch)
 {
@@ -572,8 +623,11 @@ int fft_bluestein_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, siz
             const cpx<T> *src = reinterpret_cast<const cpx<T> *>(d_in);
             cpx<T> *dst = reinterpret_cast<cpx<T> *>(d_out);
             switch (L) {
-#define KOFFT_CASE(LL) \
-    case LL: return launch_bluestein_wg<T, LL, INVERSE>(ctx, src, dst, chirp, bfft, tw, n, batch, sm, sn);
+#define KOFFT_CASE(LL)                                                                                                  \
+    case LL:                                                                                                            \
+        if constexpr (blue_persist_ok<T, LL>())                                                                         \
+            if (blue_persist_pays<T, LL>(ctx, batch)) return launch_bluestein_persist<T, LL, INVERSE>(ctx, src, dst, chirp, bfft, tw, n, batch, sm, sn); \
+        return launch_bluestein_wg<T, LL, INVERSE>(ctx, src, dst, chirp, bfft, tw, n, batch, sm, sn);
                 KOFFT_CASE(5)
                 KOFFT_CASE(6)
                 KOFFT_CASE(7)

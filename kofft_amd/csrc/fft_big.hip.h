@@ -1082,6 +1082,174 @@ __global__ __launch_bounds__(BLOCK) void bluestein_wg_kernel(const cpx<T> *__res
     }
 }
 
+// ---- the same arm, persistent (round 4) -------------------------------------------------------------------------------------
+// bluestein_wg_kernel starts a workgroup per XPB transforms, and each of them reads its table entries again: per transform and
+// thread 2 x (R - 1) x (NP - 1) twiddles (gathers with strides of 2^s entries: up to 64 cache lines per instruction), R entries of
+// fft(b) and 2 x R of the chirp -- at m = 2048 five times the bytes of the transform's own input, all through the vector L1, and
+// every pass waits for them (SQ_WAIT_ANY 65 % of the wave cycles, VALU 44 % busy: profiles/r04_bluestein1000.md as first collected).
+// Here the grid is sized to the chip, a workgroup loops over transforms, and what depends on the thread but not on the transform is
+// read ONCE: the twiddles of passes 1.. and fft(b) live in registers (pass 0's table indices are compile-time constants: scalar
+// loads), the next transform's input is in flight while this one is computed.  The chirp entries stay loads (coalesced, 8 KiB,
+// L1 hits): keeping them would cost 2 x R more registers and the second wavefront per SIMD.
+// Same butterflies, same table entries, same pointwise expressions: bit-identical to bluestein_wg_kernel.
+template <typename T, int L, int RL, int BLOCK, int WG_PER_CU, bool INVERSE>
+__global__ __launch_bounds__(BLOCK, WG_PER_CU * BLOCK / 256 /* wavefronts per SIMD */) void bluestein_persist_kernel(const cpx<T> *__restrict__ in, cpx<T> *__restrict__ out,
+                                                                                        const cpx<T> *__restrict__ chirp,
+                                                                                        const cpx<T> *__restrict__ bfft,
+                                                                                        const cpx<T> *__restrict__ tw, const int n, const T scale_m,
+                                                                                        const T scale_n, const size_t batch)
+{
+    constexpr int N = 1 << L;
+    constexpr int R = 1 << RL;
+    constexpr int TPT = N / R;
+    static_assert(TPT >= 1 && BLOCK % TPT == 0, "bad geometry");
+    constexpr int XPB = BLOCK / TPT;
+    constexpr int NP = (L + RL - 1) / RL;
+    static_assert(NP >= 2 && NP <= 4, "pass count");
+    constexpr bool WAVE = TPT <= 64;  // a transform inside one wavefront: its exchanges need no s_barrier
+    using G0 = WgGeom<L, RL, 0>;
+    using GL = WgGeom<L, RL, NP - 1>;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x;
+    const int tau = tid % TPT, slot = tid / TPT;
+    cpx<T> *buf = reinterpret_cast<cpx<T> *>(smem_raw) + (size_t)slot * lds_elems(N);
+
+    // per-thread invariants
+    cpx<T> tw1[R - 1], tw2[NP >= 3 ? R - 1 : 1], tw3[NP >= 4 ? R - 1 : 1];
+    persist_load_tw<T, L, RL, 1>(tw1, tau, tw);
+    if constexpr (NP >= 3) persist_load_tw<T, L, RL, 2>(tw2, tau, tw);
+    if constexpr (NP >= 4) persist_load_tw<T, L, RL, 3>(tw3, tau, tw);
+    constexpr bool BF_REG = RL <= 3 && NP <= 3;  // otherwise fft(b)'s entries are read while the first transform's last pass computes
+    cpx<T> bf[BF_REG ? R : 1];
+    if constexpr (BF_REG) {
+#pragma unroll
+        for (int u = 0; u < R; ++u) bf[u] = bfft[GL::out_index(tau, u)];
+    }
+    const int sc = lds_pad(tau);
+    const int g1 = lds_pad(WgGeom<L, RL, 1>::in_index(tau, 0));
+    const int g2 = NP >= 3 ? lds_pad(WgGeom<L, RL, (NP >= 3 ? 2 : 0)>::in_index(tau, 0)) : 0;
+    const int g3 = NP >= 4 ? lds_pad(WgGeom<L, RL, (NP >= 4 ? 3 : 0)>::in_index(tau, 0)) : 0;
+
+    // m = (2n - 1).next_power_of_two() >= 2n: elements m/2 .. m-1 of the padded input are zeros and outputs m/2 .. m-1 are never stored, for
+    // every n of this m -- half of the loads, chirp entries and stores are decided at compile time (RH registers of input in flight)
+    constexpr int RH = R / 2;
+    static_assert(G0::in_index(0, RH) == N / 2, "pass 0: the register number is the index's top bits");
+    auto fetch = [&](cpx<T> *raw, size_t xf) {
+        const size_t xc = xf < batch ? xf : batch - 1;  // past the end: a valid address, the values are never stored
+        const cpx<T> *row = in + xc * (size_t)n;
+#pragma unroll
+        for (int u = 0; u < RH; ++u) {
+            const int i = G0::in_index(tau, u);
+            raw[u] = ld_stream(row + (i < n ? i : n - 1));
+        }
+    };
+    auto transform = [&](cpx<T> *v, auto &&before_last) {  // before_last(): table loads that ride under the last pass's butterflies
+        persist_compute_p0<T, L, RL>(v, tw);
+        exchange_sync<WAVE>();  // the buffer's previous gathers are done
+        persist_lds_scatter<T, L, RL, 0>(v, buf, sc);
+        exchange_sync<WAVE>();
+        persist_lds_gather<T, L, RL, 1>(v, buf, g1);
+        if constexpr (NP == 2) before_last();
+        persist_compute<T, L, RL, 1>(v, tw1);
+        if constexpr (NP >= 3) {
+            exchange_sync<WAVE>();
+            persist_lds_scatter<T, L, RL, 1>(v, buf, sc);
+            exchange_sync<WAVE>();
+            persist_lds_gather<T, L, RL, 2>(v, buf, g2);
+            if constexpr (NP == 3) before_last();
+            persist_compute<T, L, RL, 2>(v, tw2);
+        }
+        if constexpr (NP >= 4) {
+            exchange_sync<WAVE>();
+            persist_lds_scatter<T, L, RL, 2>(v, buf, sc);
+            exchange_sync<WAVE>();
+            persist_lds_gather<T, L, RL, 3>(v, buf, g3);
+            before_last();
+            persist_compute<T, L, RL, 3>(v, tw3);
+        }
+    };
+
+    const size_t stride = (size_t)gridDim.x * XPB;
+    size_t xf = (size_t)blockIdx.x * XPB + slot;
+    cpx<T> raw[RH];
+    fetch(raw, xf);
+    for (size_t base = (size_t)blockIdx.x * XPB; base < batch; base += stride, xf += stride) {
+        // the table addresses below depend on the thread only: left visible, the compiler hoists the LOADS out of the transform loop
+        // (3 x R values in registers, spilled); an opaque copy of tau per transform keeps them loads
+        int tau_t = tau;
+        asm volatile("" : "+v"(tau_t));
+        cpx<T> v[R];
+#pragma unroll
+        for (int u = 0; u < RH; ++u) {
+            const int i = G0::in_index(tau_t, u);
+            cpx<T> x = raw[u];
+            if (INVERSE) x.im = -x.im;  // ifft: conj on the way in (fft.rs:1163-1165)
+            const cpx<T> a = cmul(x, chirp[i < n ? i : n - 1]);
+            v[u] = i < n ? a : mk<T>(T(0), T(0));
+        }
+#pragma unroll
+        for (int u = RH; u < R; ++u) v[u] = mk<T>(T(0), T(0));
+        fetch(raw, xf + stride);
+        cpx<T> tab[R];  // fft(b)'s entries, then the chirp's for the output
+        transform(v, [&]() {
+            if constexpr (!BF_REG) {
+#pragma unroll
+                for (int u = 0; u < R; ++u) tab[u] = bfft[GL::out_index(tau_t, u)];
+            }
+        });
+        // a *= fft(b) (fft.rs:1119-1121), ifft's conj on the way in; natural order -> the first pass's register layout
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            cpx<T> w = cmul(v[u], BF_REG ? bf[BF_REG ? u : 0] : tab[u]);
+            w.im = -w.im;
+            v[u] = w;
+        }
+        // natural order -> the first pass's register layout.  Both are "RL index bits from the register number, the rest from the
+        // thread": out_index(tau, u) = [bitrev(c) | g | tau] with u = (g, c), in_index(tau, u') = [u' | tau] -- the same element sits
+        // in the same THREAD, register u' = bitrev(c) << (RL - Q) | g: a renaming, no exchange (bluestein_wg_kernel goes through LDS)
+        {
+            cpx<T> w[R];
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                static_assert(GL::out_index(0, 1) >= TPT && G0::in_index(0, 1) == TPT, "register bits above the thread bits");
+                w[GL::out_index(0, u) / TPT] = v[u];
+            }
+#pragma unroll
+            for (int u = 0; u < R; ++u) v[u] = w[G0::in_index(0, u) / TPT];
+        }
+        // (without the exchange's barrier the two transforms' passes interleave and registers spill; pinning the values here: m = 2048 0.65 -> 0.58 ms)
+#pragma unroll
+        for (int u = 0; u < R; ++u) asm volatile("" : "+v"(v[u].re), "+v"(v[u].im));
+        transform(v, [&]() {
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                if (GL::out_index(0, u) >= N / 2) continue;
+                const int o = GL::out_index(tau_t, u);
+                tab[u] = chirp[o < n ? o : n - 1];
+            }
+        });
+        if (xf < batch) {
+            cpx<T> *orow = out + xf * (size_t)n;
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                if (GL::out_index(0, u) >= N / 2) continue;
+                const int o = GL::out_index(tau, u);
+                if (o < n) {
+                    cpx<T> a = v[u];
+                    a.im = -a.im;  // ifft: conj, * 1/m (fft.rs:1168-1172)
+                    a = mk<T>(a.re * scale_m, a.im * scale_m);
+                    cpx<T> r = cmul(a, tab[u]);
+                    if (INVERSE) {
+                        const T im = -r.im;
+                        r = mk<T>(r.re * scale_n, im * scale_n);
+                    }
+                    st_stream(orow + o, r);
+                }
+            }
+        }
+    }
+}
+
 template <typename T, bool INVERSE>
 __global__ __launch_bounds__(256) void bluestein_pre_kernel(const cpx<T> *__restrict__ in, cpx<T> *__restrict__ a,
                                                             const cpx<T> *__restrict__ chirp, const size_t n, const size_t m,

@@ -163,6 +163,11 @@ def case_bluestein(oracle):
     _complex(oracle, "c64", 40000, 9, 153, inverse=False)  # folded into the factor kernels by default
 
 
+def case_bluestein_persist(oracle):  # large batches: the persistent kernel by default, one workgroup per XPB transforms here
+    _complex(oracle, "c32", 1000, 4200, 155, check=_edges(4200))
+    _complex(oracle, "c64", 60, 66000, 156, check=_edges(66000))
+
+
 def case_big_narrow(oracle):
     _complex(oracle, "c32", 1 << 17, 1, 161)
     _complex(oracle, "c64", 1 << 18, 2, 162)
@@ -201,6 +206,7 @@ KNOBS = [
     ("KOFFT_HIP_ND_TWO_PASS", "0", case_nd_two_pass),
     ("KOFFT_HIP_BLUESTEIN_FUSED", "0", case_bluestein),
     ("KOFFT_HIP_BLUESTEIN_ONE", "0", case_bluestein),
+    ("KOFFT_HIP_BLUESTEIN_PERSIST", "0", case_bluestein_persist),
     ("KOFFT_HIP_BIG_NARROW", "0", case_big_narrow),
     ("KOFFT_HIP_BIG_FIRST11", "0", case_first11),
     ("KOFFT_HIP_BIG_BLOCKED", "0", case_blocked),

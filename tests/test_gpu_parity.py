@@ -812,6 +812,40 @@ def test_bluestein_one_launch_and_two_launch_routes(oracle, one_kernel, monkeypa
         assert_parity(y, oracle.ifft(want), f"bluestein route {one_kernel} ifft c64 n={n}", REL_TOL_F64)
 
 
+@pytest.mark.parametrize("dtype,n,batch", [
+    ("c32", 12, 196_608 + 37), ("c32", 30, 98_304 + 5), ("c32", 60, 65_536 + 21), ("c32", 100, 32_768 + 9), ("c32", 250, 16_384 + 3),
+    ("c32", 500, 8_192 + 7), ("c32", 1000, 4_096 + 3), ("c32", 1024 + 1, 4_096 + 2), ("c32", 2000, 2_048 + 1),
+    ("c64", 12, 196_608 + 37), ("c64", 30, 98_304 + 5), ("c64", 60, 65_536 + 21), ("c64", 250, 16_384 + 3),
+])
+def test_bluestein_persistent_kernel_large_batches(oracle, dtype, n, batch):
+    """Batches that give every workgroup of the chip-sized grid several transforms run bluestein_persist_kernel (twiddles and fft(b) in
+    registers, next input prefetched): m = 32 ... 4096 (c32), m = 32 ... 128 and 512 (c64), ragged last round, forward and inverse,
+    first / last / middle rows against the oracle and every row against the one-workgroup-per-transform kernel (small batches)."""
+    import kofft_amd
+
+    cdt = np.complex64 if dtype == "c32" else np.complex128
+    f = kofft_amd.HipFftImpl(np.float32 if dtype == "c32" else np.float64)
+    x = rand_c(seeded(2300 + n), (batch, n), cdt)
+    y = x.copy()
+    f.fft_batch(y)
+    pick = sorted({0, 1, 2, batch // 3, batch // 2, batch - 3, batch - 2, batch - 1})
+    want = oracle.fft(x[pick])
+    assert_parity(y[pick], want, f"bluestein persistent fft {dtype} n={n}", REL_TOL_F32 if dtype == "c32" else REL_TOL_F64)
+    # every row: the same rows in small batches (the non-persistent kernel, itself checked against the oracle above and elsewhere)
+    step = 64
+    rows = np.arange(0, batch, max(1, batch // 2000))
+    ref = np.concatenate([_small_batches(f, x[rows[i:i + step]]) for i in range(0, rows.size, step)])
+    assert bits_equal(y[rows], ref), f"bluestein persistent vs per-transform kernel {dtype} n={n}"
+    f.fft_batch(y, inverse=True)
+    assert_parity(y[pick], oracle.ifft(want), f"bluestein persistent ifft {dtype} n={n}", REL_TOL_F32 if dtype == "c32" else REL_TOL_F64)
+
+
+def _small_batches(f, rows):
+    out = rows.copy()
+    f.fft_batch(out)
+    return out
+
+
 def test_bluestein_reference_tests(fft32, fft64, oracle):
     # tests/bluestein.rs:32-66: n = 15 against the naive f32 DFT within 1e-3
     n = 15

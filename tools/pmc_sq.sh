@@ -22,7 +22,7 @@ for p in "abc":
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            if "fft_" not in k: continue
+            if "kofft::" not in k: continue
             acc[k[:90]][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, d in acc.items():
             print(k)
