@@ -553,14 +553,21 @@ int launch_bluestein_wg(kofft_hip_ctx *ctx, const cpx<T> *in, cpx<T> *out, const
 }
 
 // The same arm as a persistent kernel (bluestein_persist_kernel): batches that give every workgroup several transforms.
-// workgroups per CU: what the registers allow (f32, 16 points per thread: 166-208 VGPRs; 8: 94-100; 4: 57-59)
+// workgroups per CU, within what the registers allow (f32, 16 points per thread: 166-208 VGPRs; 8: 94-100; 4: 57-59)
 // (8 points per thread from m = 1024 on -- four passes, three or four workgroups per CU -- measured: m = 2048 -3 %, m = 1024 +5 %, m = 4096 +11 % of time)
-constexpr int blue_persist_rl(int L) { return rl_for(L); }
-constexpr int blue_persist_block(int L) { return block_for(L); }
+// f64: 8 points per thread at most (16: the twiddles alone are 176 registers)
+template <typename T>
+constexpr int blue_persist_rl(int L) { return sizeof(T) == 8 ? (rl_for(L) > 3 ? 3 : rl_for(L)) : (L >= 13 ? 4 : rl_for(L)); }
+template <typename T>
+constexpr int blue_persist_block(int L) { return ((1 << L) >> blue_persist_rl<T>(L)) > 256 ? ((1 << L) >> blue_persist_rl<T>(L)) : 256; }
 template <typename T>
 constexpr int blue_persist_wg(int L)
 {
-    return sizeof(T) == 4 ? (blue_persist_rl(L) >= 4 ? 2 : blue_persist_rl(L) == 3 ? 4 : 6) : (blue_persist_rl(L) >= 3 ? 2 : 4);
+    // measured, same box, ms per 65.5 M points: m = 32 / 64 six -> eight 0.41 -> 0.38 / 0.42 -> 0.40; m = 128 four -> five 0.38 -> 0.37; m = 512 four -> five
+    // 0.385 -> 0.395; m = 256 / 1024 two -> three 0.39 -> 0.36 / 0.455 -> 0.415; m = 2048 / 4096 need 208 / 194 registers (two)
+    if (blue_persist_block<T>(L) > 256) return 1;  // m = 8192 (f32), 4096 (f64): 512 threads, two wavefronts per SIMD
+    if (sizeof(T) == 8) return blue_persist_rl<T>(L) >= 3 ? 2 : 4;
+    return blue_persist_rl<T>(L) >= 4 ? (L <= 10 ? 3 : 2) : blue_persist_rl<T>(L) == 3 ? (L == 7 ? 5 : 4) : 8;
 }
 #ifndef KOFFT_BLUE_PERSIST_MIN_ITERS
 #define KOFFT_BLUE_PERSIST_MIN_ITERS 4
@@ -568,15 +575,14 @@ constexpr int blue_persist_wg(int L)
 template <typename T, int L>
 constexpr bool blue_persist_ok()
 {
-    // f64 with 16 points per thread: the twiddles alone are 176 registers
-    return sizeof(T) == 4 ? (L >= 5 && L <= 12) : (L >= 5 && L <= 10 && rl_for(L) <= 3);
+    return L >= 5 && L <= (sizeof(T) == 4 ? 13 : 12);
 }
 template <typename T, int L, bool INVERSE>
 int launch_bluestein_persist(kofft_hip_ctx *ctx, const cpx<T> *in, cpx<T> *out, const cpx<T> *chirp, const cpx<T> *bfft, const cpx<T> *tw,
                              size_t n, size_t batch, T scale_m, T scale_n)
 {
-    constexpr int RL = blue_persist_rl(L);
-    constexpr int BLOCK = blue_persist_block(L);
+    constexpr int RL = blue_persist_rl<T>(L);
+    constexpr int BLOCK = blue_persist_block<T>(L);
     constexpr int TPT = (1 << L) >> RL;
     constexpr int XPB = BLOCK / TPT;
     constexpr size_t lds = (size_t)XPB * lds_elems(1 << L) * sizeof(cpx<T>);
@@ -599,7 +605,7 @@ int launch_bluestein_persist(kofft_hip_ctx *ctx, const cpx<T> *in, cpx<T> *out, 
 template <typename T, int L>
 bool blue_persist_pays(const kofft_hip_ctx *ctx, size_t batch)
 {
-    constexpr int XPB = blue_persist_block(L) / ((1 << L) >> blue_persist_rl(L));
+    constexpr int XPB = blue_persist_block<T>(L) / ((1 << L) >> blue_persist_rl<T>(L));
     return ctx->blue_persist && batch >= (size_t)ctx->num_cus * blue_persist_wg<T>(L) * XPB * KOFFT_BLUE_PERSIST_MIN_ITERS;
 }
 
@@ -613,9 +619,10 @@ int fft_bluestein_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, siz
     if (rc) return rc;
     if (ctx->blue_fused && ctx->blue_one_kernel) {
         const int L = ilog2(m);
-        // measured (tools/bench_bluestein.py): one launch wins 15..50 % up to m = 4096 (c32) / 1024 (c64); beyond, the kernel
-        // needs more than 256 registers (one wavefront per SIMD) and the two launches are faster (n = 4095: 1.09 vs 1.70 ms)
-        if (L >= 5 && L <= (sizeof(T) == 4 ? 12 : 10)) {
+        // measured (tools/bench_bluestein.py): one workgroup per XPB transforms wins 15..50 % over two launches up to m = 4096 (c32) /
+        // 1024 (c64); beyond, that kernel needs more than 256 registers and the two launches are faster (n = 4095: 1.09 vs 1.70 ms).
+        // The persistent form (large batches) reaches m = 8192 (c32) / 4096 (c64)
+        if (L >= 5 && L <= 13) {
             const cpx<T> *tw = nullptr;
             rc = get_table<T>(ctx, Kind<T>::tw, m, &tw);
             if (rc) return rc;
@@ -627,7 +634,8 @@ int fft_bluestein_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, siz
     case LL:                                                                                                            \
         if constexpr (blue_persist_ok<T, LL>())                                                                         \
             if (blue_persist_pays<T, LL>(ctx, batch)) return launch_bluestein_persist<T, LL, INVERSE>(ctx, src, dst, chirp, bfft, tw, n, batch, sm, sn); \
-        return launch_bluestein_wg<T, LL, INVERSE>(ctx, src, dst, chirp, bfft, tw, n, batch, sm, sn);
+        if constexpr (LL <= (sizeof(T) == 4 ? 12 : 10)) return launch_bluestein_wg<T, LL, INVERSE>(ctx, src, dst, chirp, bfft, tw, n, batch, sm, sn); \
+        break;
                 KOFFT_CASE(5)
                 KOFFT_CASE(6)
                 KOFFT_CASE(7)
@@ -636,6 +644,7 @@ int fft_bluestein_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, siz
                 KOFFT_CASE(10)
                 KOFFT_CASE(11)
                 KOFFT_CASE(12)
+                KOFFT_CASE(13)
 #undef KOFFT_CASE
             default: break;
             }

@@ -813,13 +813,16 @@ def test_bluestein_one_launch_and_two_launch_routes(oracle, one_kernel, monkeypa
 
 
 @pytest.mark.parametrize("dtype,n,batch", [
-    ("c32", 12, 196_608 + 37), ("c32", 30, 98_304 + 5), ("c32", 60, 65_536 + 21), ("c32", 100, 32_768 + 9), ("c32", 250, 16_384 + 3),
-    ("c32", 500, 8_192 + 7), ("c32", 1000, 4_096 + 3), ("c32", 1024 + 1, 4_096 + 2), ("c32", 2000, 2_048 + 1),
-    ("c64", 12, 196_608 + 37), ("c64", 30, 98_304 + 5), ("c64", 60, 65_536 + 21), ("c64", 250, 16_384 + 3),
+    # batch >= CUs x workgroups per CU x transforms per workgroup x 4 (complex_impl.hip.h: blue_persist_pays), with room to spare
+    ("c32", 12, 300_000 + 37), ("c32", 30, 150_000 + 5), ("c32", 60, 90_000 + 21), ("c32", 100, 60_000 + 9), ("c32", 250, 20_000 + 3),
+    ("c32", 500, 14_000 + 7), ("c32", 1000, 5_000 + 3), ("c32", 1024 + 1, 2_500 + 2), ("c32", 2000, 2_500 + 1),
+    ("c32", 4095, 1_100 + 1),
+    ("c64", 12, 196_608 + 37), ("c64", 30, 98_304 + 5), ("c64", 60, 65_536 + 21), ("c64", 100, 20_000 + 5), ("c64", 250, 16_384 + 3),
+    ("c64", 500, 5_000 + 1), ("c64", 1000, 2_500 + 3), ("c64", 2000, 1_100 + 1),
 ])
 def test_bluestein_persistent_kernel_large_batches(oracle, dtype, n, batch):
     """Batches that give every workgroup of the chip-sized grid several transforms run bluestein_persist_kernel (twiddles and fft(b) in
-    registers, next input prefetched): m = 32 ... 4096 (c32), m = 32 ... 128 and 512 (c64), ragged last round, forward and inverse,
+    registers, next input prefetched): m = 32 ... 8192 (c32), m = 32 ... 4096 (c64), ragged last round, forward and inverse,
     first / last / middle rows against the oracle and every row against the one-workgroup-per-transform kernel (small batches)."""
     import kofft_amd
 
