@@ -905,13 +905,19 @@ __global__ __launch_bounds__(BLOCK, (IO::kMinWaves > 1 && BLOCK == 512 && L >= 9
 // MODE 1: stft::istft (stft.rs:117-156) -- normalise where the window-square sum exceeds 1e-8, else leave the sum;
 // MODE 2: stft::inverse_parallel (stft.rs:289-343) -- as MODE 1 but samples with a tiny sum become 0.
 // Frame f starts at sample start0 + f*hop.
+// The samples a launch covers: `nranges` runs of `range_len` samples, the first at s_first, `range_stride` apart (the whole output: one run
+// of out_len samples from 0; istft_fused_kernel leaves the runs at its workgroups' seams and the tail to this kernel).
 template <int MODE>
 __global__ __launch_bounds__(256) void istft_ola_kernel(const cpx<float> *__restrict__ frames, const float *__restrict__ window,
                                                         float *__restrict__ output, float *__restrict__ scratch,
                                                         const size_t nframes, const size_t win_len, const size_t hop,
-                                                        const size_t out_len, const size_t start0)
+                                                        const size_t out_len, const size_t start0, const size_t s_first,
+                                                        const size_t range_len, const size_t range_stride, const size_t nranges)
 {
-    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t rg = idx / range_len;
+    if (rg >= nranges) return;
+    const size_t s = s_first + rg * range_stride + (idx - rg * range_len);
     if (s >= out_len) return;
     float acc = output[s];  // accumulated into the caller's buffer (stft.rs:144, 330, 395)
     float norm = 0.0f;      // scratch / norm start from zero (stft.rs:132-134, 325-326)

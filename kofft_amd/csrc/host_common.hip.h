@@ -20,6 +20,7 @@
 
 #include "fft_big.hip.h"
 #include "fft_persist.hip.h"
+#include "fft_istft.hip.h"
 #include "fft_regfile.hip.h"
 #include "fft_split_wide.hip.h"
 #include "fft_wg.hip.h"
@@ -35,6 +36,7 @@ struct kofft_hip_ctx {
     hipEvent_t order_event = nullptr;  // kofft_hip_set_stream: orders the new stream after the old one
     int num_cus = 256;
     bool use_persist = true;  // KOFFT_HIP_NO_PERSIST=1 forces the generic kernels (A/B measurements, tests)
+    bool istft_fused = true;  // KOFFT_HIP_ISTFT_FUSED=0: ISTFT always as inverse transforms + the overlap-add kernel
     bool blue_persist = true; // KOFFT_HIP_BLUESTEIN_PERSIST=0: the one-launch Bluestein arm always as one workgroup per XPB transforms
     int persist_grid_pct = 0; // KOFFT_HIP_PERSIST_GRID_PCT: scale the persistent grids (measurements only)
     bool big_two_only = false; // KOFFT_HIP_BIG_TWO_FACTORS=1: never split into three factors (A/B measurements)

@@ -70,8 +70,101 @@ int stft_dev(kofft_hip_ctx *ctx, const float *d_signal, size_t len, const float 
     return dispatch<float, EPI_STORE>(ctx, io, win_len, count);
 }
 
+// The ordered overlap-add kernel over `nranges` runs of `range_len` output samples (see istft_ola_kernel).
+static int istft_ola_ranges(kofft_hip_ctx *ctx, const float *d_frames, size_t frames, const float *d_window, size_t win_len, size_t hop,
+                            float *d_output, size_t out_len, float *d_scratch, int mode, size_t start0, size_t s_first, size_t range_len,
+                            size_t range_stride, size_t nranges)
+{
+    if (out_len == 0 || range_len == 0 || nranges == 0) return KOFFT_OK;
+    const size_t blocks = (range_len * nranges + 255) / 256;
+    if (blocks > 0x7fffffffULL) return KOFFT_ERR_UNSUPPORTED;
+    const cpx<float> *fr = reinterpret_cast<const cpx<float> *>(d_frames);
+    if (mode == 0)
+        hipLaunchKernelGGL(istft_ola_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, fr, d_window, d_output, d_scratch, frames,
+                           win_len, hop, out_len, start0, s_first, range_len, range_stride, nranges);
+    else if (mode == 2)
+        hipLaunchKernelGGL(istft_ola_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, fr, d_window, d_output, d_scratch, frames,
+                           win_len, hop, out_len, start0, s_first, range_len, range_stride, nranges);
+    else
+        hipLaunchKernelGGL(istft_ola_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, fr, d_window, d_output, d_scratch, frames,
+                           win_len, hop, out_len, start0, s_first, range_len, range_stride, nranges);
+    KOFFT_HIP_TRY(ctx, hipGetLastError());
+    return KOFFT_OK;
+}
+
+// The fused form (fft_istft.hip.h): win = 2^L, hop = win / C, frames from sample 0, enough frames for every workgroup of the chip-sized
+// grid to own a run several steps long.  *done = false: the caller takes the two-kernel route.
+template <int L, int CL>
+static int launch_istft_fused(kofft_hip_ctx *ctx, float *d_frames, size_t frames, const float *d_window, float *d_output, size_t out_len,
+                              float *d_scratch, int mode, bool *done)
+{
+    constexpr int RL = rl_for(L);
+    constexpr int N = 1 << L, TPT = N >> RL, XPB = 256 / TPT, C = 1 << CL, HOP = N >> CL;
+    constexpr int WG = 2;
+    constexpr size_t lds = (size_t)XPB * lds_elems(N) * sizeof(cpx<float>) + (size_t)XPB * N * sizeof(float) + (size_t)N * sizeof(float);
+    static_assert(lds * WG <= 160 * 1024, "LDS budget");
+    *done = false;
+    const size_t steps = (frames + XPB - 1) / XPB;
+    size_t grid = (size_t)ctx->num_cus * WG;
+    if (ctx->persist_grid_pct > 0) grid = grid * (size_t)ctx->persist_grid_pct / 100;
+    if (grid < 1) grid = 1;
+    const size_t fpw = ((steps + grid - 1) / grid) * XPB;  // frames per workgroup: whole steps
+    if (fpw < 4 * XPB || fpw < (size_t)(2 * C)) return KOFFT_OK;
+    const size_t runs = (frames + fpw - 1) / fpw;
+    if ((frames + XPB) * (size_t)HOP > 0xffffffffffffull) return KOFFT_OK;
+    const cpx<float> *tw = nullptr;
+    int rc = get_table<float>(ctx, Kind<float>::tw, N, &tw);
+    if (rc) return rc;
+    auto kern = istft_fused_kernel<L, RL, CL, WG>;
+    {
+        static std::atomic<unsigned long long> attr_done{0};
+        const int arc = set_dyn_lds_once(ctx, attr_done, reinterpret_cast<const void *>(kern), lds);
+        if (arc) return arc;
+    }
+    const float scale = 1.0f / (float)N;
+    hipLaunchKernelGGL(kern, dim3((unsigned)runs), dim3(256), lds, ctx->stream, reinterpret_cast<cpx<float> *>(d_frames), d_window, d_output,
+                       d_scratch, tw, frames, out_len, scale, fpw, mode);
+    KOFFT_HIP_TRY(ctx, hipGetLastError());
+    // seams: the first C - 1 blocks of every run but the first
+    if (runs > 1 && C > 1) {
+        rc = istft_ola_ranges(ctx, d_frames, frames, d_window, N, HOP, d_output, out_len, d_scratch, mode, 0, fpw * HOP, (size_t)(C - 1) * HOP,
+                              fpw * HOP, runs - 1);
+        if (rc) return rc;
+    }
+    // tail: everything after the last run's completed blocks
+    const size_t a_last = (runs - 1) * fpw;
+    size_t tail_blk = a_last + ((frames - a_last + XPB - 1) / XPB) * XPB;
+    if (runs > 1 && tail_blk < a_last + (size_t)(C - 1)) tail_blk = a_last + (size_t)(C - 1);
+    const size_t tail = tail_blk * HOP;
+    if (tail < out_len) {
+        rc = istft_ola_ranges(ctx, d_frames, frames, d_window, N, HOP, d_output, out_len, d_scratch, mode, 0, tail, out_len - tail, 0, 1);
+        if (rc) return rc;
+    }
+    *done = true;
+    return KOFFT_OK;
+}
+
+static int istft_fused_dev(kofft_hip_ctx *ctx, float *d_frames, size_t frames, const float *d_window, size_t win_len, size_t hop,
+                           float *d_output, size_t out_len, float *d_scratch, int mode, bool *done)
+{
+    *done = false;
+    if (!is_pow2(win_len) || !is_pow2(hop) || hop > win_len) return KOFFT_OK;
+    const int L = ilog2(win_len), CL = L - ilog2(hop);
+#define KOFFT_CASE(LL, CC) \
+    if (L == LL && CL == CC) return launch_istft_fused<LL, CC>(ctx, d_frames, frames, d_window, d_output, out_len, d_scratch, mode, done);
+    KOFFT_CASE(9, 1)
+    KOFFT_CASE(10, 1)
+    KOFFT_CASE(10, 2)
+    KOFFT_CASE(11, 1)
+    KOFFT_CASE(11, 2)
+    KOFFT_CASE(12, 1)
+    KOFFT_CASE(12, 2)
+#undef KOFFT_CASE
+    return KOFFT_OK;
+}
+
 // stft::istft (stft.rs:117-156, mode 1), stft::inverse_parallel (stft.rs:289-343, mode 2), stft::inverse_frame
-// (stft.rs:384-399, mode 0): ifft every frame in place, then the ordered overlap-add kernel.
+// (stft.rs:384-399, mode 0): ifft every frame in place, then the ordered overlap-add kernel -- or both in one (istft_fused_dev).
 int istft_dev(kofft_hip_ctx *ctx, float *d_frames, size_t frames, const float *d_window, size_t win_len, size_t hop,
               float *d_output, size_t out_len, float *d_scratch, size_t scratch_len, int mode, size_t start0)
 {
@@ -81,26 +174,16 @@ int istft_dev(kofft_hip_ctx *ctx, float *d_frames, size_t frames, const float *d
     if (frames > 0 && !complex_len_ok(win_len)) return KOFFT_ERR_UNSUPPORTED;
     if (!ctx || (frames && (!d_frames || !d_window)) || (out_len && (!d_output || (mode != 0 && !d_scratch)))) return KOFFT_ERR_NULL;
     KOFFT_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (frames > 0 && out_len > 0 && start0 == 0 && ctx->istft_fused && ctx->use_persist) {
+        bool done = false;
+        const int rc = istft_fused_dev(ctx, d_frames, frames, d_window, win_len, hop, d_output, out_len, d_scratch, mode, &done);
+        if (rc || done) return rc;
+    }
     if (frames > 0) {
         int rc = fft_dev<float>(ctx, d_frames, d_frames, win_len, frames, 1);
         if (rc) return rc;
     }
-    if (out_len > 0) {
-        const size_t blocks = (out_len + 255) / 256;
-        if (blocks > 0x7fffffffULL) return KOFFT_ERR_UNSUPPORTED;
-        const cpx<float> *fr = reinterpret_cast<const cpx<float> *>(d_frames);
-        if (mode == 0)
-            hipLaunchKernelGGL(istft_ola_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, fr, d_window, d_output,
-                               d_scratch, frames, win_len, hop, out_len, start0);
-        else if (mode == 2)
-            hipLaunchKernelGGL(istft_ola_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, fr, d_window, d_output,
-                               d_scratch, frames, win_len, hop, out_len, start0);
-        else
-            hipLaunchKernelGGL(istft_ola_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, fr, d_window, d_output,
-                               d_scratch, frames, win_len, hop, out_len, start0);
-        KOFFT_HIP_TRY(ctx, hipGetLastError());
-    }
-    return KOFFT_OK;
+    return istft_ola_ranges(ctx, d_frames, frames, d_window, win_len, hop, d_output, out_len, d_scratch, mode, start0, 0, out_len, 0, 1);
 }
 
 // visual::spectrogram::stft_magnitudes (visual/spectrogram.rs:52-76): hann(win_len) window, frames x win_len/2 magnitudes

@@ -481,6 +481,7 @@ int kofft_hip_create(int device, kofft_hip_ctx **out)
     // Route switches (each selects another implementation of the same transform; tests/test_gpu_knobs.py runs every one of them in
     // its non-default setting against the oracle).  The tuning knobs of rounds 1-3 that only ever confirmed the default are gone.
     if (const char *e = getenv("KOFFT_HIP_NO_PERSIST")) ctx->use_persist = !(e[0] == '1');
+    if (const char *e = getenv("KOFFT_HIP_ISTFT_FUSED")) ctx->istft_fused = atoi(e) != 0;
     if (const char *e = getenv("KOFFT_HIP_BLUESTEIN_PERSIST")) ctx->blue_persist = atoi(e) != 0;
     if (const char *e = getenv("KOFFT_HIP_PERSIST_GRID_PCT")) ctx->persist_grid_pct = atoi(e);
     if (const char *e = getenv("KOFFT_HIP_BIG_THREE_MIN")) ctx->big_three_min = atoi(e);

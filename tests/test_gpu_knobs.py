@@ -168,6 +168,19 @@ def case_bluestein_persist(oracle):  # large batches: the persistent kernel by d
     _complex(oracle, "c64", 60, 66000, 156, check=_edges(66000))
 
 
+def case_istft_two_kernels(oracle):  # a frame count the fused kernel takes by default
+    import kofft_amd as K
+
+    f = K.HipFftImpl(np.float32)
+    spec = rand_c(seeded(157), (9001, 1024))
+    window = oracle.hann(1024)
+    out_len = 9000 * 256 + 1024
+    out = np.zeros(out_len, np.float32)
+    scratch = np.zeros(out_len, np.float32)
+    K.istft(spec.copy(), window, 256, out, scratch, f)
+    assert bits_equal(out, oracle.istft(spec, window, 256, out_len))
+
+
 def case_big_narrow(oracle):
     _complex(oracle, "c32", 1 << 17, 1, 161)
     _complex(oracle, "c64", 1 << 18, 2, 162)
@@ -207,6 +220,7 @@ KNOBS = [
     ("KOFFT_HIP_BLUESTEIN_FUSED", "0", case_bluestein),
     ("KOFFT_HIP_BLUESTEIN_ONE", "0", case_bluestein),
     ("KOFFT_HIP_BLUESTEIN_PERSIST", "0", case_bluestein_persist),
+    ("KOFFT_HIP_ISTFT_FUSED", "0", case_istft_two_kernels),
     ("KOFFT_HIP_BIG_NARROW", "0", case_big_narrow),
     ("KOFFT_HIP_BIG_FIRST11", "0", case_first11),
     ("KOFFT_HIP_BIG_BLOCKED", "0", case_blocked),

@@ -652,6 +652,50 @@ def test_istft_matches_oracle(fft32, oracle, win_len, hop, length):
         assert np.max(np.abs(out[ok] - signal[ok])) < 1e-3
 
 
+@pytest.mark.parametrize("win_len,hop,nframes,out_delta", [
+    (1024, 256, 9001, 0), (1024, 256, 9003, 1500), (1024, 256, 9000, -777), (1024, 512, 9002, 300),
+    (512, 256, 9001, 0), (2048, 512, 4101, 5), (2048, 1024, 4100, -3000), (4096, 1024, 2101, 0), (4096, 2048, 2100, 4097),
+])
+def test_istft_fused_kernel_large_frame_counts(oracle, monkeypatch, win_len, hop, nframes, out_delta):
+    """Frame counts that give every workgroup of the chip-sized grid a run of frames take istft_fused_kernel (inverse transform + ordered
+    overlap-add in one kernel, the seams between the workgroups' runs and the tail on the overlap-add kernel): output, scratch and the
+    frames left behind are the oracle's bytes -- output lengths equal to, beyond and short of what the frames reach; and the same call
+    with KOFFT_HIP_ISTFT_FUSED=0 (two kernels) accumulating into a NON-ZERO output gives the same bytes as the fused one."""
+    import kofft_amd as K
+
+    rng = seeded(1400 + win_len + hop + nframes)
+    spec = rand_c(rng, (nframes, win_len))
+    window = (oracle.hann(win_len) + np.float32(0.01)).astype(np.float32)
+    out_len = (nframes - 1) * hop + win_len + out_delta
+    want = oracle.istft(spec, window, hop, out_len)
+    f = K.HipFftImpl(np.float32)
+    frames = spec.copy()
+    out = np.zeros(out_len, np.float32)
+    scratch = np.full(out_len, 7.0, np.float32)
+    K.istft(frames, window, hop, out, scratch, f)
+    assert_parity(out, want, f"fused istft win={win_len} hop={hop} frames={nframes}", REL_TOL_F32)
+    pick = sorted({0, 1, 2, 3, 4, nframes // 2, nframes - 3, nframes - 2, nframes - 1})
+    assert_parity(frames[pick], oracle.ifft(spec[pick]), "fused istft leaves the inverse-transformed frames behind", REL_TOL_F32)
+    # against the two-kernel route, accumulating into a non-zero output (stft.rs:144: output[..] +=)
+    base = rng.uniform(-1, 1, out_len).astype(np.float32)
+    out_f, scr_f, fr_f = base.copy(), np.zeros(out_len, np.float32), spec.copy()
+    K.istft(fr_f, window, hop, out_f, scr_f, f)
+    monkeypatch.setenv("KOFFT_HIP_ISTFT_FUSED", "0")
+    g = K.HipFftImpl(np.float32)
+    out_g, scr_g, fr_g = base.copy(), np.zeros(out_len, np.float32), spec.copy()
+    K.istft(fr_g, window, hop, out_g, scr_g, g)
+    assert bits_equal(out_f, out_g) and bits_equal(scr_f, scr_g) and bits_equal(fr_f, fr_g)
+    assert bits_equal(scr_f, scratch)
+    # inverse_parallel (tiny sums become 0, frames untouched): same route underneath
+    keep = spec.copy()
+    out_p = np.zeros(out_len, np.float32)
+    K.inverse_parallel(keep, window, hop, out_p, f)
+    assert bits_equal(keep, spec)
+    want_p = want.copy()
+    want_p[scratch <= 1e-8] = 0.0
+    assert bits_equal(out_p, want_p)
+
+
 def test_istft_reference_tests(fft32, oracle):
     import ctypes as C
 
