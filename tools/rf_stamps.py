@@ -4,7 +4,8 @@ stamps -DKOFFT_RF_STAMPS).  Stamps of the first 4 workgroups x 8 transforms x 16
   0 loop top | 1 inputs landed | 2 A0 done | 3 past the top barrier | 4 A-local exchange done | 5 A1 done | 6 block-wide exchange done |
   7 B0 done | 8 B-local exchange done | 9 B1 + stores + next loads issued
 Prints, per phase, the mean over wavefronts / transforms (steady-state transforms 2 .. 6) in stamp ticks and in microseconds
-(s_memtime ticks at 100 MHz), and the spread between the first and the last wavefront at each stamp.
+(s_memtime counts at about 2 GHz on this part -- measured against HIP events over the whole kernel -- not at the 100 MHz of the constant
+refclk: 0.5 ns per tick), and the spread between the first and the last wavefront at each stamp.
 
 usage (GPU box): KOFFT_HIP_LIB=kofft_amd/lib_stamps/libkofft_hip.so python3 tools/rf_stamps.py [c32|c64]"""
 import ctypes as C
@@ -40,8 +41,8 @@ def main():
     buf = np.zeros(4 * 8 * 16 * 16, dtype=np.uint64)
     assert fn(buf.ctypes.data, buf.nbytes) == 0
     st = buf.reshape(4, 8, 16, 16).astype(np.int64)  # [wg][iter][wave][stamp]
-    tick_us = 0.01  # s_memtime: 100 MHz
-    print(f"{kind} n={n}: ticks of 10 ns; transforms 2..6 of workgroups 0..3")
+    tick_us = 0.0005  # s_memtime: ~2 GHz here
+    print(f"{kind} n={n}: ticks of 0.5 ns; transforms 2..6 of workgroups 0..3")
     sel = st[:, 2:7]
     per = sel[..., 1:10] - sel[..., 0:9]            # phase durations per wave
     nxt = st[:, 3:8, :, 0] - st[:, 2:7, :, 9]       # end of loop body -> next top (zero-ish)
