@@ -102,6 +102,46 @@ def main():
             data = x.reshape(-1).copy()
             f32.fftnd(data, 1, rows, cols)
             check(bits_equal(data.reshape(rows, cols), np.ascontiguousarray(want)), ("fft2d two-pass", rows, cols))
+        # round 4, later: c32 two-factor sizes with the last factor on row pairs, the persistent Bluestein kernel (every m, batches from its
+        # threshold up) and the fused ISTFT (random frame counts / output lengths around what the frames reach, both hop ratios)
+        for log2n in (16, 17, 19, 21):
+            n = 1 << log2n
+            batch = int(rng.integers((8192 >> (log2n // 2)) + 1, (8192 >> (log2n // 2)) + 24))
+            x = rand_c(rng, (batch, n))
+            y = x.copy()
+            inv = bool(rng.random() < 0.5)
+            f32.fft_batch(y, inverse=inv)
+            pick = sorted({0, batch // 2, batch - 1})
+            check(bits_equal(y[pick], oracle.ifft(x[pick]) if inv else oracle.fft(x[pick])), ("c32 row pairs", n, batch, inv))
+        for m_log, base in ((5, 300_000), (6, 150_000), (7, 90_000), (8, 60_000), (9, 20_000), (10, 14_000), (11, 5_000), (12, 2_500), (13, 1_100)):
+            lo, hi = (1 << (m_log - 2)) + 1, (1 << (m_log - 1))  # lengths whose m = (2n - 1).next_power_of_two() is 2^m_log
+            n = int(rng.integers(lo, hi + 1))
+            if n & (n - 1) == 0:
+                n -= 1
+            if n < 3:
+                n = 3
+            batch = base + int(rng.integers(0, 50))
+            for impl, cdt, ok in ((f32, np.complex64, True), (f64, np.complex128, m_log <= 12)):
+                if not ok:
+                    continue
+                x = rand_c(rng, (batch, n), cdt)
+                y = x.copy()
+                inv = bool(rng.random() < 0.5)
+                impl.fft_batch(y, inverse=inv)
+                pick = sorted({0, 1, batch // 3, batch - 2, batch - 1})
+                check(bits_equal(y[pick], oracle.ifft(x[pick]) if inv else oracle.fft(x[pick])), ("bluestein persistent", cdt.__name__, n, batch, inv))
+        for win_len, frames_lo in ((512, 9000), (1024, 9000), (2048, 4100), (4096, 2100)):
+            hop = win_len // int(rng.choice([2, 4])) if win_len > 512 else win_len // 2
+            nframes = frames_lo + int(rng.integers(0, 40))
+            reach = (nframes - 1) * hop + win_len
+            out_len = reach + int(rng.choice([0, 1, -1, 2000, -2000, hop, -hop]))
+            spec = rand_c(rng, (nframes, win_len))
+            window = rng.uniform(0.05, 1, win_len).astype(np.float32)
+            want = oracle.istft(spec, window, hop, out_len)
+            out = np.zeros(out_len, np.float32)
+            scratch = np.zeros(out_len, np.float32)
+            kofft_amd.istft(spec, window, hop, out, scratch, f32)
+            check(bits_equal(out, want), ("istft fused", win_len, hop, nframes, out_len - reach))
         print(f"round {r}: {n_cases} cases, {bad} failures", flush=True)
     print("soak done, failures:", bad)
     sys.exit(1 if bad else 0)
