@@ -170,6 +170,9 @@ struct StftIO : PlainTw {
     static constexpr int kRawBytes = sizeof(float);
     __device__ __forceinline__ rsrc_t in_desc(size_t xf, bool valid) const
     {
+#ifdef KOFFT_EXP_STFT_SAMEFRAME /* measurement only (wrong results): every frame reads frame 0's samples -- the bound on what staging the samples could gain */
+        xf = 0;
+#endif
         const size_t start = start0 + xf * hop;
         const size_t avail = (valid && start < len) ? len - start : 0;
         return make_rsrc(signal + (avail ? start : 0), (unsigned)(avail < (size_t)n ? avail : (size_t)n) * 4u);
@@ -182,6 +185,9 @@ struct StftIO : PlainTw {
     __device__ __forceinline__ unsigned in_slot_bytes() const { return (unsigned)hop * 4u; }
     __device__ __forceinline__ rsrc_t in_desc_wg(size_t xf0, size_t, int) const
     {
+#ifdef KOFFT_EXP_STFT_SAMEFRAME
+        xf0 = 0;
+#endif
         const size_t start = start0 + xf0 * hop;
         size_t avail = start < len ? len - start : 0;
         if (avail > 0x3fffffffULL) avail = 0x3fffffffULL;
@@ -199,6 +205,9 @@ struct StftIO : PlainTw {
     // with the signal, so frames that run off its end read zeros (stft.rs:95-99)
     __device__ __forceinline__ rsrc_t in_desc_n(size_t xf0, int cnt) const
     {
+#ifdef KOFFT_EXP_STFT_SAMEFRAME
+        xf0 = 0;
+#endif
         const size_t start = start0 + xf0 * hop;
         size_t avail = (cnt > 0 && start < len) ? len - start : 0;
         const size_t span = cnt > 0 ? (size_t)(cnt - 1) * hop + (size_t)n : 0;
