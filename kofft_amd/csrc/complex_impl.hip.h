@@ -319,6 +319,8 @@ int fft_big_core(kofft_hip_ctx *ctx, const cpx<T> *in_base, size_t in_row, cpx<T
     // (odd log2 n: the first factor -- the cheaper kernel: one table for all its tiles -- takes the extra bit in f32: 2^15 / 2^17 /
     // 2^19 +1.5..3 % on the same box; c64 shows no difference and keeps the smaller first factor; a single transform
     // -- the one-tile-per-workgroup kernels -- is faster the other way at 2^19, 14.0 vs 15.2 us, and keeps it too)
+    // (three factors: a larger LAST factor -- 7/7/9 or 8/7/9 and 7/7/10 instead of 8/8/7 and 8/8/8 -- measured slower, round 4: 2^23 0.184 -> 0.168,
+    // 2^24 0.170 -> 0.160 c32, the same for c64)
     const int L1 = three ? (L + 2) / 3 : (first11 ? 11 : (first_larger ? (L + 1) / 2 : L / 2));
     const int L2 = three ? (L - L1 + 1) / 2 : 0;
     const int L3 = L - L1 - L2;
