@@ -42,8 +42,8 @@ __global__ __launch_bounds__(256, WG_PER_CU) void istft_fused_kernel(cpx<float> 
     constexpr int HOP = 1 << HL;
     constexpr int DONE = XPB * HOP;              // samples completed per step
     constexpr int TOUCHED = DONE + N - HOP;      // samples a step's frames reach
-    static_assert(DONE % 256 == 0 && TOUCHED % 256 == 0, "whole rounds of the workgroup");
-    constexpr int PT = TOUCHED / 256;            // samples per thread
+    static_assert(DONE % 256 == 0, "the carried accumulators move down by whole registers");
+    constexpr int PT = (TOUCHED + 255) / 256;    // samples per thread (the last round may be partial: hop < 256)
     constexpr int PD = DONE / 256;               // ... of which complete after the step
     using G0 = WgGeom<L, RL, 0>;
     using GL = WgGeom<L, RL, NP - 1>;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256, WG_PER_CU) void istft_fused_kernel(cpx<float> 
 #pragma unroll
         for (int m = 0; m < PT; ++m) {
             const size_t s = F * HOP + (size_t)(tid + 256 * m);
-            init[m] = ((first || m >= PT - PD) && s < out_len) ? output[s] : 0.0f;
+            init[m] = ((first || tid + 256 * m >= N - HOP) && s < out_len) ? output[s] : 0.0f;  // (samples below N - HOP are carried)
         }
         cpx<T> v[R];
 #pragma unroll
@@ -125,12 +125,12 @@ __global__ __launch_bounds__(256, WG_PER_CU) void istft_fused_kernel(cpx<float> 
         // overlap-add: sample e = tid + 256 m of the step lies in block e >> HL at offset i0; frame F + k covers it iff 0 <= block - k < C
 #pragma unroll
         for (int m = 0; m < PT; ++m) {
-            if (first || m >= PT - PD) {
+            const int e = tid + 256 * m;
+            if (first || e >= N - HOP) {
                 acc[m] = init[m];
                 nrm[m] = 0.0f;
             }
-            const int e = tid + 256 * m;
-            const int blk = e >> HL, i0 = e & (HOP - 1);
+            const int blk = e >> HL, i0 = e & (HOP - 1);  // (e >= TOUCHED in a partial last round: blk - k >= C for every k)
 #pragma unroll
             for (int k = 0; k < XPB; ++k) {
                 const int d = blk - k;

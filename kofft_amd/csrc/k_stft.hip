@@ -152,13 +152,26 @@ static int istft_fused_dev(kofft_hip_ctx *ctx, float *d_frames, size_t frames, c
     const int L = ilog2(win_len), CL = L - ilog2(hop);
 #define KOFFT_CASE(LL, CC) \
     if (L == LL && CL == CC) return launch_istft_fused<LL, CC>(ctx, d_frames, frames, d_window, d_output, out_len, d_scratch, mode, done);
+    // hop = win, win / 2, win / 4, win / 8 (L = 8: the 16 frames of a step reach one window further only from win / 2 down)
+    KOFFT_CASE(8, 1)
+    KOFFT_CASE(8, 2)
+    KOFFT_CASE(8, 3)
+    KOFFT_CASE(9, 0)
     KOFFT_CASE(9, 1)
+    KOFFT_CASE(9, 2)
+    KOFFT_CASE(9, 3)
+    KOFFT_CASE(10, 0)
     KOFFT_CASE(10, 1)
     KOFFT_CASE(10, 2)
+    KOFFT_CASE(10, 3)
+    KOFFT_CASE(11, 0)
     KOFFT_CASE(11, 1)
     KOFFT_CASE(11, 2)
+    KOFFT_CASE(11, 3)
+    KOFFT_CASE(12, 0)
     KOFFT_CASE(12, 1)
     KOFFT_CASE(12, 2)
+    KOFFT_CASE(12, 3)
 #undef KOFFT_CASE
     return KOFFT_OK;
 }

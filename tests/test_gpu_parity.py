@@ -655,6 +655,8 @@ def test_istft_matches_oracle(fft32, oracle, win_len, hop, length):
 @pytest.mark.parametrize("win_len,hop,nframes,out_delta", [
     (1024, 256, 9001, 0), (1024, 256, 9003, 1500), (1024, 256, 9000, -777), (1024, 512, 9002, 300),
     (512, 256, 9001, 0), (2048, 512, 4101, 5), (2048, 1024, 4100, -3000), (4096, 1024, 2101, 0), (4096, 2048, 2100, 4097),
+    (256, 128, 33001, 3), (256, 64, 33000, -70), (256, 32, 33003, 0), (512, 512, 9001, 0), (512, 128, 9002, 1), (512, 64, 9003, -9),
+    (1024, 1024, 9000, 17), (1024, 128, 9001, 0), (2048, 2048, 4100, 0), (2048, 256, 4101, -1), (4096, 4096, 2100, 0), (4096, 512, 2101, 100),
 ])
 def test_istft_fused_kernel_large_frame_counts(oracle, monkeypatch, win_len, hop, nframes, out_delta):
     """Frame counts that give every workgroup of the chip-sized grid a run of frames take istft_fused_kernel (inverse transform + ordered

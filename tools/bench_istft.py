@@ -1,43 +1,36 @@
-"""ISTFT of BASELINE config #4's spectra on device memory (ifft of every frame + ordered overlap-add)."""
-import sys, pathlib; sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
-import ctypes as C
+"""ISTFT (stft.rs:117-156) on device memory over window / hop shapes, fused kernel against the two-kernel route (KOFFT_HIP_ISTFT_FUSED=0 in a second
+context): ~0.92 GB of spectra per call.  usage: bench_istft.py [win:hop ...]"""
+import os, sys, pathlib; sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
 import numpy as np, torch, kofft_amd
-from kofft_amd import _lib
-lib = _lib.load()
-f = kofft_amd.HipFftImpl(np.float32)
+shapes = [tuple(int(v) for v in a.split(":")) for a in sys.argv[1:]] or \
+    [(256, 64), (512, 128), (1024, 1024), (1024, 512), (1024, 256), (1024, 128), (2048, 512), (4096, 1024), (4096, 512)]
+impls = {}
+for name, val in (("fused", "1"), ("two kernels", "0")):
+    os.environ["KOFFT_HIP_ISTFT_FUSED"] = val
+    impls[name] = kofft_amd.HipFftImpl(np.float32)
 stream = torch.cuda.Stream()
-f.set_stream(stream.cuda_stream)
-total, win_len, hop = 28_800_000, 1024, 256
-frames = -(-total // hop)
-with torch.cuda.stream(stream):
-    sig = torch.empty(total, dtype=torch.float32, device="cuda").uniform_(-1, 1)
-    win = torch.from_numpy(kofft_amd.hann(win_len)).cuda()
-    spec = torch.empty((frames, win_len, 2), dtype=torch.float32, device="cuda")
-    f.stft_dev(sig.data_ptr(), total, win.data_ptr(), win_len, hop, spec.data_ptr(), 0, frames)
-    out_len = (frames - 1) * hop + win_len
+for f in impls.values():
+    f.set_stream(stream.cuda_stream)
+for win, hop in shapes:
+    frames = (115_200_000 // win)
+    out_len = (frames - 1) * hop + win
+    spec0 = torch.empty((frames, win, 2), dtype=torch.float32, device="cuda").uniform_(-1, 1)
+    spec = torch.empty_like(spec0)
+    window = torch.from_numpy(kofft_amd.hann(win)).cuda()
     out = torch.zeros(out_len, dtype=torch.float32, device="cuda")
     scratch = torch.zeros(out_len, dtype=torch.float32, device="cuda")
-    work = spec.clone()
-    def call():
-        work.copy_(spec); out.zero_()
-        return lib.kofft_hip_istft_f32_dev(f._ctx, C.c_void_p(work.data_ptr()), frames, C.c_void_p(win.data_ptr()), win_len, hop,
-                                           C.c_void_p(out.data_ptr()), out_len, C.c_void_p(scratch.data_ptr()), out_len)
-    for _ in range(3):
-        assert call() == 0
-    torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    # time only the istft (the copy_/zero_ that restore the inputs are timed separately and subtracted)
-    s.record(stream)
-    for _ in range(10):
-        call()
-    e.record(stream); torch.cuda.synchronize()
-    t_all = s.elapsed_time(e) / 10
-    err = (out[:total] - sig).abs()[hop:].max().item()  # Hann at hop = n/4 overlap-adds to a constant: exact up to round-off
-    s.record(stream)
-    for _ in range(10):
-        work.copy_(spec); out.zero_()
-    e.record(stream); torch.cuda.synchronize()
-    t_prep = s.elapsed_time(e) / 10
-ms = t_all - t_prep
-byt = 2 * spec.numel() * 4 + spec.numel() * 4 + 3 * out_len * 4
-print(f"istft {frames} x {win_len} (hop {hop}): {ms:.3f} ms  (ifft in place + overlap-add; {byt/ms/1e6:.0f} GB/s of minimal traffic), round-trip max err {err:.2e}")
+    line = f"win {win:5d} hop {hop:5d} frames {frames:7d}:"
+    for name, f in impls.items():
+        ts = []
+        with torch.cuda.stream(stream):
+            for it in range(8):
+                spec.copy_(spec0); out.zero_()
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record(stream)
+                f.istft_dev(spec.data_ptr(), frames, window.data_ptr(), win, hop, out.data_ptr(), out_len, scratch.data_ptr())
+                e.record(stream); torch.cuda.synchronize()
+                ts.append(s.elapsed_time(e))
+        ms = float(np.median(ts[3:]))
+        alg = 2 * frames * win * 8 + 3 * out_len * 4
+        line += f"  {name} {ms:7.3f} ms ({alg/ms/1e6/8000:.3f})"
+    print(line, flush=True)

@@ -130,8 +130,8 @@ def main():
                 impl.fft_batch(y, inverse=inv)
                 pick = sorted({0, 1, batch // 3, batch - 2, batch - 1})
                 check(bits_equal(y[pick], oracle.ifft(x[pick]) if inv else oracle.fft(x[pick])), ("bluestein persistent", cdt.__name__, n, batch, inv))
-        for win_len, frames_lo in ((512, 9000), (1024, 9000), (2048, 4100), (4096, 2100)):
-            hop = win_len // int(rng.choice([2, 4])) if win_len > 512 else win_len // 2
+        for win_len, frames_lo in ((256, 33000), (512, 9000), (1024, 9000), (2048, 4100), (4096, 2100)):
+            hop = win_len // int(rng.choice([1, 2, 4, 8]))
             nframes = frames_lo + int(rng.integers(0, 40))
             reach = (nframes - 1) * hop + win_len
             out_len = reach + int(rng.choice([0, 1, -1, 2000, -2000, hop, -hop]))
