@@ -86,7 +86,7 @@ def main():
             elif kind in ("rfft64", "irfft64"):
                 fft = kofft_amd.HipFftImpl(np.float64, device=0)
                 fft.set_stream(stream.cuda_stream)
-                for L in range(2, 15):
+                for L in range(2, 21):
                     n = 1 << L
                     if (args.only_n and n != args.only_n) or (args.max_n and n > args.max_n) or n < args.min_n:
                         continue
@@ -104,7 +104,7 @@ def main():
             elif kind == "rfft32":
                 fft = kofft_amd.HipFftImpl(np.float32, device=0)
                 fft.set_stream(stream.cuda_stream)
-                for L in range(2, 16):
+                for L in range(2, 22):
                     n = 1 << L
                     if (args.only_n and n != args.only_n) or (args.max_n and n > args.max_n) or n < args.min_n:
                         continue
@@ -121,7 +121,7 @@ def main():
             elif kind == "irfft32":
                 fft = kofft_amd.HipFftImpl(np.float32, device=0)
                 fft.set_stream(stream.cuda_stream)
-                for L in range(2, 16):
+                for L in range(2, 22):
                     n = 1 << L
                     if (args.only_n and n != args.only_n) or (args.max_n and n > args.max_n) or n < args.min_n:
                         continue
