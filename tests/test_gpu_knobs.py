@@ -52,6 +52,8 @@ def case_no_persist(oracle):
 def case_grid_pct(oracle):
     _complex(oracle, "c32", 4096, 1300, 21, check=_edges(1300))
     _complex(oracle, "c64", 1 << 16, 300, 22, check=_edges(300), inverse=False)
+    _complex(oracle, "c32", 1000, 4300, 23, check=_edges(4300))  # the persistent Bluestein kernel on half its grid
+    case_istft_two_kernels(oracle)                               # the fused ISTFT on half its grid (longer runs, other seams)
 
 
 def case_three_min_high(oracle):  # 2^22 as TWO factors
