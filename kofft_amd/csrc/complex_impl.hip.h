@@ -249,7 +249,7 @@ int fft_axis2_dev(kofft_hip_ctx *ctx, T *d_data, int LT, int I, size_t blocks, i
 {
     // 2^12 = 2^7 x 2^5, 2^13 = 2^7 x 2^6, 2^14 = 2^7 x 2^7: the first pass on the persistent prefetching tile kernel (4096 x 4096 c32,
     // same box: transposes 0.224 ms, 2^5 x 2^7 0.169-0.173, 2^6 x 2^6 0.178, 2^7 x 2^5 0.149; KOFFT_HIP_ND_TWO_PASS_L1 overrides: A/B)
-    int L1 = 7;
+    int L1 = LT >= 12 ? 7 : LT - 5;  // (2^11 = 2^6 x 2^5, 2^10 = 2^5 x 2^5)
     if (ctx->nd_two_pass_l1 >= 5 && ctx->nd_two_pass_l1 <= 8 && LT - ctx->nd_two_pass_l1 >= 5 && LT - ctx->nd_two_pass_l1 <= 8) L1 = ctx->nd_two_pass_l1;
     if (L1 < 5 || L1 > 8 || LT - L1 < 5 || LT - L1 > 8) return KOFFT_ERR_UNSUPPORTED;
     cpx<T> *data = reinterpret_cast<cpx<T> *>(d_data);

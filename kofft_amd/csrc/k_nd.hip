@@ -17,7 +17,10 @@ int fft_axis_dev(kofft_hip_ctx *ctx, T *d_data, size_t len, size_t lines, size_t
     // ... and the only route for axis lengths the strided kernel does not cover (non-powers of two: Bluestein; beyond 2^14)
     // Power-of-two axes of 2^12 .. 2^14 points (2^13 in f64) over a power-of-two number of adjacent lines: two column-tile passes
     // with the axis's own table instead of transpose -> rows -> transpose (round 4: one pass over the data less; AxisLastIO).
-    if (stride == inner && ctx->nd_two_pass && fused_len_ok<T>(len) && len >= 4096 && is_pow2(inner) &&
+    // c32 axes of 2^11 points too (the strided kernel holds 4 adjacent lines: 32-byte segments) up to 8192 adjacent lines: 2048 x 8192
+    // 0.229 -> 0.179 ms, 2048 x 2048 0.059 -> 0.047, 8 x 2048 x 2048 0.497 -> 0.451; over 16384 adjacent lines (2048 x 256 x 64) it loses 10 %,
+    // c64 (64-byte segments in the strided kernel) 3 %, and 2^10-point axes lose everywhere (tools/bench_nd.py).
+    if (stride == inner && ctx->nd_two_pass && fused_len_ok<T>(len) && (len >= 4096 || (len == 2048 && sizeof(T) == 4 && inner <= 8192)) && is_pow2(inner) &&
         inner >= (size_t)KOFFT_BIG_XPB(T) && lines % inner == 0 && (lines == inner || outer_stride == len * inner) &&
         lines * len * sizeof(cpx<T>) >= (size_t(16) << 20) && len * inner * sizeof(cpx<T>) <= (size_t(1) << 31)) {  // (32-bit buffer descriptors per block)
         return fft_axis2_dev<T>(ctx, d_data, ilog2(len), ilog2(inner), lines / inner, inverse);

@@ -157,6 +157,7 @@ def case_nd_transpose(oracle):  # 4096-point axis over 520 (not a power of two) 
 def case_nd_two_pass(oracle):  # power-of-two line counts: two column-tile passes by default, transposes here
     _nd(oracle, "c32", 1, 4096, 512, 141)
     _nd(oracle, "c64", 2, 4096, 128, 142)
+    _nd(oracle, "c32", 1, 2048, 1024, 143)
 
 
 def case_bluestein(oracle):

@@ -1285,11 +1285,12 @@ def test_host_pointer_stft_large(fft32, oracle):
 
 
 @pytest.mark.parametrize("depth,rows,cols", [(1, 2048, 16), (1, 1024, 64), (1, 4096, 128), (1024, 2, 8), (4, 1024, 32), (2, 2048, 4),
-                                             (1, 4096, 512), (2, 4096, 256), (4096, 2, 256), (1, 8192, 256), (1, 16384, 64), (3, 4096, 192)])
+                                             (1, 4096, 512), (2, 4096, 256), (4096, 2, 256), (1, 8192, 256), (1, 16384, 64), (3, 4096, 192),
+                                             (1, 2048, 1024), (2048, 4, 256), (2, 2048, 512)])
 def test_ndfft_long_strided_axes(fft32, fft64, oracle, depth, rows, cols):
     """Long axes that are not contiguous: the strided kernel up to 2048 points; from 4096 points (and 16 MiB of data) two
     column-tile passes with the axis's own table when the number of adjacent lines is a power of two (round 4: AxisLastIO; 2^12 =
-    2^5 x 2^7, 2^13 = 2^6 x 2^7, 2^14 = 2^7 x 2^7, one case with two outer blocks), otherwise transpose -> batched transform ->
+    2^5 x 2^7, 2^13 = 2^6 x 2^7, 2^14 = 2^7 x 2^7, one case with two outer blocks; c32 axes of 2^11 points = 2^6 x 2^5 too), otherwise transpose -> batched transform ->
     transpose back (the 192-column case, every f64 axis of 16384 points).  Every line is still the reference's 1-D transform."""
     rng = seeded(1700 + depth + rows + cols)
     for impl, dt, tol in ((fft32, np.complex64, REL_TOL_F32), (fft64, np.complex128, REL_TOL_F64)):

@@ -1,30 +1,25 @@
-"""2-D / 3-D transforms on device memory: ms per call and fraction of the roofline per axis pass."""
+"""fft2d / fft3d (ndfft.rs:74-155) on device memory, in place.  usage: bench_nd.py [f32|f64] [DxRxC ...]"""
 import sys, pathlib; sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
-import ctypes as C
 import numpy as np, torch, kofft_amd
-from kofft_amd import _lib
-lib = _lib.load()
-f = kofft_amd.HipFftImpl(np.float32)
-stream = torch.cuda.Stream()
-f.set_stream(stream.cuda_stream)
-def run(depth, rows, cols):
-    x = torch.empty((depth, rows, cols, 2), dtype=torch.float32, device="cuda").uniform_(-1, 1)
-    call = lambda: lib.kofft_hip_fftnd_c32_dev(f._ctx, C.c_void_p(x.data_ptr()), depth, rows, cols, 0)
+dt = np.float64 if (len(sys.argv) > 1 and sys.argv[1] == "f64") else np.float32
+tdt = torch.float64 if dt == np.float64 else torch.float32
+es = 16 if dt == np.float64 else 8
+f = kofft_amd.HipFftImpl(dt)
+stream = torch.cuda.Stream(); f.set_stream(stream.cuda_stream)
+shapes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[2:]] or \
+    [(1, 4096, 4096), (1, 2048, 8192), (1, 8192, 2048), (1, 1024, 1024), (1, 16384, 1024), (256, 256, 256), (64, 512, 512), (512, 512, 64),
+     (16, 1024, 1024), (1, 1000, 1000), (100, 100, 100), (1, 4096, 520)]
+for d, r, c in shapes:
+    x = torch.empty((d, r, c, 2), dtype=tdt, device="cuda").uniform_(-1e-3, 1e-3)
+    ts = []
     with torch.cuda.stream(stream):
-        for _ in range(3):
-            assert call() == 0
-        torch.cuda.synchronize()
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record(stream)
-        for _ in range(10):
-            call()
-        e.record(stream)
-        torch.cuda.synchronize()
-    ms = s.elapsed_time(e) / 10
-    axes = 2 if depth == 1 else 3
-    gbs = axes * 2 * x.numel() * 4 / ms / 1e6
-    print(f"{depth} x {rows} x {cols}: {ms:8.3f} ms, {gbs:7.0f} GB/s over {axes} axis passes = {gbs/8000:.3f} of the roofline per pass")
-import os
-shapes = ((1, 4096, 4096), (1, 1024, 1024), (1, 8192, 2048), (1, 512, 16384), (256, 256, 256), (64, 512, 512), (1, 1024, 16384), (1, 2048, 8192), (1024, 128, 128))
-for shape in shapes:
-    run(*shape)
+        for it in range(8):
+            x.uniform_(-1e-3, 1e-3)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record(stream)
+            f.fftnd_dev(x.data_ptr(), d, r, c)
+            e.record(stream); torch.cuda.synchronize()
+            ts.append(s.elapsed_time(e))
+    ms = float(np.median(ts[3:]))
+    axes = (d > 1) + (r > 1) + (c > 1)
+    print(f"{np.dtype(dt).name} {d:4d} x {r:5d} x {c:5d}: {ms:8.3f} ms  {d*r*c/ms/1e6:8.1f} GPoints/s  ({2*es*d*r*c/ms/1e6/8000:.3f} of the roofline on one read + one write; {axes} axes)", flush=True)
