@@ -138,6 +138,18 @@ struct RfCell {
     __device__ __forceinline__ static void st(int byte_off, const T v) { *(lds_t *)(size_t)(unsigned)byte_off = v; }
 };
 
+// A policy with a row window (RowWindowIO below): `win` holds the window as N pairs (w[2e], w[2e+1]).
+template <class IO, class = void>
+struct rf_row_window { static constexpr bool value = false; };
+template <class IO>
+struct rf_row_window<IO, decltype((void)IO::kRowWindow)> { static constexpr bool value = IO::kRowWindow; };
+// rfft_direct's m-point transform of a windowed real row read as m complex values (real_impl.hip.h: rfft_composed_dev at m = 2^15 / 2^14)
+template <typename T>
+struct RowWindowIO : ComplexIO<T, false> {
+    static constexpr bool kRowWindow = true;
+    const cpx<T> *__restrict__ win;
+};
+
 template <typename T, int LA, int LB, int QB0, class IO>
 __global__ __launch_bounds__(1024, 4) void fft_regfile_persist_kernel(const IO io, const cpx<T> *__restrict__ tw, const size_t batch)
 {
@@ -234,8 +246,26 @@ __global__ __launch_bounds__(1024, 4) void fft_regfile_persist_kernel(const IO i
         const rsrc_t nd = io.in_desc_n(nbase, more ? 1 : 0);  // empty when there is no next transform: the loads return zeros
         const size_t xf = base;
         cpx<T> cur[R];
+        if constexpr (rf_row_window<IO>::value) {
+            // rfft_direct's packed row with the batched entry's row window (rfft.rs:444-447 after stft.rs:96): element e = (x[2e] * w[2e],
+            // x[2e+1] * w[2e+1]).  The window pairs depend on the thread only; held across transforms they would be R more registers
+            // (the kernel has none to spare), so they are read per transform, a few at a time, from the L2-resident table (tau_a() is an
+            // opaque copy: the loads cannot be hoisted).
+            const rsrc_t wd = make_rsrc(io.win, (unsigned)Gm::N * (unsigned)ES);
+            const int wl = tau_a() * ES;
+            constexpr int WC = sizeof(T) == 4 ? 8 : 4;  // (f64: eight pairs at a time spill a register)
 #pragma unroll
-        for (int u = 0; u < R; ++u) cur[u] = io.finish_in(raw[u], io.invariant(0));
+            for (int c = 0; c < R; c += WC) {
+                cpx<T> wv[WC];
+#pragma unroll
+                for (int j = 0; j < WC; ++j) wv[j] = buf_load_cpx<T, AUX_DEFAULT>(wd, wl, (c + j) * Gm::TPT * ES);
+#pragma unroll
+                for (int j = 0; j < WC; ++j) cur[c + j] = mk<T>(raw[c + j].re * wv[j].re, raw[c + j].im * wv[j].im);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < R; ++u) cur[u] = io.finish_in(raw[u], io.invariant(0));
+        }
 #ifdef KOFFT_RF_COPY_ONLY /* measurement only: loads and stores alone */
         if (true) {
             const rsrc_t od = io.out_desc_n(xf, 1);

@@ -18,52 +18,103 @@ __global__ __launch_bounds__(256) void real_window_kernel(const T *__restrict__ 
     if (i < total) z[i] = in[i] * window[i % n];  // the framing product of stft.rs:96, element by element
 }
 
+// Post- / pre-pass of the composed route.  Bins k and m - k are computed from the same two inputs (Y[k], Y[m-k]), so one thread does both:
+// every input is read once (one thread per OUTPUT read each of them twice, the second time from another XCD's workgroup -- 1.5x the
+// pass's bytes: rfft 65536 0.30 -> 0.2x ms for this pass).  grid.x covers j = 0 .. m/2, grid.y walks the rows.  Per element the
+// expressions are those of the fused kernels' epilogues (rfft.rs:450-463, 491-503).
+template <typename T>
+__device__ __forceinline__ cpx<T> rfft_post_one(const cpx<T> a, const cpx<T> ymk, const cpx<T> w)
+{
+    const T half = T(0.5f);
+    const cpx<T> bb = mk<T>(ymk.re, -ymk.im);
+    const cpx<T> sum = cadd(a, bb), diff = csub(a, bb);
+    const cpx<T> t = cmul(w, diff);
+    const cpx<T> temp = cadd(sum, mk<T>(t.im, -t.re));
+    return mk<T>(temp.re * half, temp.im * half);
+}
 template <typename T>
 __global__ __launch_bounds__(256) void rfft_post_kernel(const cpx<T> *__restrict__ y, const cpx<T> *__restrict__ rtab,
-                                                        cpx<T> *__restrict__ out, const size_t m, const size_t total /* batch * (m+1) */)
+                                                        cpx<T> *__restrict__ out, const size_t m, const size_t rows)
+{
+    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (j > m / 2) return;
+    for (size_t b = blockIdx.y; b < rows; b += gridDim.y) {
+        const cpx<T> *yr = y + b * m;
+        cpx<T> *xr = out + b * (m + 1);
+        if (j == 0) {  // rfft.rs:450-452
+            const cpx<T> y0 = yr[0];
+            xr[0] = mk<T>(y0.re + y0.im, T(0));
+            xr[m] = mk<T>(y0.re - y0.im, T(0));
+        } else {       // rfft.rs:454-463, for k = j and k = m - j (m odd never pairs a bin with itself; m even: j = m/2 does)
+            const cpx<T> a = yr[j], c = yr[m - j];
+            xr[j] = rfft_post_one<T>(a, c, rtab[j]);
+            if (m - j != j) xr[m - j] = rfft_post_one<T>(c, a, rtab[m - j]);
+        }
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ cpx<T> irfft_pre_one(const cpx<T> a, const cpx<T> rb, const cpx<T> tw)
+{
+    const T half = T(0.5f);
+    const cpx<T> bb = mk<T>(rb.re, -rb.im);
+    const cpx<T> sum = cadd(a, bb), diff = csub(a, bb);
+    const cpx<T> w = mk<T>(tw.re, -tw.im);
+    const cpx<T> t = cmul(w, diff);
+    const cpx<T> temp = csub(sum, mk<T>(t.im, -t.re));
+    return mk<T>(temp.re * half, temp.im * half);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void irfft_pre_kernel(const cpx<T> *__restrict__ in, const cpx<T> *__restrict__ rtab,
+                                                        cpx<T> *__restrict__ scratch, const size_t m, const size_t rows)
+{
+    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (j > m / 2) return;
+    for (size_t b = blockIdx.y; b < rows; b += gridDim.y) {
+        const cpx<T> *row = in + b * (m + 1);
+        cpx<T> *sr = scratch + b * m;
+        if (j == 0) {  // rfft.rs:491-493
+            const T half = T(0.5f);
+            const T r0 = row[0].re, rm = row[m].re;
+            sr[0] = mk<T>((r0 + rm) * half, (r0 - rm) * half);
+        } else {       // rfft.rs:495-503, for k = j and k = m - j
+            const cpx<T> a = row[j], c = row[m - j];
+            sr[j] = irfft_pre_one<T>(a, c, rtab[j]);
+            if (m - j != j) sr[m - j] = irfft_pre_one<T>(c, a, rtab[m - j]);
+        }
+    }
+}
+
+// Short rows (m < 512: a 256-thread block per row would idle): one thread per output element over the whole chunk.
+template <typename T>
+__global__ __launch_bounds__(256) void rfft_post_flat_kernel(const cpx<T> *__restrict__ y, const cpx<T> *__restrict__ rtab,
+                                                             cpx<T> *__restrict__ out, const size_t m, const size_t total /* rows * (m+1) */)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const size_t b = i / (m + 1), k = i % (m + 1);
     const cpx<T> *yr = y + b * m;
-    cpx<T> x;
     if (k == 0 || k == m) {  // rfft.rs:450-452
         const cpx<T> y0 = yr[0];
-        x = (k == 0) ? mk<T>(y0.re + y0.im, T(0)) : mk<T>(y0.re - y0.im, T(0));
-    } else {                 // rfft.rs:454-463
-        const T half = T(0.5f);
-        const cpx<T> a = yr[k], ymk = yr[m - k], w = rtab[k];
-        const cpx<T> bb = mk<T>(ymk.re, -ymk.im);
-        const cpx<T> sum = cadd(a, bb), diff = csub(a, bb);
-        const cpx<T> t = cmul(w, diff);
-        const cpx<T> temp = cadd(sum, mk<T>(t.im, -t.re));
-        x = mk<T>(temp.re * half, temp.im * half);
+        out[i] = (k == 0) ? mk<T>(y0.re + y0.im, T(0)) : mk<T>(y0.re - y0.im, T(0));
+    } else {
+        out[i] = rfft_post_one<T>(yr[k], yr[m - k], rtab[k]);
     }
-    out[i] = x;
 }
-
 template <typename T>
-__global__ __launch_bounds__(256) void irfft_pre_kernel(const cpx<T> *__restrict__ in, const cpx<T> *__restrict__ rtab,
-                                                        cpx<T> *__restrict__ scratch, const size_t m, const size_t total /* batch * m */)
+__global__ __launch_bounds__(256) void irfft_pre_flat_kernel(const cpx<T> *__restrict__ in, const cpx<T> *__restrict__ rtab,
+                                                             cpx<T> *__restrict__ scratch, const size_t m, const size_t total /* rows * m */)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const size_t b = i / m, k = i % m;
     const cpx<T> *row = in + b * (m + 1);
-    const T half = T(0.5f);
-    cpx<T> s;
     if (k == 0) {  // rfft.rs:491-493
-        s = mk<T>((row[0].re + row[m].re) * half, (row[0].re - row[m].re) * half);
-    } else {       // rfft.rs:495-503
-        const cpx<T> a = row[k], rb = row[m - k], tw = rtab[k];
-        const cpx<T> bb = mk<T>(rb.re, -rb.im);
-        const cpx<T> sum = cadd(a, bb), diff = csub(a, bb);
-        const cpx<T> w = mk<T>(tw.re, -tw.im);
-        const cpx<T> t = cmul(w, diff);
-        const cpx<T> temp = csub(sum, mk<T>(t.im, -t.re));
-        s = mk<T>(temp.re * half, temp.im * half);
+        const T half = T(0.5f);
+        scratch[i] = mk<T>((row[0].re + row[m].re) * half, (row[0].re - row[m].re) * half);
+    } else {
+        scratch[i] = irfft_pre_one<T>(row[k], row[m - k], rtab[k]);
     }
-    scratch[i] = s;
 }
 
 inline unsigned blocks_for(size_t total) { return (unsigned)((total + 255) / 256); }
@@ -81,7 +132,11 @@ int rfft_composed_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, const T *d_wi
     if ((chunk * (m + 1) + 255) / 256 > 0x7fffffffULL) return KOFFT_ERR_UNSUPPORTED;
     // Powers of two beyond the single-workgroup sizes (round 3): the window product rides on the factor path's first load
     // (BigColsIO PRE_WINDOW) -- one pass over the input less.  Other lengths (Bluestein's inner transform) keep the kernel.
-    const bool fuse_window = d_window && is_pow2(m) && m > (size_t(1) << max_log2<T>()) && ctx->blue_fused;
+    // m = 2^15 (f32) / 2^14 (f64): the register-file kernel with the window on its loads (fft_regfile.hip.h: RowWindowIO) -- one pass where
+    // the factor path takes two
+    const bool regfile_window = d_window && m == (size_t(2) << max_log2<T>()) && ctx->use_regfile && chunk >= (size_t)ctx->num_cus * 2 &&
+                                batch >= (size_t)ctx->num_cus * 2;
+    const bool fuse_window = !regfile_window && d_window && is_pow2(m) && m > (size_t(1) << max_log2<T>()) && ctx->blue_fused;
     // scratch: [windowed input (only with an unfused window)] [Y]
     const size_t zbytes = (d_window && !fuse_window) ? chunk * n * sizeof(T) : 0, ybytes = chunk * m * sizeof(cpx<T>);
     rc = ensure_real_tmp(ctx, zbytes + ybytes);
@@ -91,7 +146,20 @@ int rfft_composed_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, const T *d_wi
     for (size_t b0 = 0; b0 < batch; b0 += chunk) {
         const size_t nb = (batch - b0 < chunk) ? batch - b0 : chunk;
         const T *src = d_in + b0 * n;
-        if (fuse_window) {
+        if (regfile_window && nb >= (size_t)ctx->num_cus * 2) {
+            const cpx<T> *tw = nullptr;
+            rc = get_table<T>(ctx, Kind<T>::tw, m, &tw);
+            if (rc) return rc;
+            constexpr int RLA = sizeof(T) == 4 ? 8 : 7, RLB = 7, RQB0 = 4;  // as fft_dev routes the plain transform
+            RowWindowIO<T> io{{{}, reinterpret_cast<const cpx<T> *>(src), reinterpret_cast<cpx<T> *>(y), (int)m, (T)1}, reinterpret_cast<const cpx<T> *>(d_window)};
+            rc = launch_regfile<T, RLA, RLB, RQB0>(ctx, io, tw, nb);
+            if (rc) return rc;
+        } else if (regfile_window) {  // a short last chunk: the window product as its own kernel, then whatever fft_dev picks
+            hipLaunchKernelGGL(real_window_kernel<T>, dim3(blocks_for(nb * n)), dim3(256), 0, ctx->stream, src, d_window, z, n, nb * n);
+            KOFFT_HIP_TRY(ctx, hipGetLastError());
+            rc = fft_dev<T>(ctx, z, y, m, nb, 0);
+            if (rc) return rc;
+        } else if (fuse_window) {
             rc = fft_big_windowed_dev<T>(ctx, src, y, d_window, m, nb);
             if (rc) return rc;
         } else if (d_window) {
@@ -100,12 +168,16 @@ int rfft_composed_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, const T *d_wi
             src = z;
         }
         // z[i] = (x[2i], x[2i+1]) (rfft.rs:444-446) is the row itself read as m complex values
-        if (!fuse_window) {
+        if (!fuse_window && !regfile_window) {
             rc = fft_dev<T>(ctx, src, y, m, nb, 0);
             if (rc) return rc;
         }
-        hipLaunchKernelGGL(rfft_post_kernel<T>, dim3(blocks_for(nb * (m + 1))), dim3(256), 0, ctx->stream,
-                           reinterpret_cast<const cpx<T> *>(y), rtab, reinterpret_cast<cpx<T> *>(d_out) + b0 * (m + 1), m, nb * (m + 1));
+        if (m >= 512)
+            hipLaunchKernelGGL(rfft_post_kernel<T>, dim3(blocks_for(m / 2 + 1), (unsigned)(nb < 65535 ? nb : 65535)), dim3(256), 0, ctx->stream,
+                               reinterpret_cast<const cpx<T> *>(y), rtab, reinterpret_cast<cpx<T> *>(d_out) + b0 * (m + 1), m, nb);
+        else
+            hipLaunchKernelGGL(rfft_post_flat_kernel<T>, dim3(blocks_for(nb * (m + 1))), dim3(256), 0, ctx->stream,
+                               reinterpret_cast<const cpx<T> *>(y), rtab, reinterpret_cast<cpx<T> *>(d_out) + b0 * (m + 1), m, nb * (m + 1));
         KOFFT_HIP_TRY(ctx, hipGetLastError());
     }
     return KOFFT_OK;
@@ -127,8 +199,12 @@ int irfft_composed_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, si
     cpx<T> *scratch = static_cast<cpx<T> *>(ctx->real_tmp);
     for (size_t b0 = 0; b0 < batch; b0 += chunk) {
         const size_t nb = (batch - b0 < chunk) ? batch - b0 : chunk;
-        hipLaunchKernelGGL(irfft_pre_kernel<T>, dim3(blocks_for(nb * m)), dim3(256), 0, ctx->stream,
-                           reinterpret_cast<const cpx<T> *>(d_in) + b0 * (m + 1), rtab, scratch, m, nb * m);
+        if (m >= 512)
+            hipLaunchKernelGGL(irfft_pre_kernel<T>, dim3(blocks_for(m / 2 + 1), (unsigned)(nb < 65535 ? nb : 65535)), dim3(256), 0, ctx->stream,
+                               reinterpret_cast<const cpx<T> *>(d_in) + b0 * (m + 1), rtab, scratch, m, nb);
+        else
+            hipLaunchKernelGGL(irfft_pre_flat_kernel<T>, dim3(blocks_for(nb * m)), dim3(256), 0, ctx->stream,
+                               reinterpret_cast<const cpx<T> *>(d_in) + b0 * (m + 1), rtab, scratch, m, nb * m);
         KOFFT_HIP_TRY(ctx, hipGetLastError());
         // fft.ifft(&mut scratch[..m]) (rfft.rs:504), then output[2i], output[2i+1] = scratch[i].re, .im: the rows of d_out
         rc = fft_dev<T>(ctx, reinterpret_cast<const T *>(scratch), d_out + b0 * n, m, nb, 1);

@@ -463,6 +463,30 @@ def test_regfile_resident_kernels_every_transform(oracle, dtype, log2n, batch, m
     assert_parity(outs[0][1], oracle.ifft(want), f"regfile inverse {dtype} 2^{log2n} x {batch}", tol)
 
 
+@pytest.mark.parametrize("dtype,n,batch", [("f32", 65536, 515), ("f32", 65536, 1027), ("f64", 32768, 520)])
+def test_windowed_rfft_through_the_regfile_kernel(oracle, dtype, n, batch, monkeypatch):
+    """rfft of 65536 (f32) / 32768 (f64) samples WITH a row window: the m-point transform of the packed row runs in the register-file
+    kernel with the window product on its loads (RowWindowIO; without it the window rides on the factor path's first load: two passes).
+    EVERY row against the oracle, and byte for byte against KOFFT_HIP_REGFILE=0; without a window (plain loads) alike."""
+    import kofft_amd
+
+    rdt = np.float32 if dtype == "f32" else np.float64
+    rng = seeded(4400 + n + batch)
+    x = rng.uniform(-1, 1, (batch, n)).astype(rdt)
+    win = rng.uniform(0.1, 1, n).astype(rdt)
+    want = oracle.rfft(x, win)
+    want_plain = oracle.rfft(x)
+    outs = []
+    for regfile in ("1", "0"):
+        monkeypatch.setenv("KOFFT_HIP_REGFILE", regfile)  # read when the context is created
+        f = kofft_amd.HipFftImpl(rdt)
+        got = f.rfft_batch(x, win)
+        assert_parity(got, want, f"windowed rfft regfile={regfile} {dtype} n={n} x {batch}", REL_TOL_F32 if dtype == "f32" else REL_TOL_F64)
+        assert bits_equal(f.rfft_batch(x), want_plain)
+        outs.append(got)
+    assert bits_equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("log2n,batch", [(15, 40), (16, 40), (17, 33), (18, 20), (19, 18), (20, 10), (21, 9)])
 def test_c32_last_factor_on_row_pairs(oracle, log2n, batch, monkeypatch):
     """Round 4: the c32 last factor of the two-factor path runs on PAIRS of adjacent rows -- two Complex<f32> values as one 16-byte value
