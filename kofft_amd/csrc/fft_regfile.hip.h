@@ -150,6 +150,34 @@ struct RowWindowIO : ComplexIO<T, false> {
     const cpx<T> *__restrict__ win;
 };
 
+// irfft_direct's pre-pass on the loads (rfft.rs:491-503): element e of the m-point inverse transform's input is computed from bins e and
+// m - e of the (m + 1)-bin row and table entry e.  Bin e is the thread's prefetched element; bin m - e is some other thread's prefetched
+// element of the SAME transform (an L2 hit by the time it is wanted) -- no exchange, and the pre-pass kernel's pass over HBM is gone.
+template <class IO, class = void>
+struct rf_irfft_pre { static constexpr bool value = false; };
+template <class IO>
+struct rf_irfft_pre<IO, decltype((void)IO::kIrfftPre)> { static constexpr bool value = IO::kIrfftPre; };
+template <typename T>
+__device__ __forceinline__ cpx<T> irfft_pre_one(const cpx<T> a, const cpx<T> rb, const cpx<T> tw)
+{
+    const T half = T(0.5f);
+    const cpx<T> bb = mk<T>(rb.re, -rb.im);
+    const cpx<T> sum = cadd(a, bb), diff = csub(a, bb);
+    const cpx<T> w = mk<T>(tw.re, -tw.im);
+    const cpx<T> t = cmul(w, diff);
+    const cpx<T> temp = csub(sum, mk<T>(t.im, -t.re));
+    return mk<T>(temp.re * half, temp.im * half);
+}
+template <typename T>
+struct IrfftRowIO : ComplexIO<T, true> {  // in: rows of n + 1 bins; out: rows of n complex values = 2n reals; ifft's conj / scale as ComplexIO
+    static constexpr bool kIrfftPre = true;
+    const cpx<T> *__restrict__ rtab;  // the RfftPlanner table, n entries
+    __device__ __forceinline__ rsrc_t in_desc_n(size_t xf0, int cnt) const
+    {
+        return make_rsrc(this->in + (cnt > 0 ? xf0 : 0) * (size_t)(this->n + 1), (unsigned)(cnt > 0 ? cnt : 0) * (unsigned)(this->n + 1) * (unsigned)sizeof(cpx<T>));
+    }
+};
+
 template <typename T, int LA, int LB, int QB0, class IO>
 __global__ __launch_bounds__(1024, 4) void fft_regfile_persist_kernel(const IO io, const cpx<T> *__restrict__ tw, const size_t batch)
 {
@@ -261,6 +289,37 @@ __global__ __launch_bounds__(1024, 4) void fft_regfile_persist_kernel(const IO i
                 for (int j = 0; j < WC; ++j) wv[j] = buf_load_cpx<T, AUX_DEFAULT>(wd, wl, (c + j) * Gm::TPT * ES);
 #pragma unroll
                 for (int j = 0; j < WC; ++j) cur[c + j] = mk<T>(raw[c + j].re * wv[j].re, raw[c + j].im * wv[j].im);
+            }
+        } else if constexpr (rf_irfft_pre<IO>::value) {
+            const rsrc_t rd = io.in_desc_n(xf, 1);  // this transform's row: bins 0 .. N
+            const rsrc_t td = make_rsrc(io.rtab, (unsigned)Gm::N * (unsigned)ES);
+            const int ta = tau_a();
+            // bins and table entries in chunks of WC, the next chunk's loads in flight while this one is computed (all at once would be 2 R values)
+            constexpr int WC = sizeof(T) == 4 ? 4 : 2;
+            cpx<T> mv[2][WC], tv[2][WC];
+            auto issue = [&](const int c, cpx<T> *m_, cpx<T> *t_) {
+#pragma unroll
+                for (int j = 0; j < WC; ++j) {
+                    m_[j] = buf_load_cpx<T, AUX_DEFAULT>(rd, (Gm::N - ta - (c + j) * Gm::TPT) * ES, 0);  // bin N - e (e = 0: bin N)
+                    t_[j] = buf_load_cpx<T, AUX_DEFAULT>(td, ta * ES, (c + j) * Gm::TPT * ES);
+                }
+            };
+            issue(0, mv[0], tv[0]);
+#pragma unroll
+            for (int c = 0; c < R; c += WC) {
+                const int cb = (c / WC) & 1;
+                if (c + WC < R) issue(c + WC, mv[cb ^ 1], tv[cb ^ 1]);
+#pragma unroll
+                for (int j = 0; j < WC; ++j) {
+                    cpx<T> sv = irfft_pre_one<T>(raw[c + j], mv[cb][j], tv[cb][j]);
+                    if (c + j == 0) {  // e = 0 (rfft.rs:491-493): only the real parts of bins 0 and N
+                        const T half = T(0.5f);
+                        const cpx<T> s0 = mk<T>((raw[0].re + mv[0][0].re) * half, (raw[0].re - mv[0][0].re) * half);
+                        sv = ta == 0 ? s0 : sv;
+                    }
+                    sv.im = -sv.im;  // ifft: conj on the way in (fft.rs:1163-1165)
+                    cur[c + j] = sv;
+                }
             }
         } else {
 #pragma unroll

@@ -54,17 +54,6 @@ __global__ __launch_bounds__(256) void rfft_post_kernel(const cpx<T> *__restrict
 }
 
 template <typename T>
-__device__ __forceinline__ cpx<T> irfft_pre_one(const cpx<T> a, const cpx<T> rb, const cpx<T> tw)
-{
-    const T half = T(0.5f);
-    const cpx<T> bb = mk<T>(rb.re, -rb.im);
-    const cpx<T> sum = cadd(a, bb), diff = csub(a, bb);
-    const cpx<T> w = mk<T>(tw.re, -tw.im);
-    const cpx<T> t = cmul(w, diff);
-    const cpx<T> temp = csub(sum, mk<T>(t.im, -t.re));
-    return mk<T>(temp.re * half, temp.im * half);
-}
-template <typename T>
 __global__ __launch_bounds__(256) void irfft_pre_kernel(const cpx<T> *__restrict__ in, const cpx<T> *__restrict__ rtab,
                                                         cpx<T> *__restrict__ scratch, const size_t m, const size_t rows)
 {
@@ -199,6 +188,18 @@ int irfft_composed_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, si
     cpx<T> *scratch = static_cast<cpx<T> *>(ctx->real_tmp);
     for (size_t b0 = 0; b0 < batch; b0 += chunk) {
         const size_t nb = (batch - b0 < chunk) ? batch - b0 : chunk;
+        if (m == (size_t(2) << max_log2<T>()) && ctx->use_regfile && nb >= (size_t)ctx->num_cus * 2) {
+            // m = 2^15 (f32) / 2^14 (f64): the pre-pass on the register-file kernel's loads (fft_regfile.hip.h: IrfftRowIO) -- one pass instead of two
+            const cpx<T> *tw = nullptr;
+            rc = get_table<T>(ctx, Kind<T>::tw, m, &tw);
+            if (rc) return rc;
+            constexpr int RLA = sizeof(T) == 4 ? 8 : 7, RLB = 7, RQB0 = 4;  // as fft_dev routes the plain transform
+            const T scale = (T)1 / (T)(float)m;                              // fft.rs:1167
+            IrfftRowIO<T> io{{{}, reinterpret_cast<const cpx<T> *>(d_in) + b0 * (m + 1), reinterpret_cast<cpx<T> *>(d_out + b0 * n), (int)m, scale}, rtab};
+            rc = launch_regfile<T, RLA, RLB, RQB0>(ctx, io, tw, nb);
+            if (rc) return rc;
+            continue;
+        }
         if (m >= 512)
             hipLaunchKernelGGL(irfft_pre_kernel<T>, dim3(blocks_for(m / 2 + 1), (unsigned)(nb < 65535 ? nb : 65535)), dim3(256), 0, ctx->stream,
                                reinterpret_cast<const cpx<T> *>(d_in) + b0 * (m + 1), rtab, scratch, m, nb);

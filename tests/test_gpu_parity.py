@@ -467,7 +467,8 @@ def test_regfile_resident_kernels_every_transform(oracle, dtype, log2n, batch, m
 def test_windowed_rfft_through_the_regfile_kernel(oracle, dtype, n, batch, monkeypatch):
     """rfft of 65536 (f32) / 32768 (f64) samples WITH a row window: the m-point transform of the packed row runs in the register-file
     kernel with the window product on its loads (RowWindowIO; without it the window rides on the factor path's first load: two passes).
-    EVERY row against the oracle, and byte for byte against KOFFT_HIP_REGFILE=0; without a window (plain loads) alike."""
+    EVERY row against the oracle, and byte for byte against KOFFT_HIP_REGFILE=0; without a window (plain loads) alike; and irfft of the
+    result, whose pre-pass (bins e and m - e -> element e) rides on the same kernel's loads."""
     import kofft_amd
 
     rdt = np.float32 if dtype == "f32" else np.float64
@@ -483,8 +484,11 @@ def test_windowed_rfft_through_the_regfile_kernel(oracle, dtype, n, batch, monke
         got = f.rfft_batch(x, win)
         assert_parity(got, want, f"windowed rfft regfile={regfile} {dtype} n={n} x {batch}", REL_TOL_F32 if dtype == "f32" else REL_TOL_F64)
         assert bits_equal(f.rfft_batch(x), want_plain)
-        outs.append(got)
-    assert bits_equal(outs[0], outs[1])
+        # ... and back: irfft with the pre-pass on the same kernel's loads (IrfftRowIO), every row
+        back = f.irfft_batch(got, n)
+        assert_parity(back, oracle.irfft(got, n), f"irfft regfile={regfile} {dtype} n={n} x {batch}", REL_TOL_F32 if dtype == "f32" else REL_TOL_F64)
+        outs.append((got, back))
+    assert bits_equal(outs[0][0], outs[1][0]) and bits_equal(outs[0][1], outs[1][1])
 
 
 @pytest.mark.parametrize("log2n,batch", [(15, 40), (16, 40), (17, 33), (18, 20), (19, 18), (20, 10), (21, 9)])
