@@ -86,9 +86,16 @@ def main():
                 check(bits_equal(y, oracle.ifft(x) if inv else oracle.fft(x)), (dt, n, batch, inv))
         batch = int(rng.integers(512, 700))
         x = rng.uniform(-1, 1, (batch, 65536)).astype(np.float32)
-        got = f32.rfft_batch(x)
-        check(bits_equal(got, oracle.rfft(x)), ("rfft", 65536, batch))
+        win = rng.uniform(0, 1, 65536).astype(np.float32) if rng.random() < 0.6 else None  # (a window: RowWindowIO on the register-file kernel)
+        got = f32.rfft_batch(x, win)
+        check(bits_equal(got, oracle.rfft(x, win)), ("rfft", 65536, batch, win is not None))
         check(bits_equal(f32.irfft_batch(got, 65536), oracle.irfft(got, 65536)), ("irfft", 65536, batch))
+        batch = int(rng.integers(512, 600))
+        x = rng.uniform(-1, 1, (batch, 32768))
+        win = rng.uniform(0, 1, 32768) if rng.random() < 0.6 else None
+        got = f64.rfft_batch(x, win)
+        check(bits_equal(got, oracle.rfft(x, win)), ("rfft64", 32768, batch, win is not None))
+        check(bits_equal(f64.irfft_batch(got, 32768), oracle.irfft(got, 32768)), ("irfft64", 32768, batch))
         for log2n in (14, 15, 16, 18):
             n = 1 << log2n
             batch = int(rng.integers((8192 >> (log2n // 2)) + 1, (8192 >> (log2n // 2)) + 40))  # just above the persistent factors' threshold
