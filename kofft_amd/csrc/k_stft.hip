@@ -111,7 +111,6 @@ static int launch_istft_fused(kofft_hip_ctx *ctx, float *d_frames, size_t frames
     const size_t fpw = ((steps + grid - 1) / grid) * XPB;  // frames per workgroup: whole steps
     if (fpw < 4 * XPB || fpw < (size_t)(2 * C)) return KOFFT_OK;
     const size_t runs = (frames + fpw - 1) / fpw;
-    if ((frames + XPB) * (size_t)HOP > 0xffffffffffffull) return KOFFT_OK;
     const cpx<float> *tw = nullptr;
     int rc = get_table<float>(ctx, Kind<float>::tw, N, &tw);
     if (rc) return rc;

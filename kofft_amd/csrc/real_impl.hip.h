@@ -123,9 +123,9 @@ int rfft_composed_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, const T *d_wi
     // (BigColsIO PRE_WINDOW) -- one pass over the input less.  Other lengths (Bluestein's inner transform) keep the kernel.
     // m = 2^15 (f32) / 2^14 (f64): the register-file kernel with the window on its loads (fft_regfile.hip.h: RowWindowIO) -- one pass where
     // the factor path takes two
-    const bool regfile_window = d_window && m == (size_t(2) << max_log2<T>()) && ctx->use_regfile && chunk >= (size_t)ctx->num_cus * 2 &&
-                                batch >= (size_t)ctx->num_cus * 2;
-    const bool fuse_window = !regfile_window && d_window && is_pow2(m) && m > (size_t(1) << max_log2<T>()) && ctx->blue_fused;
+    // (a chunk with fewer than two transforms per CU -- a short last one -- takes the route below it)
+    const bool regfile_window = d_window && m == (size_t(2) << max_log2<T>()) && ctx->use_regfile;
+    const bool fuse_window = d_window && is_pow2(m) && m > (size_t(1) << max_log2<T>()) && ctx->blue_fused;
     // scratch: [windowed input (only with an unfused window)] [Y]
     const size_t zbytes = (d_window && !fuse_window) ? chunk * n * sizeof(T) : 0, ybytes = chunk * m * sizeof(cpx<T>);
     rc = ensure_real_tmp(ctx, zbytes + ybytes);
@@ -143,11 +143,6 @@ int rfft_composed_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, const T *d_wi
             RowWindowIO<T> io{{{}, reinterpret_cast<const cpx<T> *>(src), reinterpret_cast<cpx<T> *>(y), (int)m, (T)1}, reinterpret_cast<const cpx<T> *>(d_window)};
             rc = launch_regfile<T, RLA, RLB, RQB0>(ctx, io, tw, nb);
             if (rc) return rc;
-        } else if (regfile_window) {  // a short last chunk: the window product as its own kernel, then whatever fft_dev picks
-            hipLaunchKernelGGL(real_window_kernel<T>, dim3(blocks_for(nb * n)), dim3(256), 0, ctx->stream, src, d_window, z, n, nb * n);
-            KOFFT_HIP_TRY(ctx, hipGetLastError());
-            rc = fft_dev<T>(ctx, z, y, m, nb, 0);
-            if (rc) return rc;
         } else if (fuse_window) {
             rc = fft_big_windowed_dev<T>(ctx, src, y, d_window, m, nb);
             if (rc) return rc;
@@ -157,7 +152,7 @@ int rfft_composed_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, const T *d_wi
             src = z;
         }
         // z[i] = (x[2i], x[2i+1]) (rfft.rs:444-446) is the row itself read as m complex values
-        if (!fuse_window && !regfile_window) {
+        if (!fuse_window && !(regfile_window && nb >= (size_t)ctx->num_cus * 2)) {
             rc = fft_dev<T>(ctx, src, y, m, nb, 0);
             if (rc) return rc;
         }
