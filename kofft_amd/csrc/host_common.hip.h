@@ -303,17 +303,12 @@ template <> struct PersistCfg<10, RfftIO<float>> : PersistCfgBase<RfftIO<float>>
 template <> struct PersistCfg<10, StftIO> : PersistCfgBase<StftIO> {
     static constexpr int BLOCK = 256, MINW = 2, WG_PER_CU = 2, DEPTH = KOFFT_STFT10_DEPTH;
 };
-#ifndef KOFFT_MAG10_TWLDS
-#define KOFFT_MAG10_TWLDS false
-#endif
-#ifndef KOFFT_MAG10_WG
-#define KOFFT_MAG10_WG 3
-#endif
 // stft_magnitudes runs the n-point COMPLEX transform of each real frame (visual/spectrogram.rs:52-76): twice STFT's butterflies for half
 // its output -- compute-limited at every window; window in LDS and three workgroups per CU: n = 1024 0.210 -> 0.195 ms (config 4's stream)
 template <> struct PersistCfg<10, StftMagIO> {
-    static constexpr int BLOCK = 256, NBUF = 1, RL = 4, MINW = KOFFT_MAG10_WG, WG_PER_CU = KOFFT_MAG10_WG, DEPTH = KOFFT_STFT10_DEPTH;
-    static constexpr bool kInvInLds = KOFFT_MAG10_WG >= 3, kTwLastInLds = KOFFT_MAG10_TWLDS;
+    // (the last pass's twiddles from an LDS copy -- no spill at three workgroups -- measured slower: 0.205 -> 0.220 ms)
+    static constexpr int BLOCK = 256, NBUF = 1, RL = 4, MINW = 3, WG_PER_CU = 3, DEPTH = KOFFT_STFT10_DEPTH;
+    static constexpr bool kInvInLds = true, kTwLastInLds = false;
 };
 // irfft prefetches two row elements per output: the last pass reads its twiddles from LDS to stay inside 256 VGPRs
 #ifndef KOFFT_IRFFT10_WG
@@ -344,13 +339,7 @@ template <> struct PersistCfg<11, StftIO> : PersistCfgStftBig<StftIO> {};
 // (the magnitude kernels spill 21 / 11 registers at three workgroups per CU -- tools/kernel_regs.py -- and are still 13 % faster than at two:
 // n = 2048 / 4096 0.219 / 0.226 against 0.250 / 0.254 ms)
 template <> struct PersistCfg<12, StftMagIO> : PersistCfgStftBig<StftMagIO> {};
-#ifndef KOFFT_MAG11_TWLDS
-#define KOFFT_MAG11_TWLDS false
-#endif
-template <> struct PersistCfg<11, StftMagIO> {
-    static constexpr int BLOCK = 256, NBUF = 1, RL = 4, MINW = 3, WG_PER_CU = 3;
-    static constexpr bool kInvInLds = true, kTwLastInLds = KOFFT_MAG11_TWLDS;
-};
+template <> struct PersistCfg<11, StftMagIO> : PersistCfgStftBig<StftMagIO> {};
 // rfft 8192 (m = 4096): window pairs in registers so that two workgroups (exchange buffer + post-pass table) fit a CU
 template <> struct PersistCfg<12, RfftIO<float>> {
     static constexpr int BLOCK = 256, NBUF = 1, RL = 4, MINW = 2, WG_PER_CU = 2;
