@@ -1023,11 +1023,15 @@ __global__ __launch_bounds__(BLOCK) void bluestein_wg_kernel(const cpx<T> *__res
     const bool active = xf < batch;
     const PlainTw io{};
 
+    // m >= 2n (see bluestein_persist_kernel): registers R/2 .. R-1 of the first pass hold elements m/2 .. m-1, zeros whatever n is
+    static_assert(G0::in_index(0, R / 2) == N / 2, "pass 0: the register number is the index's top bits");
     cpx<T> v[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) v[u] = mk<T>(T(0), T(0));
     if (active) {  // one branch around all loads
         const cpx<T> *row = in + xf * (size_t)n;
 #pragma unroll
-        for (int u = 0; u < R; ++u) {
+        for (int u = 0; u < R / 2; ++u) {
             const int i = G0::in_index(tau, u);
             const int ic = i < n ? i : n - 1;  // branch-free: clamp the address, select the value
             cpx<T> x = ld_stream(row + ic);
@@ -1035,9 +1039,6 @@ __global__ __launch_bounds__(BLOCK) void bluestein_wg_kernel(const cpx<T> *__res
             const cpx<T> a = cmul(x, chirp[ic]);
             v[u] = i < n ? a : mk<T>(T(0), T(0));
         }
-    } else {
-#pragma unroll
-        for (int u = 0; u < R; ++u) v[u] = mk<T>(T(0), T(0));
     }
     auto transform = [&]() {
         wg_compute<T, L, RL, 0>(v, io, tw, xf, tau);
@@ -1047,25 +1048,27 @@ __global__ __launch_bounds__(BLOCK) void bluestein_wg_kernel(const cpx<T> *__res
         if constexpr (NP > 4) { wg_exchange<T, L, RL, 3, false, false, XPB>(v, smem_raw, tau, slot); wg_compute<T, L, RL, 4>(v, io, tw, xf, tau); }
     };
     transform();
-    // a *= fft(b) (fft.rs:1119-1121), then ifft's conj on the way in; natural order -> the first pass's register layout
-    cpx<T> *buf = reinterpret_cast<cpx<T> *>(smem_raw) + (size_t)slot * lds_elems(N);
-    __syncthreads();  // the last gathers of the first transform are done
+    // a *= fft(b) (fft.rs:1119-1121), then ifft's conj on the way in; natural order -> the first pass's register layout: the same element
+    // stays in the same thread (bluestein_persist_kernel), register u' = out_index(0, u) / TPT -- a renaming (round 2 went through LDS)
+    {
+        cpx<T> w[R];
 #pragma unroll
-    for (int u = 0; u < R; ++u) {
-        const int o = GL::out_index(tau, u);
-        cpx<T> w = cmul(v[u], bfft[o]);
-        w.im = -w.im;
-        buf[lds_pad(o)] = w;
+        for (int u = 0; u < R; ++u) {
+            static_assert(GL::out_index(0, 1) >= TPT && G0::in_index(0, 1) == TPT, "register bits above the thread bits");
+            cpx<T> p = cmul(v[u], bfft[GL::out_index(tau, u)]);
+            p.im = -p.im;
+            w[GL::out_index(0, u) / TPT] = p;
+        }
+#pragma unroll
+        for (int u = 0; u < R; ++u) v[u] = w[u];
     }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < R; ++u) v[u] = buf[lds_pad(G0::in_index(tau, u))];
-    __syncthreads();  // ... before the second transform's first scatter
+    __syncthreads();  // the last gathers of the first transform are done before the second transform's first scatter
     transform();
     if (active) {
         cpx<T> *orow = out + xf * (size_t)n;
 #pragma unroll
         for (int u = 0; u < R; ++u) {
+            if (GL::out_index(0, u) >= N / 2) continue;  // outputs m/2 .. m-1 are never stored (n <= m/2)
             const int o = GL::out_index(tau, u);
             if (o < n) {
                 cpx<T> a = v[u];
