@@ -334,6 +334,7 @@ template <class IO> struct PersistCfgStftBig {
     static constexpr int BLOCK = 256, NBUF = 1, RL = 4, MINW = 3, WG_PER_CU = 3;
     static constexpr bool kInvInLds = true, kTwLastInLds = false;
 };
+// (round 4: 8 points per thread -- four passes, 104-107 registers, four wavefronts per SIMD -- measured 8 % slower at both sizes)
 template <> struct PersistCfg<12, StftIO> : PersistCfgStftBig<StftIO> {};
 template <> struct PersistCfg<11, StftIO> : PersistCfgStftBig<StftIO> {};
 // (the magnitude kernels spill 21 / 11 registers at three workgroups per CU -- tools/kernel_regs.py -- and are still 13 % faster than at two:
