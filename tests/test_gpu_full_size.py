@@ -126,6 +126,80 @@ def test_cfg4_stft_10min_48k(dev_fft, oracle):
         assert torch.equal(part, out[f0:f1])
 
 
+def test_cfg4_istft_of_the_spectra_full_size(dev_fft, oracle, monkeypatch):
+    """SURVEY 8(f) row 1 at the bench's size: ISTFT of config #4's 112 500 spectra (fused inverse transform + overlap-add, seams and tail on
+    the ordered overlap-add kernel).  The WHOLE output and scratch against the oracle bit for bit (the C restatement takes ~2 s for
+    115 M points), the frames left behind on a sample, the round trip against the signal, and every byte against the two-kernel route."""
+    import kofft_amd
+
+    fft, stream = dev_fft
+    total, win_len, hop = 28_800_000, 1024, 256
+    frames = -(-total // hop)
+    with torch.cuda.stream(stream):
+        t = torch.arange(total, dtype=torch.float32, device="cuda")
+        g = torch.Generator(device="cuda")
+        g.manual_seed(5)
+        sig = 0.5 * torch.sin(2 * np.pi * 440.0 * t / 48000.0) + 0.25 * torch.empty_like(t).uniform_(-1, 1, generator=g)
+        del t
+        win_h = kofft_amd.hann(win_len)
+        win = torch.from_numpy(win_h).cuda()
+        spec = torch.empty((frames, win_len, 2), dtype=torch.float32, device="cuda")
+        fft.stft_dev(sig.data_ptr(), total, win.data_ptr(), win_len, hop, spec.data_ptr(), 0, frames)
+        stream.synchronize()
+        spec_h = spec.cpu().numpy().view(np.complex64).reshape(frames, win_len)
+        want = oracle.istft(spec_h, win_h, hop, total)
+        work = spec.clone()
+        out = torch.zeros(total, dtype=torch.float32, device="cuda")
+        scratch = torch.full((total,), 7.0, dtype=torch.float32, device="cuda")
+        fft.istft_dev(work.data_ptr(), frames, win.data_ptr(), win_len, hop, out.data_ptr(), total, scratch.data_ptr())
+        stream.synchronize()
+        assert bits_equal(out.cpu().numpy(), want)
+        pick = [0, 1, 2, 3, 219, 220, 221, 56_250, frames - 2, frames - 1]  # (220 frames per workgroup run at 512 workgroups: a seam)
+        assert bits_equal(work[pick].cpu().numpy().view(np.complex64).reshape(len(pick), win_len), oracle.ifft(spec_h[pick]))
+        ok = scratch > 1e-3
+        assert (out[ok] - sig[ok]).abs().max().item() < 1e-3
+        # the two-kernel route: same bytes everywhere
+        monkeypatch.setenv("KOFFT_HIP_ISTFT_FUSED", "0")
+        two = kofft_amd.HipFftImpl(np.float32, device=0)
+        two.set_stream(stream.cuda_stream)
+        work2 = spec.clone()
+        out2 = torch.zeros(total, dtype=torch.float32, device="cuda")
+        scratch2 = torch.zeros(total, dtype=torch.float32, device="cuda")
+        two.istft_dev(work2.data_ptr(), frames, win.data_ptr(), win_len, hop, out2.data_ptr(), total, scratch2.data_ptr())
+        stream.synchronize()
+        assert torch.equal(out.view(torch.int32), out2.view(torch.int32)) and torch.equal(scratch.view(torch.int32), scratch2.view(torch.int32))
+        assert torch.equal(work.view(torch.int32), work2.view(torch.int32))
+
+
+def test_bluestein_65536x1000_full_size(dev_fft, oracle, monkeypatch):
+    """SURVEY 8(f) row 4 at the bench's size: 65 536 x 1000-pt c32 through the Bluestein arm (persistent kernel).  A sample of rows against
+    the oracle bit for bit, EVERY row against the one-workgroup-per-transform kernel (KOFFT_HIP_BLUESTEIN_PERSIST=0), and the round trip."""
+    import kofft_amd
+
+    fft, stream = dev_fft
+    n, batch = 1000, 65536
+    with torch.cuda.stream(stream):
+        g = torch.Generator(device="cuda")
+        g.manual_seed(77)
+        x = torch.empty((batch, n, 2), dtype=torch.float32, device="cuda").uniform_(-1, 1, generator=g)
+        y = torch.empty_like(x)
+        fft.fft_dev_oop(x.data_ptr(), y.data_ptr(), n, batch)
+        stream.synchronize()
+        idx = torch.tensor([0, 1, 2, 1023, 1024, 2047, 2048, 32768, 50_000, 65534, 65535], device="cuda")
+        got = y[idx].cpu().numpy().view(np.complex64).reshape(len(idx), n)
+        assert bits_equal(got, oracle.fft(x[idx].cpu().numpy().view(np.complex64).reshape(len(idx), n)))
+        monkeypatch.setenv("KOFFT_HIP_BLUESTEIN_PERSIST", "0")
+        old = kofft_amd.HipFftImpl(np.float32, device=0)
+        old.set_stream(stream.cuda_stream)
+        y2 = torch.empty_like(x)
+        old.fft_dev_oop(x.data_ptr(), y2.data_ptr(), n, batch)
+        stream.synchronize()
+        assert torch.equal(y.view(torch.int32), y2.view(torch.int32))
+        fft.fft_dev(y.data_ptr(), n, batch, True)
+        stream.synchronize()
+        assert (y - x).abs().max().item() < 2e-3
+
+
 def test_cfg5_1024x2p20_c64(oracle):
     """config #5 at full size: 1024 x 2^20-point Complex64 forward (16 GiB in, 16 GiB out), two-factor device path."""
     import kofft_amd
