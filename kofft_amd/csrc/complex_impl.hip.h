@@ -579,9 +579,9 @@ constexpr bool blue_persist_ok()
 {
     return L >= 5 && L <= (sizeof(T) == 4 ? 13 : 12);
 }
-template <typename T, int L, bool INVERSE>
-int launch_bluestein_persist(kofft_hip_ctx *ctx, const cpx<T> *in, cpx<T> *out, const cpx<T> *chirp, const cpx<T> *bfft, const cpx<T> *tw,
-                             size_t n, size_t batch, T scale_m, T scale_n)
+template <typename T, int L, bool INVERSE, class SRC>
+int launch_bluestein_persist_src(kofft_hip_ctx *ctx, const SRC &src, cpx<T> *out, const cpx<T> *chirp, const cpx<T> *bfft, const cpx<T> *tw,
+                                 size_t n, size_t batch, T scale_m, T scale_n)
 {
     constexpr int RL = blue_persist_rl<T>(L);
     constexpr int BLOCK = blue_persist_block<T>(L);
@@ -589,20 +589,30 @@ int launch_bluestein_persist(kofft_hip_ctx *ctx, const cpx<T> *in, cpx<T> *out, 
     constexpr int XPB = BLOCK / TPT;
     constexpr size_t lds = (size_t)XPB * lds_elems(1 << L) * sizeof(cpx<T>);
     static_assert(lds * blue_persist_wg<T>(L) <= 160 * 1024, "LDS budget");
-    auto kern = bluestein_persist_kernel<T, L, RL, BLOCK, blue_persist_wg<T>(L), INVERSE>;
+    // (the STFT source's 64-bit sample positions and window values cost registers: one workgroup per CU less where the row form is at its limit)
+    constexpr bool kRows = std::is_same<SRC, BlueRowsSrc<T, INVERSE>>::value;
+    constexpr int WG = (kRows || blue_persist_wg<T>(L) <= 2 || RL == 2 || L == 9) ? blue_persist_wg<T>(L) : blue_persist_wg<T>(L) - 1;
+    auto kern = bluestein_persist_kernel<T, L, RL, BLOCK, WG, INVERSE, SRC>;
     {
         static std::atomic<unsigned long long> attr_done{0};
         const int arc = set_dyn_lds_once(ctx, attr_done, reinterpret_cast<const void *>(kern), lds);
         if (arc) return arc;
     }
-    size_t blocks = (size_t)ctx->num_cus * blue_persist_wg<T>(L);
+    size_t blocks = (size_t)ctx->num_cus * WG;
     if (ctx->persist_grid_pct > 0) blocks = blocks * (size_t)ctx->persist_grid_pct / 100;
     if (blocks < 1) blocks = 1;
     const size_t need = (batch + XPB - 1) / XPB;
     if (blocks > need) blocks = need;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BLOCK), lds, ctx->stream, in, out, chirp, bfft, tw, (int)n, scale_m, scale_n, batch);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BLOCK), lds, ctx->stream, src, out, chirp, bfft, tw, (int)n, scale_m, scale_n, batch);
     KOFFT_HIP_TRY(ctx, hipGetLastError());
     return KOFFT_OK;
+}
+template <typename T, int L, bool INVERSE>
+int launch_bluestein_persist(kofft_hip_ctx *ctx, const cpx<T> *in, cpx<T> *out, const cpx<T> *chirp, const cpx<T> *bfft, const cpx<T> *tw,
+                             size_t n, size_t batch, T scale_m, T scale_n)
+{
+    const BlueRowsSrc<T, INVERSE> src{in, (int)n, batch};
+    return launch_bluestein_persist_src<T, L, INVERSE>(ctx, src, out, chirp, bfft, tw, n, batch, scale_m, scale_n);
 }
 template <typename T, int L>
 bool blue_persist_pays(const kofft_hip_ctx *ctx, size_t batch)
@@ -610,6 +620,51 @@ bool blue_persist_pays(const kofft_hip_ctx *ctx, size_t batch)
     constexpr int XPB = blue_persist_block<T>(L) / ((1 << L) >> blue_persist_rl<T>(L));
     return ctx->blue_persist && batch >= (size_t)ctx->num_cus * blue_persist_wg<T>(L) * XPB * KOFFT_BLUE_PERSIST_MIN_ITERS;
 }
+
+// STFT with a window length that is not a power of two (stft.rs:91-103 calls fft.fft(frame) for any win_len): the frames through the
+// persistent Bluestein kernel with the framing product on its loads.  *done = false: the caller takes the composed route.
+#ifdef KOFFT_BLUE_STFT_UNIT
+int stft_bluestein_dev(kofft_hip_ctx *ctx, const float *d_signal, size_t len, const float *d_window, size_t n, size_t start0, size_t hop,
+                       float *d_out, size_t count, bool *done)
+{
+    using T = float;
+    *done = false;
+    if (!(ctx->blue_fused && ctx->blue_one_kernel && ctx->blue_persist) || is_pow2(n) || n < 3) return KOFFT_OK;
+    size_t m = 1;
+    while (m < 2 * n - 1) m <<= 1;
+    const int L = ilog2(m);
+    if (L < 5 || L > 13) return KOFFT_OK;
+    const cpx<T> *chirp = nullptr, *bfft = nullptr, *tw = nullptr;
+    int rc = get_bluestein<T>(ctx, n, m, &chirp, &bfft);
+    if (rc) return rc;
+    rc = get_table<T>(ctx, Kind<T>::tw, m, &tw);
+    if (rc) return rc;
+    const T sm = (T)1 / (T)(float)m, sn = (T)1 / (T)(float)n;
+    const BlueStftSrc src{d_signal, d_window, len, hop, start0, (int)n};
+    cpx<T> *dst = reinterpret_cast<cpx<T> *>(d_out);
+    switch (L) {
+#define KOFFT_CASE(LL)                                                                                                  \
+    case LL:                                                                                                            \
+        if (!blue_persist_pays<T, LL>(ctx, count)) return KOFFT_OK;                                                     \
+        rc = launch_bluestein_persist_src<T, LL, false>(ctx, src, dst, chirp, bfft, tw, n, count, sm, sn);              \
+        break;
+        KOFFT_CASE(5)
+        KOFFT_CASE(6)
+        KOFFT_CASE(7)
+        KOFFT_CASE(8)
+        KOFFT_CASE(9)
+        KOFFT_CASE(10)
+        KOFFT_CASE(11)
+        KOFFT_CASE(12)
+        KOFFT_CASE(13)
+#undef KOFFT_CASE
+    default: return KOFFT_OK;
+    }
+    if (rc) return rc;
+    *done = true;
+    return KOFFT_OK;
+}
+#endif
 
 template <typename T, bool INVERSE>
 int fft_bluestein_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t batch)

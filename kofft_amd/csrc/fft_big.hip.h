@@ -1095,8 +1095,47 @@ __global__ __launch_bounds__(BLOCK) void bluestein_wg_kernel(const cpx<T> *__res
 // loads), the next transform's input is in flight while this one is computed.  The chirp entries stay loads (coalesced, 8 KiB,
 // L1 hits): keeping them would cost 2 x R more registers and the second wavefront per SIMD.
 // Same butterflies, same table entries, same pointwise expressions: bit-identical to bluestein_wg_kernel.
-template <typename T, int L, int RL, int BLOCK, int WG_PER_CU, bool INVERSE>
-__global__ __launch_bounds__(BLOCK, WG_PER_CU * BLOCK / 256 /* wavefronts per SIMD */) void bluestein_persist_kernel(const cpx<T> *__restrict__ in, cpx<T> *__restrict__ out,
+// Where the n input values of transform xf come from: rows of n complex values (fft / ifft), or STFT frames of a real signal
+// (stft.rs:91-103 for a window length that is not a power of two: frame[i] = (signal[start + i] * window[i], 0), zeros past the end --
+// what stft_frame_kernel writes out for the composed route, here on this kernel's loads: one pass over HBM instead of three).
+template <typename T, bool INVERSE>
+struct BlueRowsSrc {
+    using Raw = cpx<T>;
+    const cpx<T> *__restrict__ in;
+    int n;
+    size_t batch;
+    __device__ __forceinline__ Raw fetch(size_t xf, int i) const
+    {
+        const size_t xc = xf < batch ? xf : batch - 1;  // past the end: a valid address, the values are never stored
+        return ld_stream(in + xc * (size_t)n + (i < n ? i : n - 1));
+    }
+    __device__ __forceinline__ cpx<T> finish(Raw x, size_t, int) const
+    {
+        if (INVERSE) x.im = -x.im;  // ifft: conj on the way in (fft.rs:1163-1165)
+        return x;
+    }
+};
+struct BlueStftSrc {
+    using Raw = float;
+    const float *__restrict__ signal;
+    const float *__restrict__ window;
+    size_t len, hop, start0;
+    int n;
+    __device__ __forceinline__ Raw fetch(size_t xf, int i) const
+    {
+        const size_t pos = start0 + xf * hop + (size_t)(i < n ? i : n - 1);
+        return pos < len ? signal[pos] : 0.0f;
+    }
+    __device__ __forceinline__ cpx<float> finish(Raw x, size_t xf, int i) const
+    {
+        const int ic = i < n ? i : n - 1;
+        const bool in = start0 + xf * hop + (size_t)ic < len;
+        return mk<float>(in ? x * window[ic] : 0.0f, 0.0f);  // stft.rs:95-100
+    }
+};
+
+template <typename T, int L, int RL, int BLOCK, int WG_PER_CU, bool INVERSE, class SRC = BlueRowsSrc<T, INVERSE>>
+__global__ __launch_bounds__(BLOCK, WG_PER_CU * BLOCK / 256 /* wavefronts per SIMD */) void bluestein_persist_kernel(const SRC src, cpx<T> *__restrict__ out,
                                                                                         const cpx<T> *__restrict__ chirp,
                                                                                         const cpx<T> *__restrict__ bfft,
                                                                                         const cpx<T> *__restrict__ tw, const int n, const T scale_m,
@@ -1137,14 +1176,10 @@ __global__ __launch_bounds__(BLOCK, WG_PER_CU * BLOCK / 256 /* wavefronts per SI
     // every n of this m -- half of the loads, chirp entries and stores are decided at compile time (RH registers of input in flight)
     constexpr int RH = R / 2;
     static_assert(G0::in_index(0, RH) == N / 2, "pass 0: the register number is the index's top bits");
-    auto fetch = [&](cpx<T> *raw, size_t xf) {
-        const size_t xc = xf < batch ? xf : batch - 1;  // past the end: a valid address, the values are never stored
-        const cpx<T> *row = in + xc * (size_t)n;
+    using Raw = typename SRC::Raw;
+    auto fetch = [&](Raw *raw, size_t xf) {
 #pragma unroll
-        for (int u = 0; u < RH; ++u) {
-            const int i = G0::in_index(tau, u);
-            raw[u] = ld_stream(row + (i < n ? i : n - 1));
-        }
+        for (int u = 0; u < RH; ++u) raw[u] = src.fetch(xf, G0::in_index(tau, u));
     };
     auto transform = [&](cpx<T> *v, auto &&before_last) {  // before_last(): table loads that ride under the last pass's butterflies
         persist_compute_p0<T, L, RL>(v, tw);
@@ -1174,7 +1209,7 @@ __global__ __launch_bounds__(BLOCK, WG_PER_CU * BLOCK / 256 /* wavefronts per SI
 
     const size_t stride = (size_t)gridDim.x * XPB;
     size_t xf = (size_t)blockIdx.x * XPB + slot;
-    cpx<T> raw[RH];
+    Raw raw[RH];
     fetch(raw, xf);
     for (size_t base = (size_t)blockIdx.x * XPB; base < batch; base += stride, xf += stride) {
         // the table addresses below depend on the thread only: left visible, the compiler hoists the LOADS out of the transform loop
@@ -1185,8 +1220,7 @@ __global__ __launch_bounds__(BLOCK, WG_PER_CU * BLOCK / 256 /* wavefronts per SI
 #pragma unroll
         for (int u = 0; u < RH; ++u) {
             const int i = G0::in_index(tau_t, u);
-            cpx<T> x = raw[u];
-            if (INVERSE) x.im = -x.im;  // ifft: conj on the way in (fft.rs:1163-1165)
+            const cpx<T> x = src.finish(raw[u], xf, i);
             const cpx<T> a = cmul(x, chirp[i < n ? i : n - 1]);
             v[u] = i < n ? a : mk<T>(T(0), T(0));
         }

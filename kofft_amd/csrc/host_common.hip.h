@@ -664,6 +664,8 @@ template <typename T>
 int rfft_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, const T *d_window, size_t n, size_t batch);  // k_real_f32/f64.hip
 template <typename T>
 int irfft_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t batch);
+int stft_bluestein_dev(kofft_hip_ctx *ctx, const float *d_signal, size_t len, const float *d_window, size_t n, size_t start0, size_t hop,
+                       float *d_out, size_t count, bool *done);  // k_complex_f32.hip (complex_impl.hip.h)
 int stft_dev(kofft_hip_ctx *ctx, const float *d_signal, size_t len, const float *d_window, size_t win_len, size_t start0,
              size_t hop, float *d_out, size_t count);  // k_stft.hip
 int istft_dev(kofft_hip_ctx *ctx, float *d_frames, size_t frames, const float *d_window, size_t win_len, size_t hop,

@@ -1,4 +1,5 @@
 // k_complex_f32.hip -- Complex<float> transforms (fft.rs:1054-1174): every kernel instance of the family.
+#define KOFFT_BLUE_STFT_UNIT 1  // stft_bluestein_dev (float only) is defined in this translation unit
 #include "complex_impl.hip.h"
 
 namespace kofft {

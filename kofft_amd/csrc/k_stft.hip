@@ -65,7 +65,13 @@ int stft_dev(kofft_hip_ctx *ctx, const float *d_signal, size_t len, const float 
     if (!complex_len_ok(win_len)) return KOFFT_ERR_UNSUPPORTED;
     if (!ctx || (!d_signal && len) || !d_window || !d_out) return KOFFT_ERR_NULL;
     KOFFT_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (!fused_len_ok<float>(win_len)) return stft_composed_dev(ctx, d_signal, len, d_window, win_len, start0, hop, d_out, count);
+    if (!fused_len_ok<float>(win_len)) {
+        // a window that is not a power of two and enough frames: the framing product on the persistent Bluestein kernel's loads
+        bool done = false;
+        const int rc = stft_bluestein_dev(ctx, d_signal, len, d_window, win_len, start0, hop, d_out, count, &done);
+        if (rc || done) return rc;
+        return stft_composed_dev(ctx, d_signal, len, d_window, win_len, start0, hop, d_out, count);
+    }
     StftIO io{{}, d_signal, d_window, reinterpret_cast<cpx<float> *>(d_out), len, hop, start0, (int)win_len};
     return dispatch<float, EPI_STORE>(ctx, io, win_len, count);
 }

@@ -680,6 +680,28 @@ def test_istft_matches_oracle(fft32, oracle, win_len, hop, length):
         assert np.max(np.abs(out[ok] - signal[ok])) < 1e-3
 
 
+@pytest.mark.parametrize("win_len,hop,frames", [(12, 5, 300_000), (30, 10, 150_000), (60, 20, 90_000), (100, 40, 60_000), (400, 160, 20_001),
+                                                (500, 125, 14_003), (1000, 250, 5_001), (1102, 441, 2_600), (2500, 625, 1_100)])
+def test_stft_window_not_a_power_of_two_large_frame_counts(oracle, monkeypatch, win_len, hop, frames):
+    """stft.rs:91-103 calls fft.fft(frame) for ANY window length: lengths that are not powers of two take the Bluestein arm.  With enough
+    frames the framing product rides on the persistent Bluestein kernel's loads (BlueStftSrc: one pass over HBM; the composed route writes
+    the frames out, then transforms them in place).  Frames that run off the end of the signal included; head, middle and tail against the
+    oracle, EVERY frame against the composed route (KOFFT_HIP_BLUESTEIN_PERSIST=0)."""
+    import kofft_amd
+
+    rng = seeded(2600 + win_len)
+    total = (frames - 3) * hop + win_len // 3  # the last frames are partly / wholly past the end
+    sig = rng.uniform(-1, 1, total).astype(np.float32)
+    win = rng.uniform(0.1, 1, win_len).astype(np.float32)
+    f = kofft_amd.HipFftImpl(np.float32)
+    got = f.stft_into(sig, win, hop, frames, check_frames=False)
+    for first, count in ((0, 3), (frames // 2, 2), (frames - 5, 5)):
+        assert bits_equal(got[first:first + count], oracle.stft_range(sig, win, hop, first, count)), (first, count)
+    monkeypatch.setenv("KOFFT_HIP_BLUESTEIN_PERSIST", "0")
+    g = kofft_amd.HipFftImpl(np.float32)
+    assert bits_equal(got, g.stft_into(sig, win, hop, frames, check_frames=False))
+
+
 @pytest.mark.parametrize("win_len,hop,nframes,out_delta", [
     (1024, 256, 9001, 0), (1024, 256, 9003, 1500), (1024, 256, 9000, -777), (1024, 512, 9002, 300),
     (512, 256, 9001, 0), (2048, 512, 4101, 5), (2048, 1024, 4100, -3000), (4096, 1024, 2101, 0), (4096, 2048, 2100, 4097),
