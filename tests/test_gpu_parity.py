@@ -909,7 +909,7 @@ def test_bluestein_one_launch_and_two_launch_routes(oracle, one_kernel, monkeypa
 
 
 @pytest.mark.parametrize("dtype,n,batch", [
-    # batch >= CUs x workgroups per CU x transforms per workgroup x 4 (complex_impl.hip.h: blue_persist_pays), with room to spare
+    # batch >= CUs x workgroups per CU x transforms per workgroup (complex_impl.hip.h: blue_persist_pays), several rounds of the grid
     ("c32", 12, 300_000 + 37), ("c32", 30, 150_000 + 5), ("c32", 60, 90_000 + 21), ("c32", 100, 60_000 + 9), ("c32", 250, 20_000 + 3),
     ("c32", 500, 14_000 + 7), ("c32", 1000, 5_000 + 3), ("c32", 1024 + 1, 2_500 + 2), ("c32", 2000, 2_500 + 1),
     ("c32", 4095, 1_100 + 1),
