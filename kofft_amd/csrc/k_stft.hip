@@ -115,6 +115,7 @@ static int launch_istft_fused(kofft_hip_ctx *ctx, float *d_frames, size_t frames
     if (ctx->persist_grid_pct > 0) grid = grid * (size_t)ctx->persist_grid_pct / 100;
     if (grid < 1) grid = 1;
     const size_t fpw = ((steps + grid - 1) / grid) * XPB;  // frames per workgroup: whole steps
+    // (fewer than four steps per run: the two kernels are as fast or faster -- 1024 / 256 x 3000 frames 0.023 against 0.030 ms fused)
     if (fpw < 4 * XPB || fpw < (size_t)(2 * C)) return KOFFT_OK;
     const size_t runs = (frames + fpw - 1) / fpw;
     const cpx<float> *tw = nullptr;
