@@ -542,19 +542,24 @@ class Workload:
 
         src, dst = self._keep
         n, batch = self.cfg["n"], self.cfg["batch_per_gpu"]
-        torch.mul(src, 1e-18, out=dst)
-        for _ in range(2):
-            fft32.fft_dev(dst.data_ptr(), n, batch, False)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        for _ in range(steps):
-            fft32.fft_dev(dst.data_ptr(), n, batch, False)
-        e1.record(stream)
-        torch.cuda.synchronize(dev)
-        ms = e0.elapsed_time(e1) / steps
-        finite = bool(torch.isfinite(dst[:64]).all().item())
+        per_buffer, finite = [], True
+        # both of the headline's buffers in turn (this workload is done with them): where the driver placed a buffer moves every streaming
+        # kernel here by +-5-8 %; with both timed, a gap to the headline that shows on both is not one badly placed buffer
+        for buf in (dst, src):
+            torch.mul(src, 1e-18, out=buf)
+            for _ in range(2):
+                fft32.fft_dev(buf.data_ptr(), n, batch, False)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(steps):
+                fft32.fft_dev(buf.data_ptr(), n, batch, False)
+            e1.record(stream)
+            torch.cuda.synchronize(dev)
+            per_buffer.append(e0.elapsed_time(e1) / steps)
+            finite = finite and bool(torch.isfinite(buf[:64]).all().item())
+        ms = min(per_buffer)
         return {"inplace_ms_per_step": ms, "inplace_frac": self.alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "steps": steps,
-                "values_finite": finite}
+                "inplace_ms_per_buffer": {"second": per_buffer[0], "first": per_buffer[1]}, "values_finite": finite}
 
     def shard_kernel_ms(self, fft32, stream, dev, worlds=(1, 2, 4, 8), reps=200):
         """Kernel time of rank 0's frame shard for each world size, on THIS one GPU: what compute-only strong scaling of
