@@ -32,7 +32,7 @@ def main():
     ns = sorted({n for (_, n) in d})
     out = [f"# Size sweep `{name}` (tools/sweep.py, one box, ~512 MiB per launch)", "",
            "Fraction of the 8 TB/s HBM roofline from algorithmic bytes and HIP-event time (20 launches after 5 warm-ups); "
-           "box-to-box spread +-5 % (compare columns of ONE file only)." + (" " + note if note else ""), "",
+           "box-to-box spread +-5 % typically, up to 15-20 % seen in round 4 (STFT 1024: 0.57 on one box, 0.70-0.78 on others) -- compare columns of ONE file only." + (" " + note if note else ""), "",
            "| n | " + " | ".join(KINDS) + " |", "|---|" + "---|" * len(KINDS)]
     for n in ns:
         cells = []
