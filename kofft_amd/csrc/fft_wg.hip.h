@@ -67,6 +67,9 @@ struct PlainTw {
 #ifndef KOFFT_C64_SMALL_BLOCK
 #define KOFFT_C64_SMALL_BLOCK 64
 #endif
+#ifndef KOFFT_C_LOAD_AUX
+#define KOFFT_C_LOAD_AUX AUX_NT  // cache policy of the complex kernels' descriptor loads (A/B hook: tools/exp_inplace_ab.py)
+#endif
 // FftImpl::fft (fft.rs:1054) / ifft (fft.rs:1134-1174: conj, fft, conj, *scale).
 template <typename T, bool INVERSE>
 struct ComplexIO : PlainTw {
@@ -112,7 +115,7 @@ struct ComplexIO : PlainTw {
     }
     __device__ __forceinline__ Raw fetch_d(rsrc_t d, int lane_bytes, int iu, int row_off = 0) const
     {
-        return buf_load_cpx<T, AUX_NT>(d, row_off + lane_bytes, iu * (int)sizeof(cpx<T>));
+        return buf_load_cpx<T, KOFFT_C_LOAD_AUX>(d, row_off + lane_bytes, iu * (int)sizeof(cpx<T>));
     }
     __device__ __forceinline__ void store_d(rsrc_t d, int lane_bytes, int ou, cpx<T> v, int row_off = 0) const
     {

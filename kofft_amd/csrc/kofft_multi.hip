@@ -41,6 +41,14 @@
 #include <thread>
 #include <vector>
 
+// (see kNcclFloat32 below)
+#if defined(__has_include)
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#define KOFFT_HAVE_RCCL_HEADER 1
+#endif
+#endif
+
 namespace {
 
 // ---- RCCL, bound lazily ------------------------------------------------------------------------------------------
@@ -55,7 +63,14 @@ struct Rccl {
     const char *(*GetErrorString)(int) = nullptr;
     std::string error;
 };
-constexpr int kNcclFloat32 = 7;  // ncclFloat32 (rccl.h: ncclDataType_t)
+// ncclFloat32 of ncclDataType_t: taken from RCCL's own header when the build machine has it (only the enumerator -- the
+// functions stay dlsym-bound so that the library loads, and everything but the exchange works, without RCCL installed).
+#ifdef KOFFT_HAVE_RCCL_HEADER
+constexpr int kNcclFloat32 = (int)ncclFloat32;
+static_assert((int)ncclFloat32 == 7, "ncclFloat32 moved: the header-less build's literal below must follow");
+#else
+constexpr int kNcclFloat32 = 7;  // ncclFloat32 (rccl.h: ncclDataType_t) -- header absent at build time
+#endif
 
 void rccl_bind(Rccl &r);
 Rccl &rccl()
@@ -386,8 +401,9 @@ int ensure_peers(kofft_hip_multi *m)
 {
     if (m->peers_up) return KOFFT_OK;
     const int G = m->ngpu;
-    m->peer_stream.assign((size_t)G * G, nullptr);
-    m->peer_done.assign((size_t)G * G, nullptr);
+    // restartable: a call that failed part-way left its streams / events in the vectors; only the missing ones are created
+    if (m->peer_stream.size() != (size_t)G * G) m->peer_stream.assign((size_t)G * G, nullptr);
+    if (m->peer_done.size() != (size_t)G * G) m->peer_done.assign((size_t)G * G, nullptr);
     for (int r = 0; r < G; ++r) {
         KOFFT_MULTI_TRY(m, hipSetDevice(m->devices[r]));
         for (int p = 0; p < G; ++p) {
@@ -396,8 +412,10 @@ int ensure_peers(kofft_hip_multi *m)
                 const hipError_t e = hipDeviceEnablePeerAccess(m->devices[p], 0);
                 if (e != hipSuccess) (void)hipGetLastError();  // already enabled, or no direct path: the copy is then staged by the runtime
             }
-            KOFFT_MULTI_TRY(m, hipStreamCreateWithFlags(&m->peer_stream[(size_t)r * G + p], hipStreamNonBlocking));
-            KOFFT_MULTI_TRY(m, hipEventCreateWithFlags(&m->peer_done[(size_t)r * G + p], hipEventDisableTiming));
+            if (!m->peer_stream[(size_t)r * G + p])
+                KOFFT_MULTI_TRY(m, hipStreamCreateWithFlags(&m->peer_stream[(size_t)r * G + p], hipStreamNonBlocking));
+            if (!m->peer_done[(size_t)r * G + p])
+                KOFFT_MULTI_TRY(m, hipEventCreateWithFlags(&m->peer_done[(size_t)r * G + p], hipEventDisableTiming));
         }
     }
     m->peers_up = true;
@@ -416,6 +434,11 @@ int gather_direct(kofft_hip_multi *m, float *const *base, size_t per_floats)
             if (p == r) continue;
             hipStream_t ps = m->peer_stream[(size_t)r * G + p];
             KOFFT_MULTI_TRY(m, hipStreamWaitEvent(ps, m->ev[2][r], 0));  // behind r's kernels (and the zero fill of a short slot)
+            // ... and behind whatever the caller had queued on the DESTINATION's stream when this call began (ev[1][p] is recorded on
+            // stream[p] before p's kernels): a consumer of the previous call's gathered buffer ordered on stream[p] -- the stream
+            // kofft_hip_multi_context hands out for exactly that -- must have finished reading slot r before it is overwritten.
+            // The RCCL form runs the all-gather ON stream[p] and has this ordering by construction.
+            KOFFT_MULTI_TRY(m, hipStreamWaitEvent(ps, m->ev[1][p], 0));
             KOFFT_MULTI_TRY(m, hipMemcpyPeerAsync(base[p] + (size_t)r * per_floats, m->devices[p], base[r] + (size_t)r * per_floats,
                                                   m->devices[r], bytes, ps));
             KOFFT_MULTI_TRY(m, hipEventRecord(m->peer_done[(size_t)r * G + p], ps));

@@ -80,6 +80,7 @@ def test_dry_protocol_eight_ranks_one_line_with_every_workload_key():
         assert key in line, key
     assert line["n_gpus"] == 8 and line["WORLD_SIZE"] == "8" and line["launcher"] == "self"
     assert list(line["workloads"]) == ["stft1024", "rfft2048", "c64_2p20"]
+    assert "multi_single_process" in line  # rank 0's single-process RCCL-vs-direct gather A/B of config #4 (N > 1 only)
     # one rank: the SURVEY 8(f) rows ride along
     res1 = _run(["--dry-launch", "--dry-protocol"], timeout=300)
     assert res1.returncode == 0, res1.stderr[-2000:]
