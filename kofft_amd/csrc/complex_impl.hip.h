@@ -248,7 +248,7 @@ template <typename T>
 int fft_axis2_dev(kofft_hip_ctx *ctx, T *d_data, int LT, int I, size_t blocks, int inverse)
 {
     // 2^12 = 2^7 x 2^5, 2^13 = 2^7 x 2^6, 2^14 = 2^7 x 2^7: the first pass on the persistent prefetching tile kernel (4096 x 4096 c32,
-    // same box: transposes 0.224 ms, 2^5 x 2^7 0.169-0.173, 2^6 x 2^6 0.178, 2^7 x 2^5 0.149; KOFFT_HIP_ND_TWO_PASS_L1 overrides: A/B)
+    // same box: transposes 0.224 ms, 2^5 x 2^7 0.169-0.173, 2^6 x 2^6 0.178, 2^7 x 2^5 0.149)
     int L1 = LT >= 12 ? 7 : LT - 5;  // (2^11 = 2^6 x 2^5, 2^10 = 2^5 x 2^5)
     if (ctx->nd_two_pass_l1 >= 5 && ctx->nd_two_pass_l1 <= 8 && LT - ctx->nd_two_pass_l1 >= 5 && LT - ctx->nd_two_pass_l1 <= 8) L1 = ctx->nd_two_pass_l1;
     if (L1 < 5 || L1 > 8 || LT - L1 < 5 || LT - L1 > 8) return KOFFT_ERR_UNSUPPORTED;
@@ -435,7 +435,7 @@ int fft_big_core(kofft_hip_ctx *ctx, const cpx<T> *in_base, size_t in_row, cpx<T
         b.nt_load = ctx->big_mid_nt >= 0 ? ctx->big_mid_nt != 0 : (nb * xf_bytes > (size_t(192) << 20) && load_piece >= 64);
         rc = KOFFT_ERR_UNSUPPORTED;
         // last factor: 2 = rows resident (table entries per row tile in LDS), 1 = the generic persistent tile kernel, 0 = one tile
-        // per workgroup (two 512-thread workgroups per CU at 128 registers); KOFFT_HIP_BIG_LAST_MODE for A/B measurements
+        // per workgroup (two 512-thread workgroups per CU at 128 registers) (big_last_mode: compile-time constant since round 4, no environment knob)
         if (rows_resident) {
             switch (L3) {
             case 7: rc = launch_rows_persist<T, 7>(ctx, b, tw, nb); break;

@@ -50,14 +50,14 @@ struct kofft_hip_ctx {
     bool big_persist = true;   // KOFFT_HIP_BIG_PERSIST=0: factors on the one-tile-per-workgroup kernel (A/B measurements)
     size_t big_persist_min_units = 32;  // KOFFT_HIP_BIG_PERSIST_MIN_UNITS: units (columns / rows) per CU from which the persistent factor kernels run
     int big_first_persist = -1;  // KOFFT_HIP_BIG_FIRST_PERSIST=0/1: first factor one tile per workgroup / persistent (default: big_persist)
-    int big_last_mode = -1;      // KOFFT_HIP_BIG_LAST_MODE=0/1/2: last factor one tile per workgroup / generic persistent / rows resident
+    int big_last_mode = -1;      // (compile-time only since round 4; no getenv) last factor one tile per workgroup / generic persistent / rows resident
     bool big_rows_resident = true;  // KOFFT_HIP_BIG_ROWS_RESIDENT=0: last factor on the generic tile kernel (A/B measurements)
-    int big_mid_nt = -1;       // KOFFT_HIP_BIG_MID_NT=0/1: force plain / streaming loads of the intermediate (default: by chunk size)
+    int big_mid_nt = -1;       // (compile-time only since round 4; no getenv) force plain / streaming loads of the intermediate (default: by chunk size)
     bool blue_fused = true;    // KOFFT_HIP_BLUESTEIN_FUSED=0: pointwise steps as separate kernels at every size
     bool blue_one_kernel = true;  // KOFFT_HIP_BLUESTEIN_ONE=0: two launches through a scratch even where one workgroup holds m points
     bool nd_transpose = true;  // KOFFT_HIP_ND_TRANSPOSE=0: long strided axes through the strided kernel
     bool nd_two_pass = true;   // KOFFT_HIP_ND_TWO_PASS=0: power-of-two axes of 4096 .. 16384 points through the transposes instead of two column-tile passes (A/B)
-    int nd_two_pass_l1 = 0;    // KOFFT_HIP_ND_TWO_PASS_L1: log2 of the first pass's sub-transform (default LT - 7)
+    int nd_two_pass_l1 = 0;    // (compile-time only since round 4; no getenv) log2 of the first pass's sub-transform (default LT - 7)
     int nd_transpose_min = 4096;  // KOFFT_HIP_ND_TRANSPOSE_MIN: shortest axis that takes the transpose route (measured: 1024 loses, 2048 ties)
     bool zero_copy = true;     // KOFFT_HIP_ZERO_COPY=0: small host calls through staged copies like large ones
     bool host_pipeline = true; // KOFFT_HIP_HOST_PIPELINE=0: host-pointer batches in one upload / kernel / download

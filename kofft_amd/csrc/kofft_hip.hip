@@ -595,6 +595,7 @@ int kofft_hip_release_scratch(kofft_hip_ctx *ctx)
         *bufs[i] = nullptr;
         *sizes[i] = 0;
     }
+    ctx->big_tmp_external = false;  // (KOFFT_EXP_API builds: the script's intermediate is forgotten, the next call allocates its own)
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     ctx->pinned = ctx->pinned_dev = nullptr;
     ctx->pinned_bytes = 0;

@@ -8,7 +8,9 @@ get_twiddles); every call goes to the C restatement, which cites the reference l
 from __future__ import annotations
 
 import ctypes as C
+import os
 import subprocess
+import threading
 from pathlib import Path
 
 import numpy as np
@@ -178,3 +180,84 @@ def stft_magnitudes(samples: np.ndarray, win_len: int, hop: int):
     mx = C.c_float(0.0)
     _chk(lib().ko_stft_magnitudes_f32(_p(sig), _SZ(sig.size), _SZ(int(win_len)), _SZ(int(hop)), _p(mags), C.byref(mx)))
     return mags, float(mx.value)
+
+
+# ---- threaded batch entries (full-size parity tests: EVERY transform of a BASELINE config against the oracle) ----------------
+# Each worker thread calls the plain C batch entry on its own contiguous block of the batch (one planner per call, nothing shared:
+# the C side has no global state); ctypes releases the GIL for the duration of the call.
+def host_threads() -> int:
+    """Cores this process may use: affinity mask, capped by the cgroup CPU quota."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()[:2]
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return cores
+
+
+def _run_blocks(total: int, threads: int | None, work) -> None:
+    """work(first, count) over `total` units split into contiguous blocks, one thread each; the first failure is re-raised."""
+    k = max(1, min(threads or host_threads(), total))
+    per = -(-total // k)
+    errs: list[BaseException] = []
+
+    def run(first):
+        try:
+            work(first, min(per, total - first))
+        except BaseException as e:  # noqa: BLE001 -- re-raised on the calling thread
+            errs.append(e)
+    ths = [threading.Thread(target=run, args=(f,)) for f in range(0, total, per)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    if errs:
+        raise errs[0]
+
+
+def fft_inplace_mt(a: np.ndarray, inverse: bool = False, threads: int | None = None) -> np.ndarray:
+    """ScalarFftImpl::fft / ifft on every row of the C-contiguous [batch, n] complex array `a`, IN PLACE (no copy), batch split over threads."""
+    s = _sfx(a.dtype)
+    assert a.ndim == 2 and a.flags.c_contiguous and a.dtype == _cdt(s)
+    batch, n = a.shape
+    fn = getattr(lib(), f"ko_fft_batch_{s}")
+    row = n * a.itemsize
+
+    def work(first, count):
+        _chk(fn(C.c_void_p(a.ctypes.data + first * row), _SZ(n), _SZ(count), int(bool(inverse))))
+    _run_blocks(batch, threads, work)
+    return a
+
+
+def rfft_mt(x: np.ndarray, window: np.ndarray | None = None, threads: int | None = None) -> np.ndarray:
+    """RfftPlanner::rfft_with_scratch on every row of the [batch, n] real array (optional window product first): [batch, n/2+1] complex."""
+    s = _sfx(x.dtype)
+    a = np.ascontiguousarray(x, _rdt(s))
+    assert a.ndim == 2
+    batch, n = a.shape
+    out = np.empty((batch, n // 2 + 1), _cdt(s))
+    w = None if window is None else np.ascontiguousarray(window, _rdt(s))
+    fn = getattr(lib(), f"ko_rfft_batch_{s}")
+
+    def work(first, count):
+        _chk(fn(C.c_void_p(a.ctypes.data + first * n * a.itemsize), C.c_void_p(out.ctypes.data + first * (n // 2 + 1) * out.itemsize),
+                _p(w), _SZ(n), _SZ(count)))
+    _run_blocks(batch, threads, work)
+    return out
+
+
+def stft_mt(signal: np.ndarray, window: np.ndarray, hop: int, frames: int, threads: int | None = None) -> np.ndarray:
+    """stft::stft (stft.rs:76-105), frame ranges split over threads (ko_stft_range_f32: the same arithmetic per frame)."""
+    sig = np.ascontiguousarray(signal, np.float32)
+    win = np.ascontiguousarray(window, np.float32)
+    out = np.zeros((frames, win.size), np.complex64)
+    if hop == 0 or frames < -(-sig.size // hop) or frames == 0 or win.size == 0:
+        return stft(sig, win, hop, frames)  # the error paths / empty cases: the serial entry decides
+
+    def work(first, count):
+        _chk(lib().ko_stft_range_f32(_p(sig), _SZ(sig.size), _p(win), _SZ(win.size), _SZ(hop),
+                                     C.c_void_p(out.ctypes.data + first * win.size * 8), _SZ(first), _SZ(count)))
+    _run_blocks(frames, threads, work)
+    return out

@@ -285,6 +285,56 @@ def test_multi_direct_gather_on_one_card(oracle, g):
     m.close()
 
 
+def test_direct_gather_waits_for_a_reader_on_the_destination_stream(oracle):
+    """ADVICE r4 (kofft_multi.hip, gather_direct): the peer copy r -> p must order behind work ALREADY QUEUED on the destination's
+    stream[p] -- the stream kofft_hip_multi_context hands to callers so that they can order consumers of the gathered buffer on it.
+    Two asynchronous device-form calls into the SAME output buffers; between them a slow reader (a long spin, then a snapshot copy of
+    the gathered buffer) queued on every stream[p].  The snapshots must hold the FIRST call's spectrogram on every logical device, the
+    buffers the SECOND call's.  Without the wait on ev[1][p] the second call's copies overwrite slot r while the reader still waits."""
+    import torch
+
+    import kofft_amd
+
+    g = 3
+    dev = torch.device("cuda", 0)
+    win = kofft_amd.hann(512)
+    hop = 128
+    sig_a = _signal(80_011, seed=5)
+    sig_b = _signal(80_011, seed=6)
+    frames = -(-sig_a.size // hop)
+    want_a = oracle.stft(sig_a, win, hop, frames)
+    want_b = oracle.stft(sig_b, win, hop, frames)
+    per = -(-frames // g)
+    m = kofft_amd.HipMulti(g, devices=[0] * g)
+    m.set_gather("direct")
+    dw = torch.from_numpy(win).to(dev)
+    sl_a, sl_b, outs, snaps = [], [], [], []
+    for r in range(g):
+        first, count = m.stft_slice(sig_a.size, 512, hop, frames, r)
+        sl_a.append(torch.from_numpy(sig_a[first:first + count].copy()).to(dev))
+        sl_b.append(torch.from_numpy(sig_b[first:first + count].copy()).to(dev))
+        outs.append(torch.full((g * per, 512, 2), 7.0, dtype=torch.float32, device=dev))
+        snaps.append(torch.zeros((g * per, 512, 2), dtype=torch.float32, device=dev))
+    torch.cuda.synchronize(dev)
+    optr = [t_.data_ptr() for t_ in outs]
+    m.stft_dev([t_.data_ptr() for t_ in sl_a], sig_a.size, [dw.data_ptr()] * g, 512, hop, frames, allgather=True, d_out=optr)
+    for p in range(g):  # the consumer of call 1's gathered buffer, ordered on stream[p]; on device 0 behind ~30 ms of spinning
+        _, st = m.context(p)
+        with torch.cuda.stream(torch.cuda.ExternalStream(st, device=dev)):
+            if p == 0:  # ONE slow destination: its peers' kernels of call 2 finish long before this reader does
+                torch.cuda._sleep(60_000_000)
+            snaps[p].copy_(outs[p])
+    m.stft_dev([t_.data_ptr() for t_ in sl_b], sig_b.size, [dw.data_ptr()] * g, 512, hop, frames, allgather=True, d_out=optr)
+    m.synchronize()
+    torch.cuda.synchronize(dev)
+    for p in range(g):
+        snap = snaps[p].cpu().numpy().view(np.complex64).reshape(g * per, 512)
+        assert bits_equal(snap[:frames], want_a), f"logical device {p}: the reader saw slots of the NEXT call"
+        have = outs[p].cpu().numpy().view(np.complex64).reshape(g * per, 512)
+        assert bits_equal(have[:frames], want_b), f"logical device {p}: second call's gathered spectrogram differs"
+    m.close()
+
+
 def test_multi_gather_mode_from_the_environment(monkeypatch):
     import kofft_amd
 

@@ -1391,10 +1391,9 @@ def test_large_n_batches_around_the_tile_width_steps(fft32, fft64, oracle, dtype
 @pytest.mark.parametrize("batch", [1024, 1283])
 def test_n16384_wave_split_kernels(fft32, oracle, batch):
     """n = 16384.  Default: fft_split_wide_persist_kernel (512 threads, 32 points each, a wavefront owns 2048 points = 128-byte
-    runs both ways; one LDS buffer, two barriers, pass B1's 31 table entries resident in registers).  KOFFT_HIP_SPLIT14=1:
-    fft_split1_persist_kernel (1024 threads, 16 points each).  KOFFT_HIP_SPLIT=0: the generic kernel.  Complex forward / inverse,
-    STFT and magnitudes with a 16384-sample window, all three routes against the oracle bit for bit; workgroups with 4, 5 and
-    6 transforms."""
+    runs both ways; one LDS buffer, two barriers, pass B1's 31 table entries resident in registers).  KOFFT_HIP_SPLIT=0: the
+    generic kernel.  Complex forward / inverse, STFT and magnitudes with a 16384-sample window, both routes against the oracle
+    bit for bit; workgroups with 4, 5 and 6 transforms."""
     import os
 
     import kofft_amd
@@ -1407,7 +1406,7 @@ def test_n16384_wave_split_kernels(fft32, oracle, batch):
     frames = -(-sig.size // 4096)
     want_stft = oracle.stft(sig, w, 4096, frames)
     wm, wmx = oracle.stft_magnitudes(sig, 16384, 4096)
-    for knob, val in (("KOFFT_HIP_SPLIT14", "2"), ("KOFFT_HIP_SPLIT14", "1"), ("KOFFT_HIP_SPLIT", "0")):
+    for knob, val in (("KOFFT_HIP_SPLIT", "1"), ("KOFFT_HIP_SPLIT", "0")):  # the default route, then the generic kernel
         os.environ[knob] = val
         try:
             f = kofft_amd.HipFftImpl(np.float32)

@@ -1,9 +1,8 @@
-#!/usr/bin/env python3
 """Config 5's last factor: variants of the kernel on IDENTICAL buffers (the mode depends on the physical placement of the
 intermediate and the output, so variants can only be compared on one (src, mid, dst) triple).  Libraries built with
 -DKOFFT_EXP_API take the intermediate from this script (kofft_hip_exp_set_big_tmp).  The base library is first run on
 --tries freshly allocated (mid, dst) pairs to find a slow and a fast placement; then every variant runs on both.
-Run under `rocprofv3 --kernel-trace`, parse with `exp_c64_ctx.py --parse`.
+Run as `rocprofv3 --kernel-trace ... -- python3 tools/exp_c64_ab.py ...` (python3 itself after `--`: no env / shebang hop), parse with `exp_c64_ctx.py --parse`.
 
 usage (GPU box): python3 tools/exp_c64_ab.py base=kofft_amd/lib/libkofft_hip.so st16=kofft_amd/lib_st16/libkofft_hip.so ..."""
 import argparse

@@ -1,10 +1,9 @@
-#!/usr/bin/env python3
 """Config 5: the last factor's fast / slow mode follows the INTERMEDIATE's placement (exp_c64_ab.py: fast mid + slow dst = fast).
 How does one get a fast intermediate?  Times the two factor kernels (32 transforms per call) with the intermediate taken from
   torch      separate 512 MiB torch allocations (hipMalloc underneath)
   contig     hipExtMallocWithFlags(hipDeviceMallocContiguous) of 512 MiB
   window     512 MiB windows (2 MiB-aligned offsets) of ONE large allocation (plain and contiguous)
-Library built with -DKOFFT_EXP_API.  Run under `rocprofv3 --kernel-trace`, parse with `exp_c64_ctx.py --parse`."""
+Library built with -DKOFFT_EXP_API.  Run as `rocprofv3 --kernel-trace ... -- python3 tools/exp_c64_alloc.py ...` (python3 itself after `--`: no env / shebang hop), parse with `exp_c64_ctx.py --parse`."""
 import argparse
 import ctypes as C
 import json

@@ -1,9 +1,8 @@
-#!/usr/bin/env python3
 """The block-interleaved c64 intermediate (KOFFT_HIP_BIG_BLOCKED) against the natural layout on IDENTICAL buffers: two contexts of one
 -DKOFFT_EXP_API build (one created with KOFFT_HIP_BIG_BLOCKED=0), the same input, output and intermediate handed to both, over
 --pairs freshly allocated (intermediate, output) pairs -- the placement of the intermediate decides a +-8 % mode, so
 runs in two processes or two contexts with their own scratch cannot tell the layouts apart.
-Run under `rocprofv3 --kernel-trace`, parse with `exp_c64_ctx.py --parse`.
+Run as `rocprofv3 --kernel-trace ... -- python3 tools/exp_c64_blocked.py ...` (python3 itself after `--`: no env / shebang hop), parse with `exp_c64_ctx.py --parse`.
 usage (GPU box): python3 tools/exp_c64_blocked.py --lib kofft_amd/lib_exp/libkofft_hip.so [--log2n 20] [--batch 32]"""
 import argparse
 import ctypes as C

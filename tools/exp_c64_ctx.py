@@ -1,8 +1,7 @@
-#!/usr/bin/env python3
 """Config 5's last factor: fast / slow mode per ALLOCATION of the intermediate (exp_c64_shift.py: the mode follows the context,
 i.e. the hipMalloc of the 512 MiB scratch, not the byte shift).  Creates --contexts contexts (each with its own scratch, all kept
 alive so that every one gets different physical memory), times one 32-transform chunk per call through each, then runs a second
-round of calls per context (the one a --pmc pass is read for).  Run under rocprofv3 (--kernel-trace [--pmc ...]);
+round of calls per context (the one a --pmc pass is read for).  Run as `rocprofv3 --kernel-trace [--pmc ...] -- python3 tools/exp_c64_ctx.py ...` (python3 itself after `--`);
 `--parse <kernel_trace.csv> [--counters <counter_collection.csv>]` prints per-context kernel times and counter means.
 
 usage (GPU box): python3 tools/exp_c64_ctx.py [--contexts 12] [--out gpurun_out/exp3/cells.json]"""

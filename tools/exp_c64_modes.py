@@ -1,11 +1,10 @@
-#!/usr/bin/env python3
 """Config 5's fast / slow modes, round 2 of the hunt (see exp_c64_ctx.py): what decides the mode?
   realloc   ONE context, its scratch released and re-allocated --reps times with dummy allocations in between (so the
             intermediate moves while the twiddle table stays): does the mode follow the intermediate?
   env:K=V,K=V   --contexts fresh contexts created under these environment knobs (e.g. KOFFT_HIP_BIG_CHUNK_MB=128,
-            KOFFT_HIP_BIG_MID_NT=0), each timed on `batch` transforms per call
+            a -DKOFFT_EXP_API build with big_mid_nt forced to 0; the environment knob was removed in round 4), each timed on `batch` transforms per call
   dst       one context, the OUTPUT buffer re-allocated --reps times
-Run under `rocprofv3 --kernel-trace`, parse with `exp_c64_ctx.py --parse`.
+Run as `rocprofv3 --kernel-trace ... -- python3 tools/exp_c64_modes.py ...` (python3 itself after `--`: no env / shebang hop), parse with `exp_c64_ctx.py --parse`.
 
 usage (GPU box): python3 tools/exp_c64_modes.py realloc env: env:KOFFT_HIP_BIG_CHUNK_MB=128 dst [--batch 32]"""
 import argparse

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Config 5 (1024 x 2^20 c64): what is the LAST factor kernel sensitive to?  (192 <-> 221 us per 512 MiB chunk
 between boxes / runs with the first factor constant at 183 us.)  One process, several builds of the library side by side
 (ctypes, one context each), cells:
@@ -6,7 +5,7 @@ between boxes / runs with the first factor constant at 183 us.)  One process, se
   B  the same buffers through every build given with --libs (name=path; e.g. round 2's build, store-policy / mapping variants)
   C  one 512 MiB chunk (32 transforms) per call at different positions of the output buffer
   D  one chunk per call with the output shifted by a few hundred bytes .. 64 KiB
-Run it under `rocprofv3 --kernel-trace` and feed the trace to --parse to get the two factor kernels apart: every cell prints the
+Run it as `rocprofv3 --kernel-trace ... -- python3 tools/exp_c64_place.py ...` (python3 itself after `--`) and feed the trace to --parse to get the two factor kernels apart: every cell prints the
 number of library kernel dispatches it made, the parser walks the trace in dispatch order.
 
 usage (GPU box): python3 tools/exp_c64_place.py --libs head=kofft_amd/lib/libkofft_hip.so r02=kofft_amd/lib_r02/libkofft_hip.so ...
