@@ -520,7 +520,7 @@ class Workload:
                 state["inv"] = not state["inv"]
             self.launch = launch2d
             self.cfg = {"workload": WORKLOADS[name], "rows": rows, "cols": cols, "direction": "forward / inverse alternating, in place",
-                        "passes_over_hbm": "rows: 1; columns: see DESIGN 5.7"}
+                        "passes_over_hbm": "2: rows + the columns' first two stages, then one column-tile pass (DESIGN 5.7)"}
             self.dtype, self.scaling, self.kernels_per_step = "f32", "weak", None
             self._keep = (img,)
             return

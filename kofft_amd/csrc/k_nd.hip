@@ -94,6 +94,10 @@ int fft_nd_dev(kofft_hip_ctx *ctx, T *d_data, size_t depth, size_t rows, size_t 
         return fft_dev<T>(ctx, d_data, d_data, cols, depth * rows, inverse);
     }
     // 2-D (ndfft.rs:89-98): rows first, then columns
+    if constexpr (sizeof(T) == 4) {
+        // c32, rows of 1024 .. 4096 points, 1024 .. 4096 of them: rows + the columns' first two stages fused, then ONE column-tile pass
+        if (fft2d_fused_ok(ctx, rows, cols)) return fft2d_fused_c32(ctx, reinterpret_cast<float *>(d_data), rows, cols, inverse);
+    }
     rc = fft_dev<T>(ctx, d_data, d_data, cols, rows, inverse);
     if (rc) return rc;
     return fft_axis_dev<T>(ctx, d_data, rows, cols, cols, 0, cols, inverse);

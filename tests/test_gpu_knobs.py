@@ -160,6 +160,10 @@ def case_nd_two_pass(oracle):  # power-of-two line counts: two column-tile passe
     _nd(oracle, "c32", 1, 2048, 1024, 143)
 
 
+def case_nd_fused(oracle):  # 4096-point rows: rows + two column stages fused by default, rows then two column-tile passes here
+    _nd(oracle, "c32", 1, 1024, 4096, 144)
+
+
 def case_bluestein(oracle):
     _complex(oracle, "c32", 1000, 700, 151)      # one launch by default
     _complex(oracle, "c32", 12345, 40, 152)      # fused into the transforms' loads / stores by default
@@ -220,6 +224,7 @@ KNOBS = [
     ("KOFFT_HIP_ZERO_COPY", "0", case_zero_copy),
     ("KOFFT_HIP_ND_TRANSPOSE", "0", case_nd_transpose),
     ("KOFFT_HIP_ND_TWO_PASS", "0", case_nd_two_pass),
+    ("KOFFT_HIP_ND_FUSED", "0", case_nd_fused),
     ("KOFFT_HIP_BLUESTEIN_FUSED", "0", case_bluestein),
     ("KOFFT_HIP_BLUESTEIN_ONE", "0", case_bluestein),
     ("KOFFT_HIP_BLUESTEIN_PERSIST", "0", case_bluestein_persist),

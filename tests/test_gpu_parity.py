@@ -826,6 +826,36 @@ def test_fft2d_matches_oracle(fft32, oracle, rows, cols):
     assert_parity(data.reshape(rows, cols), back, f"ifft2d {rows}x{cols}", REL_TOL_F32)
 
 
+@pytest.mark.parametrize("rows,cols", [(1024, 4096), (2048, 4096), (4096, 4096), (1024, 1024), (2048, 1024), (4096, 1024), (1024, 2048),
+                                       (2048, 2048), (4096, 2048), (512, 4096)])
+def test_fft2d_fused_two_passes(fft32, oracle, rows, cols):
+    """Round 5 (fft_nd_fused.hip.h): c32 images with rows of 1024 / 2048 / 4096 points and 1024 .. 4096 rows -- the row transforms and
+    the columns' first two Stockham stages in one pass (four rows per workgroup step), the remaining column stages as one column-tile
+    pass with the frequency prefix K = 2 bits (512 rows: below one group per CU, the three-pass route).  Forward and inverse, EVERY
+    value against the oracle's rows-then-columns (ndfft.rs:89-98) bit for bit; an impulse image with its exact answer (ndfft.rs tests)."""
+    rng = seeded(5200 + rows + 3 * cols)
+    x = rand_c(rng, (rows, cols))
+    x[3, 5] = 0  # (a few exact zeros and a large value: sign-of-zero and cancellation paths)
+    x[rows - 1, cols - 1] = 1e6
+
+    def axis(a, ax, inverse=False):
+        moved = np.moveaxis(a, ax, -1).copy(order="C")  # (a copy even when the axis is already last: the oracle works in place)
+        oracle.fft_inplace_mt(moved, inverse=inverse)
+        return np.ascontiguousarray(np.moveaxis(moved, -1, ax))
+    want = axis(axis(x, 1), 0)
+    data = x.reshape(-1).copy()
+    fft32.fftnd(data, 1, rows, cols)
+    assert bits_equal(data.reshape(rows, cols), want), f"fft2d {rows}x{cols}"
+    fft32.fftnd(data, 1, rows, cols, inverse=True)
+    back = axis(axis(want, 1, True), 0, True)
+    assert bits_equal(data.reshape(rows, cols), back), f"ifft2d {rows}x{cols}"
+    imp = np.zeros((rows, cols), np.complex64)
+    imp[0, 0] = 2.5 - 1.0j
+    d2 = imp.reshape(-1).copy()
+    fft32.fftnd(d2, 1, rows, cols)
+    assert np.all(d2 == np.complex64(2.5 - 1.0j))
+
+
 @pytest.mark.parametrize("depth,rows,cols", [(2, 2, 2), (4, 8, 16), (16, 32, 64), (64, 4, 256)])
 def test_fft3d_matches_oracle(fft32, fft64, oracle, depth, rows, cols):
     """ndfft::fft3d_inplace (ndfft.rs:114-155): z, then y, then x."""
