@@ -250,6 +250,14 @@ __device__ __forceinline__ void persist_transform(const typename persist_raw<IO,
             if constexpr (CFG::kInvInLds) cur[u] = io.finish_in(raw[u], (st.inv_lds + tau)[FirstG::in_index(0, u)]);
             else cur[u] = io.finish_in(raw[u], st.inv[u]);
         }
+    } else if constexpr (io_frame_rem<IO>::value) {
+        const int rem = io.frame_rem(xf);  // the frame's existing samples, worked out once
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const int i = FirstG::in_index(0, u) + tau;
+            if constexpr (CFG::kInvInLds) cur[u] = io.finish_rem(i, raw[u], (st.inv_lds + tau)[FirstG::in_index(0, u)], rem);
+            else cur[u] = io.finish_rem(i, raw[u], st.inv[u], rem);
+        }
     } else {
 #pragma unroll
         for (int u = 0; u < R; ++u) {
@@ -373,7 +381,10 @@ __device__ __forceinline__ void persist_transform(const typename persist_raw<IO,
             const int row_off = sub * (int)io.out_row_bytes();
 #pragma unroll
             for (int u = 0; u < R; ++u) {
-                if constexpr (io_has_acc<IO>::value) io.store_d_acc(od, lane_bytes, LastG::out_index(0, u), cur[u], row_off, acc);
+                if constexpr (io_half_spectrum<IO>::value) {
+                    static_assert((LastG::out_index(0, 1) % TPT) == 0 && TPT <= N / 2, "register part and thread part of the index: disjoint bit fields");
+                    if (LastG::out_index(0, u) < N / 2) io.store_d_acc_kept(od, lane_bytes, LastG::out_index(0, u), cur[u], row_off, acc);  // (a constant per u)
+                } else if constexpr (io_has_acc<IO>::value) io.store_d_acc(od, lane_bytes, LastG::out_index(0, u), cur[u], row_off, acc);
                 else io.store_d(od, lane_bytes, LastG::out_index(0, u), cur[u], row_off);
             }
         }

@@ -31,6 +31,16 @@ template <class IO, class = void>
 struct io_has_acc { static constexpr bool value = false; };
 template <class IO>
 struct io_has_acc<IO, decltype((void)IO::kHasAcc)> { static constexpr bool value = IO::kHasAcc; };
+// policies whose range test can be hoisted out of the per-sample loop (StftIO and its heirs: frame_rem / finish_rem)
+template <class IO, class = void>
+struct io_frame_rem { static constexpr bool value = false; };
+template <class IO>
+struct io_frame_rem<IO, decltype((void)IO::kFrameRem)> { static constexpr bool value = IO::kFrameRem; };
+// policies that keep bins 0 .. n/2-1 only and offer store_d_acc_kept (StftMagIO)
+template <class IO, class = void>
+struct io_half_spectrum { static constexpr bool value = false; };
+template <class IO>
+struct io_half_spectrum<IO, decltype((void)IO::kHalfSpectrum)> { static constexpr bool value = IO::kHalfSpectrum; };
 
 // A policy whose input value k needs row elements k AND m - k (irfft) can get the second one from the lane that loaded it
 // instead of loading it again, when a transform's threads share a wavefront: io_pairs_in_wave<IO> (see IrfftIO).
@@ -228,6 +238,19 @@ struct StftIO : PlainTw {
     {
         return mk<float>(in_range(xf, i) ? x * w : 0.0f, 0.0f);  // past the end: exactly +0, whatever the window holds
     }
+    // The same test with the frame's sample count worked out ONCE (round 5): rem = samples of frame xf that exist, 0 .. n; sample i is
+    // in range iff i < rem -- one 32-bit compare per sample instead of a 64-bit add and compare (and their registers) per sample.
+    static constexpr bool kFrameRem = true;
+    __device__ __forceinline__ int frame_rem(size_t xf) const
+    {
+        const size_t start = start0 + xf * hop;
+        const size_t avail = start < len ? len - start : 0;
+        return (int)(avail < (size_t)n ? avail : (size_t)n);
+    }
+    __device__ __forceinline__ cpx<float> finish_rem(int i, Raw x, Inv w, int rem) const
+    {
+        return mk<float>(i < rem ? x * w : 0.0f, 0.0f);  // past the end: exactly +0, whatever the window holds
+    }
     // a frame that lies wholly inside the signal needs no per-sample range test (4 VALU instructions per sample)
     __device__ __forceinline__ bool inside(size_t xf) const { return start0 + xf * hop + (size_t)n <= len; }
     __device__ __forceinline__ cpx<float> finish_in(Raw x, Inv w) const { return mk<float>(x * w, 0.0f); }
@@ -279,6 +302,17 @@ struct StftMagIO : StftIO {
             buf_store_f32(m, d, row_off + (lane_bytes >> 1), ou * 4);
             if (m > acc) acc = m;
         }
+    }
+    // The same store where the CALLER has decided, at compile time, that bin ou + tau is below n/2 (round 5, fft_persist.hip.h: the
+    // register part ou of the last pass's output index and the thread part tau are disjoint bit fields, so ou + tau < n/2 <=> ou < n/2,
+    // a constant per register): no range test per store -- 16 runtime branches less per transform -- and the discarded half of the last
+    // stage's butterflies is dead code.
+    static constexpr bool kHalfSpectrum = true;
+    __device__ __forceinline__ void store_d_acc_kept(rsrc_t d, int lane_bytes, int ou, cpx<float> v, int row_off, Acc &acc) const
+    {
+        const float m = mag(v);
+        buf_store_f32(m, d, row_off + (lane_bytes >> 1), ou * 4);
+        if (m > acc) acc = m;
     }
     __device__ __forceinline__ rsrc_t out_desc_n(size_t xf0, int cnt) const
     {
