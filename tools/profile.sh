@@ -12,12 +12,12 @@ mkdir -p $OUT
 # provenance of the counters: the kernel sources and the library that actually ran, recorded NOW (summarize_profile.py copies these)
 python3 -c "import bench, hashlib, json; print(json.dumps({'csrc_sha16': bench.csrc_sha16(), 'lib_sha16': hashlib.sha256(open('kofft_amd/lib/libkofft_hip.so','rb').read()).hexdigest()[:16]}))" > $OUT/provenance.json
 cd $PWD
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-cpu-baseline --no-extra-workloads --min-seconds 0 "$@" > $OUT/trace_bench.log 2>&1
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-cpu-baseline --no-extra-workloads --no-twin --min-seconds 0 "$@" > $OUT/trace_bench.log 2>&1
 echo "trace rc=$?" >> $OUT/trace_bench.log
-timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --no-cpu-baseline --no-extra-workloads --min-seconds 0 --steps 3 --warmup 1 "$@" > $OUT/pmc_fetch.log 2>&1
+timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --no-cpu-baseline --no-extra-workloads --no-twin --min-seconds 0 --steps 3 --warmup 1 "$@" > $OUT/pmc_fetch.log 2>&1
 echo "fetch rc=$?" >> $OUT/pmc_fetch.log
-timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --no-cpu-baseline --no-extra-workloads --min-seconds 0 --steps 3 --warmup 1 "$@" > $OUT/pmc_write.log 2>&1
+timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --no-cpu-baseline --no-extra-workloads --no-twin --min-seconds 0 --steps 3 --warmup 1 "$@" > $OUT/pmc_write.log 2>&1
 echo "write rc=$?" >> $OUT/pmc_write.log
-timeout -k 10 600 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU --output-format csv -d $OUT/pmc_sq -- python3 bench.py --no-cpu-baseline --no-extra-workloads --min-seconds 0 --steps 3 --warmup 1 "$@" > $OUT/pmc_sq.log 2>&1
+timeout -k 10 600 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU --output-format csv -d $OUT/pmc_sq -- python3 bench.py --no-cpu-baseline --no-extra-workloads --no-twin --min-seconds 0 --steps 3 --warmup 1 "$@" > $OUT/pmc_sq.log 2>&1
 echo "sq rc=$?" >> $OUT/pmc_sq.log
 find $OUT -name "*.csv" | head -50
