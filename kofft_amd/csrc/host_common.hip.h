@@ -56,7 +56,6 @@ struct kofft_hip_ctx {
     bool blue_fused = true;    // KOFFT_HIP_BLUESTEIN_FUSED=0: pointwise steps as separate kernels at every size
     bool blue_one_kernel = true;  // KOFFT_HIP_BLUESTEIN_ONE=0: two launches through a scratch even where one workgroup holds m points
     bool nd_transpose = true;  // KOFFT_HIP_ND_TRANSPOSE=0: long strided axes through the strided kernel
-    bool rfft_big_fused = true;  // KOFFT_HIP_RFFT_BIG_FUSED=0: rfft32 of 2^17 .. 2^22 reals through three passes (factor, factor, post-pass kernel) instead of two (A/B)
     bool nd_fused = true;      // KOFFT_HIP_ND_FUSED=0: 2-D c32 images with 1024 .. 4096-point rows through rows + two column-tile passes instead of the fused two passes (A/B)
     bool nd_two_pass = true;   // KOFFT_HIP_ND_TWO_PASS=0: power-of-two axes of 4096 .. 16384 points through the transposes instead of two column-tile passes (A/B)
     int nd_two_pass_l1 = 0;    // (compile-time only since round 4; no getenv) log2 of the first pass's sub-transform (default LT - 7)
@@ -658,8 +657,6 @@ template <typename T>
 int fft_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t batch, int inverse);  // k_complex_f32/f64.hip
 template <typename T>
 int fft_axis2_dev(kofft_hip_ctx *ctx, T *d_data, int LT, int I, size_t blocks, int inverse);  // k_complex_f32/f64.hip: ndfft's long axes in two passes
-bool rfft_big_fused_ok(const kofft_hip_ctx *ctx, size_t m, size_t batch);                       // k_real_big.hip: inner lengths / batches the two-pass rfft32 route takes
-int rfft_big_fused_f32(kofft_hip_ctx *ctx, const float *d_in, float *d_out, const float *d_window, size_t m, size_t batch);  // ... first factor (+ window), last factor + post-pass
 bool fft2d_fused_ok(const kofft_hip_ctx *ctx, size_t rows, size_t cols);                      // k_nd_fused.hip: shapes the two-pass 2-D route takes
 int fft2d_fused_c32(kofft_hip_ctx *ctx, float *d_data, size_t rows, size_t cols, int inverse);  // ... rows + 2 column stages, then one column-tile pass
 template <typename T>

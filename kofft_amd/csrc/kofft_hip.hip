@@ -502,7 +502,6 @@ int kofft_hip_create(int device, kofft_hip_ctx **out)
     if (const char *e = getenv("KOFFT_HIP_BIG_FIRST11")) ctx->big_first11 = !(e[0] == '0');
     if (const char *e = getenv("KOFFT_HIP_ND_TWO_PASS")) ctx->nd_two_pass = !(e[0] == '0');
     if (const char *e = getenv("KOFFT_HIP_ND_FUSED")) ctx->nd_fused = !(e[0] == '0');
-    if (const char *e = getenv("KOFFT_HIP_RFFT_BIG_FUSED")) ctx->rfft_big_fused = !(e[0] == '0');
     if (const char *e = getenv("KOFFT_HIP_BIG_ROW_PAIRS")) ctx->big_row_pairs = !(e[0] == '0');
     if (const char *e = getenv("KOFFT_HIP_BIG_BLOCKED")) ctx->big_blocked = !(e[0] == '0');
     if (const char *e = getenv("KOFFT_HIP_BIG_CHUNK_MB")) {

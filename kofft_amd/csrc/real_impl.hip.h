@@ -112,10 +112,9 @@ template <typename T>
 int rfft_composed_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, const T *d_window, size_t n, size_t batch)
 {
     const size_t m = n / 2;
-    if constexpr (sizeof(T) == 4) {
-        // m = 2^16 .. 2^21, batches that give every workgroup of the last factor a transform: two passes (k_real_big.hip, round 5)
-        if (rfft_big_fused_ok(ctx, m, batch)) return rfft_big_fused_f32(ctx, d_in, d_out, d_window, m, batch);
-    }
+    // (Round 5: the last factor on mirrored tile PAIRS -- rows K and 2^LA - K in one workgroup -- with the post-pass in its epilogue, two
+    // passes instead of three, was built, bit-exact on every row, and measured SLOWER: 527-678 us for the fused kernel against 185-210 us
+    // (last factor on row pairs) + 217 us (post-pass kernel) at n = 2^17 .. 2^20; commit 2191bc6 has it, DESIGN 9 the numbers.)
     const cpx<T> *rtab = nullptr;
     int rc = get_table<T>(ctx, Kind<T>::rt, m, &rtab);
     if (rc) return rc;

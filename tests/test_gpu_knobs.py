@@ -160,15 +160,6 @@ def case_nd_two_pass(oracle):  # power-of-two line counts: two column-tile passe
     _nd(oracle, "c32", 1, 2048, 1024, 143)
 
 
-def case_rfft_big_fused(oracle):  # rfft of 2^17 reals: two passes by default, three (factor, factor, post-pass kernel) here
-    import kofft_amd
-
-    f = kofft_amd.HipFftImpl(np.float32)
-    x = seeded(145).uniform(-1, 1, (40, 1 << 17)).astype(np.float32)
-    win = oracle.hann(1 << 17)
-    assert bits_equal(f.rfft_batch(x, win), oracle.rfft(x, win))
-
-
 def case_nd_fused(oracle):  # 4096-point rows: rows + two column stages fused by default, rows then two column-tile passes here
     _nd(oracle, "c32", 1, 1024, 4096, 144)
 
@@ -234,7 +225,6 @@ KNOBS = [
     ("KOFFT_HIP_ND_TRANSPOSE", "0", case_nd_transpose),
     ("KOFFT_HIP_ND_TWO_PASS", "0", case_nd_two_pass),
     ("KOFFT_HIP_ND_FUSED", "0", case_nd_fused),
-    ("KOFFT_HIP_RFFT_BIG_FUSED", "0", case_rfft_big_fused),
     ("KOFFT_HIP_BLUESTEIN_FUSED", "0", case_bluestein),
     ("KOFFT_HIP_BLUESTEIN_ONE", "0", case_bluestein),
     ("KOFFT_HIP_BLUESTEIN_PERSIST", "0", case_bluestein_persist),
