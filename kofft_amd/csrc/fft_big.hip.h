@@ -296,7 +296,8 @@ struct AxisLastIO {
     static constexpr bool kTileInvariantTw = false;
     static constexpr bool kTileGroupTw = true;
     int tpg = 1;
-    __device__ __forceinline__ bool nt_in() const { return true; }
+    bool nt_load = true;  // streaming loads of the intermediate; off (round 5) where it is meant to be served by the Infinity Cache
+    __device__ __forceinline__ bool nt_in() const { return nt_load; }
     __device__ __forceinline__ T out_scale() const { return scale; }
     __device__ __forceinline__ size_t xf_transform(size_t xf) const { return xf >> (S + JB); }
     __device__ __forceinline__ unsigned in_off(size_t xf) const

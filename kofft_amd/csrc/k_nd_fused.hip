@@ -38,6 +38,8 @@ int fft2d_fused_core(kofft_hip_ctx *ctx, cpx<float> *data, int LT)
     }
     const int S = 2, LS = LT - S;
     AxisLastIO<float, INVERSE> m{mid, data, S, LS, LC, LT - LS, LT - 1 - S, elems, 1.0f / (float)rows};
+    // (plain against streaming loads of the intermediate measured equal on 16 .. 128 MiB images, round 5; the factor path's rule)
+    m.nt_load = elems * sizeof(cpx<float>) > (size_t(192) << 20);
     const size_t units = size_t(1) << (S + LC);
     switch (LS) {
 #define KOFFT_CASE(LL) \
