@@ -164,3 +164,71 @@ def test_two_contexts_in_two_threads(oracle):
     b = threading.Thread(target=worker, args=(42, [(4096, 130), (12, 700), (1 << 15, 9), (512, 900)]))
     a.start(); b.start(); a.join(); b.join()
     assert not errors, errors
+
+
+def test_bench_two_rank_rehearsal_carries_the_single_process_gather_ab():
+    """bench.py's N > 1 line on a one-GPU box: `--gpus 2 --rehearse-one-card` runs the whole two-rank protocol with
+    both ranks on cuda:0 (gloo process group: NOT a measurement) and, after the per-rank part, rank 0 alone drives config #4 through
+    the single-process multi-device handle over two logical devices -- the line must carry `multi_single_process` with the direct
+    gather's time, the check that every device holds the same gathered spectrogram, and every BASELINE config in roofline.configs."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    res = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--rehearse-one-card", "--steps", "3", "--warmup", "1",
+                          "--min-seconds", "0", "--ramp-ms", "20", "--no-cpu-baseline", "--detail-file", "/tmp/kofft_bench_rehearsal_detail.json"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert len(lines[0]) < 6000  # the driver's tail buffer keeps the whole line
+    assert line["n_gpus"] == 2 and "rehearsal" in line
+    ab = line["multi_single_process"]
+    assert ab["devices"] == 2 and ab["logical_devices_on_one_card"] is True, ab
+    assert ab["gather_direct_ms"] > 0 and ab["kernel_ms"] > 0 and ab["gathered_identical_on_every_device"] is True, ab
+    cfgs = line["roofline"]["configs"]
+    assert {"#2_inplace", "#2_oop", "#3", "#4", "#5"} <= set(cfgs), sorted(cfgs)
+    assert cfgs["#5"]["cap"] == 0.5 and "allgather_ms" in cfgs["#4"]
+    assert line["config"]["form"].startswith("in place") and line["values_finite"] is True
+
+
+def test_bench_single_rank_line_is_compact_and_complete():
+    """The N = 1 line: one JSON line below the driver's tail buffer, the in-place form as the headline with its
+    out-of-place twin beside it, and every BASELINE config and SURVEY 8(f) row summarised inside `roofline.configs`."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    res = subprocess.run([sys.executable, str(root / "bench.py"), "--steps", "3", "--warmup", "1", "--min-seconds", "0", "--ramp-ms", "20",
+                          "--cpu-seconds", "1", "--detail-file", "/tmp/kofft_bench_n1_detail.json"], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < 6000, len(lines[0])
+    line = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["unit"] == "GPoints/s" and line["dtype"] == "f32" and line["steps"] == 3 and line["n_gpus"] == 1
+    assert line["config"]["form"].startswith("in place") and line["values_finite"] is True
+    rf = line["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-6
+    cfgs = rf["configs"]
+    assert list(cfgs)[:2] == ["#2_inplace", "#2_oop"]
+    assert {"#3", "#4", "#5", "f1", "f2", "f3", "f4"} <= set(cfgs), sorted(cfgs)
+    for k, c in cfgs.items():
+        assert "error" not in c and 0.0 < c["frac"] < 1.0 and c["ms"] > 0, (k, c)
+    assert cfgs["#5"]["cap"] == 0.5
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] >= 1
+    for v in line.values():  # the driver truncates long strings: keep every one short
+        if isinstance(v, str):
+            assert len(v) <= 120, v
