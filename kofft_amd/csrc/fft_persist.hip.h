@@ -375,18 +375,26 @@ __device__ __forceinline__ void persist_transform(const typename persist_raw<IO,
         }
         if (NBUF == 2) exchange_sync<WAVE>();  // ybuf is the next transform's first exchange buffer
     } else {
-        if (active) {
-            const rsrc_t od = io.out_desc_n(xf0, cnt);
-            const int lane_bytes = tau * (int)sizeof(cpx<T>);
-            const int row_off = sub * (int)io.out_row_bytes();
+        // NO branch around the stores (round 5).  The descriptor covers exactly the cnt valid transforms of the group (EMPTY when there is
+        // none), so a lane without a transform -- sub >= cnt: its row offset lies beyond the descriptor -- stores into the bounds check and
+        // nothing else.  With `if (active)` here the compiler could not know at the loop head whether the previous transform's R stores had
+        // been issued: vmcnt counts loads and stores in issue order, so it assumed they had not and waited for them to COMPLETE before the
+        // current transform's inputs could be used -- `s_waitcnt vmcnt(23 .. 16)` in the n = 4096 kernel where vmcnt(47 .. 32) is enough,
+        // vmcnt(15 .. 0) in the n = 1024 STFT kernel: every step began by draining its predecessor's stores.
+        (void)active;
+        const rsrc_t od = io.out_desc_n(xf0, cnt);
+        const int lane_bytes = tau * (int)sizeof(cpx<T>);
+        const int row_off = sub * (int)io.out_row_bytes();
+#ifdef KOFFT_PERSIST_ACTIVE_BRANCH /* measurement only (tools/build_variant.sh): rounds 1-4's branch around the stores, for same-box A/Bs */
+        if (active)
+#endif
 #pragma unroll
-            for (int u = 0; u < R; ++u) {
-                if constexpr (io_half_spectrum<IO>::value) {
-                    static_assert((LastG::out_index(0, 1) % TPT) == 0 && TPT <= N / 2, "register part and thread part of the index: disjoint bit fields");
-                    if (LastG::out_index(0, u) < N / 2) io.store_d_acc_kept(od, lane_bytes, LastG::out_index(0, u), cur[u], row_off, acc);  // (a constant per u)
-                } else if constexpr (io_has_acc<IO>::value) io.store_d_acc(od, lane_bytes, LastG::out_index(0, u), cur[u], row_off, acc);
-                else io.store_d(od, lane_bytes, LastG::out_index(0, u), cur[u], row_off);
-            }
+        for (int u = 0; u < R; ++u) {
+            if constexpr (io_half_spectrum<IO>::value) {
+                static_assert((LastG::out_index(0, 1) % TPT) == 0 && TPT <= N / 2, "register part and thread part of the index: disjoint bit fields");
+                if (LastG::out_index(0, u) < N / 2) io.store_d_acc_kept(od, lane_bytes, LastG::out_index(0, u), cur[u], row_off, acc);  // (a constant per u)
+            } else if constexpr (io_has_acc<IO>::value) io.store_d_acc(od, lane_bytes, LastG::out_index(0, u), cur[u], row_off, acc);
+            else io.store_d(od, lane_bytes, LastG::out_index(0, u), cur[u], row_off);
         }
     }
 }
