@@ -285,7 +285,10 @@ template <bool INV> struct PersistCfg<12, ComplexIO<double, INV>> {
     static constexpr int BLOCK = 256, NBUF = 1, RL = 4, MINW = 2, WG_PER_CU = 2;
     static constexpr bool kInvInLds = false, kTwLastInLds = false, kTwGlobal = true;
 };
-template <class IO> struct PersistCfg<12, IO> : PersistCfgBase<IO> { static constexpr int BLOCK = 256, MINW = 2, WG_PER_CU = 2; };
+#ifndef KOFFT_C12_DEPTH
+#define KOFFT_C12_DEPTH 1  // (round 5 A/B: two transforms ahead for the n = 4096 kernels -- three register sets, 166 VGPRs)
+#endif
+template <class IO> struct PersistCfg<12, IO> : PersistCfgBase<IO> { static constexpr int BLOCK = 256, MINW = 2, WG_PER_CU = 2, DEPTH = KOFFT_C12_DEPTH; };
 template <class IO> struct PersistCfg<11, IO> : PersistCfgBase<IO> { static constexpr int BLOCK = 256, MINW = 2, WG_PER_CU = 2; };
 template <class IO> struct PersistCfg<10, IO> : PersistCfgBase<IO> {
     static constexpr int BLOCK = 256, MINW = IO::kLeanRegisters ? 3 : 2, WG_PER_CU = MINW;
