@@ -475,8 +475,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 1024 ? 4 : 2)) void fft_tile_persi
 
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int tid = threadIdx.x;
-    const int tau = tid / XPB;
-    const int slot = tid % XPB;
+    const int tau_launch = tid / XPB, slot_launch = tid % XPB;
+    const int tau = tau_launch, slot = slot_launch;
 
     constexpr bool GROUPED = io_tile_group_tw<IO>::value;
     size_t tpg = 1;
@@ -565,6 +565,12 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 1024 ? 4 : 2)) void fft_tile_persi
     // sequence the compiler does not pad, and one that stored the NEXT tile's values from a few lanes about once in
     // ten launches on gfx950.)
     auto run_tile = [&](cpx<T> *cur, const size_t t, const bool do_store) {
+        // 1024-thread instances (128 registers per thread): opaque copies of the thread's coordinates, taken per tile.  Every LDS base
+        // of the exchanges and the thread part of the store offset depend on the thread only, so the compiler computes them once and
+        // keeps them for the whole launch -- a handful of registers the kernel does not have: 3 .. 7 of them were spilled, and every
+        // reload from scratch is a vector-memory load whose s_waitcnt also waits for the prefetched next tile (round 5).
+        int tau = tau_launch, slot = slot_launch;
+        if constexpr (BLOCK >= 1024) asm volatile("" : "+v"(tau), "+v"(slot));
         const size_t xf = t * XPB + slot;
         if (IO::kConjIn) {
 #pragma unroll
@@ -833,7 +839,11 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 1024 ? 4 : 2)) void fft_rows_persi
 #pragma unroll
         for (int g = 0; g < GRP; ++g) reg_pass_r<T, QL>(cur + g * (1 << QL), twl + g * ((1 << QL) - 1));
         const rsrc_t d = make_rsrc(io.out + (size_t)tb * out_row, out_bytes);
-        const int lane = (int)((tkt * XPB + slot + ((unsigned)tau << out_sl)) * (unsigned)ES);
+        int lane = (int)((tkt * XPB + slot + ((unsigned)tau << out_sl)) * (unsigned)ES);
+        // A folded pointwise factor reads its table at the store's own element index: with the row tile fixed per workgroup those R
+        // 64-bit addresses do not depend on the transform, the compiler keeps all of them for the whole launch (32 registers) and the
+        // kernel spilled 14 .. 28.  An opaque copy per transform: recomputed, a few VALU operations each (round 5).
+        if constexpr (io_post<IO>::value != 0) asm volatile("" : "+v"(lane));
         const T scale = io.out_scale();
         if (!do_store) return;
         // (offsets in the VGPR field: see fft_tile_persist_kernel)
