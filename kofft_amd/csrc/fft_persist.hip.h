@@ -349,6 +349,10 @@ __device__ __forceinline__ void persist_transform(const typename persist_raw<IO,
             // Lane tau of store g handles k = g*TPT + tau - a: every store instruction then covers whole lines (the
             // row-contiguous form touches 5 lines per 512-byte store, 2 of them partially; measured +8 % on config 3),
             // at the price of one extra, mostly empty, store (g = R) that also carries X[N].
+            // (Round 5: these stores keep their branches.  Without them -- every lane storing R + 1 times, the idle ones beyond the
+            // descriptor, their LDS reads clamped -- the compiler's waits relax from vmcnt(31 .. 16) to vmcnt(62), and config 3 runs
+            // 0.6 % SLOWER, 3.176 against 3.158 ms over three interleaved same-box runs: two more store instructions per transform in
+            // every lane cost more than the waits did.  The plain store epilogue below is the other way round.)
             constexpr int LINE = 128 / (int)sizeof(cpx<T>);
             const int a = io.row_misalign(xf) & (LINE - 1);
             const int k0 = tau - a;  // -15 .. TPT-1
