@@ -108,19 +108,26 @@ int kofft_hip_fft_c32_dev_oop(kofft_hip_ctx *ctx, const float *d_in, float *d_ou
 int kofft_hip_fft_c64_dev_oop(kofft_hip_ctx *ctx, const double *d_in, double *d_out, size_t n,
                               size_t batch, int inverse);
 
-/* ScalarFftImpl::fft_radix4 (fft.rs:1455-1548) byte for byte -- an OPT-IN compatibility arm.  kofft's
- * fft_with_strategy(.., FftStrategy::Radix4) (fft.rs:1356) runs it for powers of four, and from n = 16 its output is NOT
- * the DFT (its "bit-reversal for radix-4" loop, fft.rs:1462-1474, flips one bit per base-4 digit instead of reversing the
- * digits); every other entry point here, and the host mirrors' fft_with_strategy by default, return the true transform.
- * These four reproduce the reference's bytes for callers that depend on them (the mirrors call them when
- * KOFFT_HIP_RADIX4_COMPAT=1 or their radix4_compat flag is set): the swap loop as a gather through its net permutation,
- * butterfly4 in the reference's operation order, the three running-product twiddle sequences of every stage built on the
- * host with Complex::mul.  n not a power of four -> fft() (fft.rs:1457-1460; n == 0 -> EMPTY_INPUT); n > 2^20 ->
- * KOFFT_ERR_UNSUPPORTED.  Forward only, like the reference.  data: batch * n complex. */
+/* ScalarFftImpl::fft_radix4 (fft.rs:1455-1548) byte for byte.  kofft's fft_with_strategy(.., FftStrategy::Radix4)
+ * (fft.rs:1356) runs it for powers of four, and from n = 16 its output is NOT the DFT (its "bit-reversal for radix-4" loop,
+ * fft.rs:1462-1474, flips one bit per base-4 digit instead of reversing the digits).  A drop-in returns the reference's
+ * bytes: the host mirrors' fft_with_strategy(.., Radix4) calls these entries BY DEFAULT (round 6); their radix4_compat =
+ * false / KOFFT_HIP_RADIX4_COMPAT=0 opts out and gives the true transform for every strategy, like every other entry
+ * point here.  The swap loop runs as a gather through its net permutation, butterfly4 in the reference's operation order,
+ * the three running-product twiddle sequences of every stage built on the host with Complex::mul (O(n) host work and
+ * 12 / 20 bytes of device tables per point, once per (context, n)).  n not a power of four -> fft() (fft.rs:1457-1460;
+ * n == 0 -> EMPTY_INPUT); n > 2^26 -> KOFFT_ERR_UNSUPPORTED (the limit of kofft_hip_fft_*).  data: batch * n complex. */
 int kofft_hip_fft_radix4_c32(kofft_hip_ctx *ctx, float *data, size_t n, size_t batch);
 int kofft_hip_fft_radix4_c64(kofft_hip_ctx *ctx, double *data, size_t n, size_t batch);
 int kofft_hip_fft_radix4_c32_dev(kofft_hip_ctx *ctx, const float *d_in, float *d_out, size_t n, size_t batch);
 int kofft_hip_fft_radix4_c64_dev(kofft_hip_ctx *ctx, const double *d_in, double *d_out, size_t n, size_t batch);
+/* FftPlan::ifft with strategy Radix4 (fft.rs:2040-2055 -> 2037 -> 1356): `c.im = -c.im`, fft_radix4, `c.im = -c.im;
+ * c.re * scale; c.im * scale` with scale = 1 / (n as f32 -> T), the conjugations and the scale folded into the first
+ * gather and the last stage's store.  Lengths that are not a power of four: ifft()'s arithmetic (fft.rs:1163-1172). */
+int kofft_hip_ifft_radix4_c32(kofft_hip_ctx *ctx, float *data, size_t n, size_t batch);
+int kofft_hip_ifft_radix4_c64(kofft_hip_ctx *ctx, double *data, size_t n, size_t batch);
+int kofft_hip_ifft_radix4_c32_dev(kofft_hip_ctx *ctx, const float *d_in, float *d_out, size_t n, size_t batch);
+int kofft_hip_ifft_radix4_c64_dev(kofft_hip_ctx *ctx, const double *d_in, double *d_out, size_t n, size_t batch);
 
 /* FftImpl::fft_strided / ifft_strided (fft.rs:1175-1199, 1236-1260), host pointers:
  * gathers n = scratch_len elements data[i*stride], transforms, scatters back.

@@ -98,6 +98,7 @@ template <> struct Abi<float> {
     static int rfft_table(size_t m, float *o) { return kofft_hip_rfft_table_f32(m, o); }
     static int fftnd(kofft_hip_ctx *c, float *d, size_t dp, size_t r, size_t cl, int inv) { return kofft_hip_fftnd_c32(c, d, dp, r, cl, inv); }
     static int radix4(kofft_hip_ctx *c, float *d, size_t n, size_t b) { return kofft_hip_fft_radix4_c32(c, d, n, b); }
+    static int iradix4(kofft_hip_ctx *c, float *d, size_t n, size_t b) { return kofft_hip_ifft_radix4_c32(c, d, n, b); }
 };
 template <> struct Abi<double> {
     static int fft(kofft_hip_ctx *c, double *d, size_t n, size_t b, int inv) { return kofft_hip_fft_c64(c, d, n, b, inv); }
@@ -108,6 +109,7 @@ template <> struct Abi<double> {
     static int rfft_table(size_t m, double *o) { return kofft_hip_rfft_table_f64(m, o); }
     static int fftnd(kofft_hip_ctx *c, double *d, size_t dp, size_t r, size_t cl, int inv) { return kofft_hip_fftnd_c64(c, d, dp, r, cl, inv); }
     static int radix4(kofft_hip_ctx *c, double *d, size_t n, size_t b) { return kofft_hip_fft_radix4_c64(c, d, n, b); }
+    static int iradix4(kofft_hip_ctx *c, double *d, size_t n, size_t b) { return kofft_hip_ifft_radix4_c64(c, d, n, b); }
 };
 }  // namespace detail
 
@@ -172,11 +174,12 @@ public:
         int rc = kofft_hip_create(device, &ctx_);
         if (rc != 0) throw DeviceError(rc, "kofft_hip_create");
         const char *e = std::getenv("KOFFT_HIP_RADIX4_COMPAT");
-        radix4_compat = e && e[0] == '1';
+        radix4_compat = !(e && e[0] == '0');
     }
-    // fft_with_strategy(.., Radix4) reproduces the reference's fft_radix4 bytes (NOT a DFT from n = 16) instead of the true
-    // transform.  Off unless KOFFT_HIP_RADIX4_COMPAT=1 or set here.
-    bool radix4_compat = false;
+    // fft_with_strategy(.., Radix4) reproduces the reference's fft_radix4 bytes (fft.rs:1356, 1455-1548; NOT a DFT from
+    // n = 16): strict drop-in, ON by default since round 6.  KOFFT_HIP_RADIX4_COMPAT=0, or false here, opts out (the true
+    // transform for every strategy).
+    bool radix4_compat = true;
     static HipFftImpl default_() { return HipFftImpl(0); }
     ~HipFftImpl() override { if (ctx_) kofft_hip_destroy(ctx_); }
     HipFftImpl(const HipFftImpl &) = delete;
@@ -205,9 +208,9 @@ public:
     {
         return oop_strided(input, in_stride, output, out_stride, true);
     }
-    // fft.rs:1337-1363.  Every strategy runs the Stockham path.  Deliberate divergence: the reference's Radix4 arm
-    // (fft_radix4, fft.rs:1455-1548) is not a DFT from n = 16 (its digit-reversal loop is wrong);
-    // with radix4_compat the reference's bytes are reproduced instead (kofft_hip_fft_radix4_*).
+    // fft.rs:1337-1363.  Radix2 / SplitRadix / Auto run the Stockham path (fft and stockham_fft agree for n >= 2); Radix4
+    // runs fft_radix4 (fft.rs:1356) like the reference -- not a DFT from n = 16 (its digit-reversal loop is wrong; DESIGN.md
+    // section 1), but a drop-in returns the reference's bytes (kofft_hip_fft_radix4_*).  radix4_compat = false opts out.
     Result fft_with_strategy(std::vector<C> &input, FftStrategy strategy) const override
     {
         if (input.empty()) return Result::Err(FftError::EmptyInput);
@@ -217,6 +220,12 @@ public:
     }
     // ScalarFftImpl::fft_radix4 (fft.rs:1455-1548), the reference's bytes
     Result fft_radix4(std::vector<C> &input) const { return st(detail::Abi<T>::radix4(ctx_, fp(input), input.size(), 1)); }
+    // FftPlan::ifft's loop around that arm (fft.rs:2040-2055): conj, fft_radix4, conj * 1/(n as f32), on the device
+    Result ifft_radix4(std::vector<C> &input) const
+    {
+        if (input.empty()) return Result::Err(FftError::EmptyInput);
+        return st(detail::Abi<T>::iradix4(ctx_, fp(input), input.size(), 1));
+    }
 
     // RealFftImpl<T> blanket methods (rfft.rs:780-833); checks in rfft_direct's order (rfft.rs:433-443)
     Result rfft_with_scratch(std::vector<T> &input, std::vector<C> &output, std::vector<C> &scratch) const
@@ -312,7 +321,11 @@ public:
     }
 };
 
-// fft::FftPlan (fft.rs:1989-2094): a length and a strategy bound to an implementation; every arm is the device transform
+// fft::FftPlan (fft.rs:1989-2094): a length and a strategy bound to an implementation.  FftPlan::fft (fft.rs:2012-2038):
+// an f32 plan with strategy Radix2 / Radix4 takes the *_with_twiddles shortcut, and every *_with_twiddles is stockham_fft
+// (fft.rs:1645-1660) -- the Stockham transform, NOT fft_radix4; every other plan goes through fft_with_strategy, where
+// Radix4 means fft_radix4.  FftPlan::ifft (fft.rs:2040-2055) = conj, that same fft, conj * 1/(n as f32).  Not reproduced:
+// the reference's f32 Radix2 / Radix4 plan of length 1 panics (unreachable!() in stockham_fft, fft.rs:655-662); identity here.
 template <typename T>
 class FftPlan {
 public:
@@ -322,13 +335,15 @@ public:
     Result fft(std::vector<Complex<T>> &input) const
     {
         if (input.size() != n) return Result::Err(FftError::MismatchedLengths);
+        if (stockham_shortcut()) return n == 1 ? Result::Ok() : fft_.fft(input);
         return fft_.fft_with_strategy(input, strategy);
     }
-    Result ifft(std::vector<Complex<T>> &input) const  // conj, fft, conj, * 1/(n as f32): ifft's arithmetic
+    Result ifft(std::vector<Complex<T>> &input) const
     {
         if (input.size() != n) return Result::Err(FftError::MismatchedLengths);
-        if (n <= 1) return fft_.fft_with_strategy(input, strategy);
-        return fft_.ifft(input);
+        if (n <= 1) return fft(input);
+        if (strategy == FftStrategy::Radix4 && fft_.radix4_compat && !stockham_shortcut()) return fft_.ifft_radix4(input);
+        return fft_.ifft(input);  // conj, fft, conj, * 1/(n as f32): ifft's arithmetic
     }
     Result fft_out_of_place(const std::vector<Complex<T>> &input, std::vector<Complex<T>> &output) const
     {
@@ -344,6 +359,10 @@ public:
     }
 
 private:
+    bool stockham_shortcut() const  // fft.rs:2016-2035
+    {
+        return sizeof(T) == 4 && (strategy == FftStrategy::Radix2 || strategy == FftStrategy::Radix4);
+    }
     const HipFftImpl<T> &fft_;
 };
 

@@ -105,8 +105,9 @@ fn status(ctx: *const KofftHipCtx, rc: c_int) -> Result<(), FftError> {
 /// One device context per instance; `Send` but not `Sync`, like `ScalarFftImpl` (kofft fft.rs:589-605).
 pub struct HipFftImpl<T: Float> {
     ctx: *mut KofftHipCtx,
-    /// `fft_with_strategy(.., Radix4)` reproduces kofft's `fft_radix4` bytes (NOT a DFT from n = 16) instead of the true
-    /// transform.  Off unless `KOFFT_HIP_RADIX4_COMPAT=1` or set by the caller.
+    /// `fft_with_strategy(.., Radix4)` reproduces kofft's `fft_radix4` bytes (fft.rs:1356, 1455-1548; NOT a DFT from n = 16):
+    /// strict drop-in, ON by default.  `KOFFT_HIP_RADIX4_COMPAT=0`, or `false` set by the caller, opts out (the true
+    /// transform for every strategy).
     pub radix4_compat: bool,
     _t: PhantomData<T>,
 }
@@ -118,7 +119,7 @@ impl<T: Float> HipFftImpl<T> {
         let mut ctx = core::ptr::null_mut();
         let rc = unsafe { kofft_hip_create(device as c_int, &mut ctx) };
         assert!(rc == 0 && !ctx.is_null(), "kofft_hip_create failed: {rc}");
-        let radix4_compat = std::env::var("KOFFT_HIP_RADIX4_COMPAT").map_or(false, |v| v == "1");
+        let radix4_compat = std::env::var("KOFFT_HIP_RADIX4_COMPAT").map_or(true, |v| v != "0");
         Self { ctx, radix4_compat, _t: PhantomData }
     }
 }
@@ -180,9 +181,10 @@ macro_rules! impl_fft {
                 Ok(())
             }
             fn fft_with_strategy(&self, input: &mut [$cplx], strategy: FftStrategy) -> Result<(), FftError> {
-                // kofft fft.rs:1337-1363: every strategy runs the Stockham path here.  (The crate's own Radix4 arm,
-                // fft_radix4, is not a DFT from n = 16: its digit-reversal loop is wrong; this shim returns the correct
-                // transform unless `radix4_compat` asks for the crate's bytes.)
+                // kofft fft.rs:1337-1363: Radix2 / SplitRadix / Auto run the Stockham path (fft and stockham_fft agree for
+                // n >= 2); Radix4 runs the crate's fft_radix4 arm (fft.rs:1356) byte for byte -- not a DFT from n = 16 (its
+                // digit-reversal loop is wrong), but a drop-in returns what the crate returns.  `radix4_compat = false`
+                // opts out.
                 if input.is_empty() { return Err(FftError::EmptyInput); }
                 if input.len() == 1 { return Ok(()); }
                 if strategy == FftStrategy::Radix4 && self.radix4_compat { return self.fft_radix4(input); }

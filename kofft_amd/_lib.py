@@ -52,6 +52,10 @@ SIGNATURES = {
     "kofft_hip_fft_radix4_c64": (C.c_int, [_ctx, C.c_void_p, _sz, _sz]),
     "kofft_hip_fft_radix4_c32_dev": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, _sz, _sz]),
     "kofft_hip_fft_radix4_c64_dev": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, _sz, _sz]),
+    "kofft_hip_ifft_radix4_c32": (C.c_int, [_ctx, C.c_void_p, _sz, _sz]),
+    "kofft_hip_ifft_radix4_c64": (C.c_int, [_ctx, C.c_void_p, _sz, _sz]),
+    "kofft_hip_ifft_radix4_c32_dev": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, _sz, _sz]),
+    "kofft_hip_ifft_radix4_c64_dev": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, _sz, _sz]),
     "kofft_hip_fft_c32_strided": (C.c_int, [_ctx, C.c_void_p, _sz, _sz, _sz, C.c_int]),
     "kofft_hip_fft_c64_strided": (C.c_int, [_ctx, C.c_void_p, _sz, _sz, _sz, C.c_int]),
     "kofft_hip_rfft_f32": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p, _sz, _sz]),

@@ -819,24 +819,26 @@ int fft_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t batch,
 
 
 // ---------------------------------------------------------------------------------
-// ScalarFftImpl::fft_radix4 (fft.rs:1455-1548), the reference's bytes (opt-in: fft_radix4.hip.h)
+// ScalarFftImpl::fft_radix4 (fft.rs:1455-1548), the reference's bytes (fft_radix4.hip.h): what fft_with_strategy(.., Radix4)
+// runs (fft.rs:1356).  inverse = FftPlan::ifft's loop around that arm (fft.rs:2040-2055): conj, fft_radix4, conj * 1/n.
 // ---------------------------------------------------------------------------------
 template <typename T>
-int fft_radix4_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t batch)
+int fft_radix4_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t batch, int inverse)
 {
     if (batch == 0) return KOFFT_OK;
-    // fft.rs:1457-1460: anything but a power of four falls back to fft() (n == 0 -> EmptyInput there)
-    if (!is_pow2(n) || (ilog2(n) & 1)) return fft_dev<T>(ctx, d_in, d_out, n, batch, 0);
-    if (n > (size_t(1) << 20)) return KOFFT_ERR_UNSUPPORTED;  // (tables of n entries per context; the arm is a compatibility path)
+    // fft.rs:1457-1460: anything but a power of four falls back to fft() (n == 0 -> EmptyInput there); around it the plan's
+    // conj / conj * scale loop is ifft()'s arithmetic (fft.rs:1163-1172)
+    if (!is_pow2(n) || (ilog2(n) & 1)) return fft_dev<T>(ctx, d_in, d_out, n, batch, inverse);
+    if (n > (size_t(1) << max_log2_big<T>())) return KOFFT_ERR_UNSUPPORTED;  // the limit of fft_dev itself
     if (!ctx || !d_in || !d_out) return KOFFT_ERR_NULL;
     KOFFT_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const cpx<T> *in = reinterpret_cast<const cpx<T> *>(d_in);
     cpx<T> *out = reinterpret_cast<cpx<T> *>(d_out);
-    if (n == 1) {  // no swap, no stage
+    if (n == 1) {  // no swap, no stage; the plan's loop: im = -(-im), re * 1, im * 1 -- the value itself
         if (d_in != d_out) KOFFT_HIP_TRY(ctx, hipMemcpyAsync(d_out, d_in, batch * 2 * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
         return KOFFT_OK;
     }
-    // tables: (kind 9 / 10, n) = permutation, (11 / 12, n) = stage triples
+    // tables: (kind 9 / 10, n) = permutation, (11 / 12, n) = stage triples; O(n) host work once per (context, n)
     const int kp = sizeof(T) == 4 ? 9 : 10, kw = sizeof(T) == 4 ? 11 : 12;
     auto ip = ctx->tables.find(std::make_pair(kp, n));
     auto iw = ctx->tables.find(std::make_pair(kw, n));
@@ -864,11 +866,16 @@ int fft_radix4_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t
     }
     const unsigned *perm = static_cast<const unsigned *>(ip->second);
     const cpx<T> *w = static_cast<const cpx<T> *>(iw->second);
+    const T scale = (T)1 / (T)(float)n;  // fft.rs:2048
     auto grid = [](size_t quads) { return dim3((unsigned)((quads + 255) / 256)); };
+    auto first = [&](const cpx<T> *src, cpx<T> *dst, size_t quads) {
+        if (inverse) hipLaunchKernelGGL((radix4_first_kernel<T, true>), grid(quads), dim3(256), 0, ctx->stream, src, dst, perm, n, quads, scale);
+        else hipLaunchKernelGGL((radix4_first_kernel<T, false>), grid(quads), dim3(256), 0, ctx->stream, src, dst, perm, n, quads, scale);
+    };
     if (n == 4) {  // the permutation is the identity and every thread owns its quad: in place is safe
         const size_t quads = batch;
         if (quads > 0x7fffffffULL * 256) return KOFFT_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL(radix4_first_kernel<T>, grid(quads), dim3(256), 0, ctx->stream, in, out, perm, n, quads);
+        first(in, out, quads);
         KOFFT_HIP_TRY(ctx, hipGetLastError());
         return KOFFT_OK;
     }
@@ -881,12 +888,15 @@ int fft_radix4_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t
     cpx<T> *tmp = static_cast<cpx<T> *>(ctx->real_tmp);
     for (size_t b0 = 0; b0 < batch; b0 += chunk) {
         const size_t nb = (batch - b0 < chunk) ? batch - b0 : chunk, quads = nb * (n / 4);
-        hipLaunchKernelGGL(radix4_first_kernel<T>, grid(quads), dim3(256), 0, ctx->stream, in + b0 * n, tmp, perm, n, quads);
+        first(in + b0 * n, tmp, quads);
         KOFFT_HIP_TRY(ctx, hipGetLastError());
         size_t off = 0;
         for (size_t len = 16; len <= n; len <<= 2) {
             cpx<T> *dst = (len == n) ? out + b0 * n : tmp;  // the last stage lands in the caller's buffer
-            hipLaunchKernelGGL(radix4_stage_kernel<T>, grid(quads), dim3(256), 0, ctx->stream, tmp, dst, w + 3 * off, len, n, quads);
+            if (len == n && inverse)
+                hipLaunchKernelGGL((radix4_stage_kernel<T, true>), grid(quads), dim3(256), 0, ctx->stream, tmp, dst, w + 3 * off, len, n, quads, scale);
+            else
+                hipLaunchKernelGGL((radix4_stage_kernel<T, false>), grid(quads), dim3(256), 0, ctx->stream, tmp, dst, w + 3 * off, len, n, quads, scale);
             KOFFT_HIP_TRY(ctx, hipGetLastError());
             off += len / 4;
         }

@@ -665,7 +665,7 @@ int fft2d_fused_c32(kofft_hip_ctx *ctx, float *d_data, size_t rows, size_t cols,
 template <typename T>
 int fft_big_windowed_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, const T *d_window, size_t m, size_t batch);  // factor path, window in the first load
 template <typename T>
-int fft_radix4_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t batch);  // fft.rs:1455-1548, the reference's bytes (opt-in)
+int fft_radix4_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t batch, int inverse);  // fft.rs:1455-1548, the reference's bytes (inverse: FftPlan::ifft's loop around it)
 template <typename T>
 int rfft_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, const T *d_window, size_t n, size_t batch);  // k_real_f32/f64.hip
 template <typename T>

@@ -6,7 +6,7 @@ namespace kofft {
 namespace host {
 template int fft_dev<float>(kofft_hip_ctx *, const float *, float *, size_t, size_t, int);
 template int fft_axis2_dev<float>(kofft_hip_ctx *, float *, int, int, size_t, int);
-template int fft_radix4_dev<float>(kofft_hip_ctx *, const float *, float *, size_t, size_t);
+template int fft_radix4_dev<float>(kofft_hip_ctx *, const float *, float *, size_t, size_t, int);
 template int fft_big_windowed_dev<float>(kofft_hip_ctx *, const float *, float *, const float *, size_t, size_t);
 }  // namespace host
 }  // namespace kofft

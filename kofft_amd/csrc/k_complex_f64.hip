@@ -5,7 +5,7 @@ namespace kofft {
 namespace host {
 template int fft_dev<double>(kofft_hip_ctx *, const double *, double *, size_t, size_t, int);
 template int fft_axis2_dev<double>(kofft_hip_ctx *, double *, int, int, size_t, int);
-template int fft_radix4_dev<double>(kofft_hip_ctx *, const double *, double *, size_t, size_t);
+template int fft_radix4_dev<double>(kofft_hip_ctx *, const double *, double *, size_t, size_t, int);
 template int fft_big_windowed_dev<double>(kofft_hip_ctx *, const double *, double *, const double *, size_t, size_t);
 }  // namespace host
 }  // namespace kofft

@@ -167,13 +167,13 @@ int fft_host(kofft_hip_ctx *ctx, T *data, size_t n, size_t batch, int inverse)
     return KOFFT_OK;
 }
 
-// ScalarFftImpl::fft_radix4 on a host buffer (opt-in compatibility arm, fft_radix4.hip.h)
+// ScalarFftImpl::fft_radix4 on a host buffer (fft_radix4.hip.h); inverse: FftPlan::ifft's loop around it (fft.rs:2040-2055)
 template <typename T>
-int fft_radix4_host(kofft_hip_ctx *ctx, T *data, size_t n, size_t batch)
+int fft_radix4_host(kofft_hip_ctx *ctx, T *data, size_t n, size_t batch, int inverse)
 {
     if (batch == 0) return KOFFT_OK;
-    if (!is_pow2(n) || (ilog2(n) & 1)) return fft_host<T>(ctx, data, n, batch, 0);  // fft.rs:1457-1460
-    if (n > (size_t(1) << 20)) return KOFFT_ERR_UNSUPPORTED;
+    if (!is_pow2(n) || (ilog2(n) & 1)) return fft_host<T>(ctx, data, n, batch, inverse);  // fft.rs:1457-1460
+    if (n > (size_t(1) << max_log2_big<T>())) return KOFFT_ERR_UNSUPPORTED;
     if (n == 1) return KOFFT_OK;
     if (!ctx || !data) return KOFFT_ERR_NULL;
     KOFFT_HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -182,7 +182,7 @@ int fft_radix4_host(kofft_hip_ctx *ctx, T *data, size_t n, size_t batch)
     if (rc) return rc;
     T *d = static_cast<T *>(ctx->stage[0]);
     KOFFT_HIP_TRY(ctx, hipMemcpyAsync(d, data, bytes, hipMemcpyHostToDevice, ctx->stream));
-    rc = fft_radix4_dev<T>(ctx, d, d, n, batch);
+    rc = fft_radix4_dev<T>(ctx, d, d, n, batch, inverse);
     if (rc) return rc;
     KOFFT_HIP_TRY(ctx, hipMemcpyAsync(data, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
     KOFFT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -660,15 +660,25 @@ int kofft_hip_fft_c64_dev_oop(kofft_hip_ctx *ctx, const double *d_in, double *d_
 {
     return fft_dev<double>(ctx, d_in, d_out, n, batch, inverse);
 }
-int kofft_hip_fft_radix4_c32(kofft_hip_ctx *ctx, float *data, size_t n, size_t batch) { return fft_radix4_host<float>(ctx, data, n, batch); }
-int kofft_hip_fft_radix4_c64(kofft_hip_ctx *ctx, double *data, size_t n, size_t batch) { return fft_radix4_host<double>(ctx, data, n, batch); }
+int kofft_hip_fft_radix4_c32(kofft_hip_ctx *ctx, float *data, size_t n, size_t batch) { return fft_radix4_host<float>(ctx, data, n, batch, 0); }
+int kofft_hip_fft_radix4_c64(kofft_hip_ctx *ctx, double *data, size_t n, size_t batch) { return fft_radix4_host<double>(ctx, data, n, batch, 0); }
 int kofft_hip_fft_radix4_c32_dev(kofft_hip_ctx *ctx, const float *d_in, float *d_out, size_t n, size_t batch)
 {
-    return fft_radix4_dev<float>(ctx, d_in, d_out, n, batch);
+    return fft_radix4_dev<float>(ctx, d_in, d_out, n, batch, 0);
 }
 int kofft_hip_fft_radix4_c64_dev(kofft_hip_ctx *ctx, const double *d_in, double *d_out, size_t n, size_t batch)
 {
-    return fft_radix4_dev<double>(ctx, d_in, d_out, n, batch);
+    return fft_radix4_dev<double>(ctx, d_in, d_out, n, batch, 0);
+}
+int kofft_hip_ifft_radix4_c32(kofft_hip_ctx *ctx, float *data, size_t n, size_t batch) { return fft_radix4_host<float>(ctx, data, n, batch, 1); }
+int kofft_hip_ifft_radix4_c64(kofft_hip_ctx *ctx, double *data, size_t n, size_t batch) { return fft_radix4_host<double>(ctx, data, n, batch, 1); }
+int kofft_hip_ifft_radix4_c32_dev(kofft_hip_ctx *ctx, const float *d_in, float *d_out, size_t n, size_t batch)
+{
+    return fft_radix4_dev<float>(ctx, d_in, d_out, n, batch, 1);
+}
+int kofft_hip_ifft_radix4_c64_dev(kofft_hip_ctx *ctx, const double *d_in, double *d_out, size_t n, size_t batch)
+{
+    return fft_radix4_dev<double>(ctx, d_in, d_out, n, batch, 1);
 }
 int kofft_hip_fft_c32_strided(kofft_hip_ctx *ctx, float *data, size_t data_len, size_t stride, size_t n,
                               int inverse)

@@ -26,6 +26,10 @@ static bool same_bits(const std::vector<Complex32> &a, const std::vector<Complex
 {
     return a.size() == b.size() && std::memcmp(a.data(), b.data(), a.size() * sizeof(Complex32)) == 0;
 }
+static bool same_bits(const std::vector<Complex64> &a, const std::vector<Complex64> &b)
+{
+    return a.size() == b.size() && std::memcmp(a.data(), b.data(), a.size() * sizeof(Complex64)) == 0;
+}
 
 int main()
 {
@@ -308,17 +312,37 @@ int main()
         std::vector<Complex32> x64(64);
         for (size_t i = 0; i < 64; ++i) x64[i] = Complex32(std::sin(0.3f * (float)i), std::cos(1.1f * (float)i));
         auto want = oracle_fft(x64);
-        FftPlan<float>(64, FftStrategy::Radix4, fft).fft(x64).unwrap();  // the correct transform
+        FftPlan<float>(64, FftStrategy::Radix4, fft).fft(x64).unwrap();  // f32 plan: the *_with_twiddles shortcut = stockham_fft (fft.rs:2016-2035)
         CHECK(same_bits(x64, want));
-        // opt-in: the reference's own fft_radix4 bytes (fft.rs:1455-1548), which are not that transform
-        std::vector<Complex32> r4(64), r4want(64);
-        for (size_t i = 0; i < 64; ++i) r4[i] = r4want[i] = Complex32(std::sin(0.3f * (float)i), std::cos(1.1f * (float)i));
+        // fft_with_strategy(.., Radix4) on a DEFAULT-constructed implementation: the reference's own fft_radix4 bytes
+        // (fft.rs:1356, 1455-1548), which are not that transform
+        std::vector<Complex32> r4(64), r4want(64), r4in(64);
+        for (size_t i = 0; i < 64; ++i) r4[i] = r4want[i] = r4in[i] = Complex32(std::sin(0.3f * (float)i), std::cos(1.1f * (float)i));
         ko_fft_radix4_batch_f32(reinterpret_cast<float *>(r4want.data()), 64, 1);
-        HipFftImpl<float> compat;
-        compat.radix4_compat = true;
-        compat.fft_with_strategy(r4, FftStrategy::Radix4).unwrap();
+        CHECK(fft.radix4_compat);
+        fft.fft_with_strategy(r4, FftStrategy::Radix4).unwrap();
         CHECK(same_bits(r4, r4want));
         CHECK(!same_bits(r4, want));
+        // the opt-out: the true transform for every strategy
+        HipFftImpl<float> plain;
+        plain.radix4_compat = false;
+        r4 = r4in;
+        plain.fft_with_strategy(r4, FftStrategy::Radix4).unwrap();
+        CHECK(same_bits(r4, want));
+        // an f64 plan has no shortcut: Radix4 -> fft_radix4, and ifft = conj, fft_radix4, conj * 1/n (fft.rs:2040-2055)
+        std::vector<Complex64> d4(64), d4want(64), d4inv(64);
+        for (size_t i = 0; i < 64; ++i) d4[i] = d4want[i] = d4inv[i] = Complex64(std::sin(0.3 * (double)i), std::cos(1.1 * (double)i));
+        ko_fft_radix4_batch_f64(reinterpret_cast<double *>(d4want.data()), 64, 1);
+        FftPlan<double> p4(64, FftStrategy::Radix4, fft64);
+        p4.fft(d4).unwrap();
+        CHECK(same_bits(d4, d4want));
+        std::vector<Complex64> d4ref = d4inv;
+        for (auto &c : d4ref) c.im = -c.im;
+        ko_fft_radix4_batch_f64(reinterpret_cast<double *>(d4ref.data()), 64, 1);
+        const double sc = 1.0 / (double)(float)64;
+        for (auto &c : d4ref) { c.im = -c.im; c.re = c.re * sc; c.im = c.im * sc; }
+        p4.ifft(d4inv).unwrap();
+        CHECK(same_bits(d4inv, d4ref));
     }
     {   // multi-GPU STFT through the C++ mirror: one device here, same path as G devices
         std::vector<float> sig(3000), window = hann(256);

@@ -1310,7 +1310,8 @@ def test_fft_plan(fft32, fft64, oracle):
         with pytest.raises(K.FftError) as e:
             call()
         assert e.value.code == K.FftError.MismatchedLengths
-    # every strategy returns the (correct) Stockham result on the device, for f32 and f64, including Radix4 at n = 64
+    # an f32 plan is the Stockham transform for EVERY strategy: Radix2 / Radix4 take the *_with_twiddles shortcut
+    # (fft.rs:2016-2035 -> stockham_fft, fft.rs:1645-1660), SplitRadix / Auto reach it through fft_with_strategy
     rng = seeded(8100)
     x = rand_c(rng, (64,))
     want = oracle.fft(x)
@@ -1318,11 +1319,25 @@ def test_fft_plan(fft32, fft64, oracle):
         y = x.copy()
         K.FftPlan(64, strat, fft32).fft(y)
         assert bits_equal(y, want)
+        K.FftPlan(64, strat, fft32).ifft(y)
+        assert bits_equal(y, oracle.ifft(want))
+    # an f64 plan has no shortcut: Radix4 -> fft_with_strategy -> fft_radix4 (fft.rs:2037, 1356), the reference's bytes --
+    # which from n = 16 are not the DFT
     xd = rand_c(rng, (256,), np.complex128)
+    for strat in (K.FftStrategy.Radix2, K.FftStrategy.SplitRadix, K.FftStrategy.Auto):
+        yd = xd.copy()
+        K.FftPlan(256, strat, fft64).fft(yd)
+        assert bits_equal(yd, oracle.fft(xd))
     yd = xd.copy()
     K.FftPlan(256, K.FftStrategy.Radix4, fft64).fft(yd)
+    assert bits_equal(yd, oracle.fft_radix4(xd[None])[0])
+    assert np.abs(yd - np.fft.fft(xd)).max() > 1e-3
+    # ... and with the opt-out every strategy is the true transform
+    plain = K.HipFftImpl(np.float64, radix4_compat=False)
+    yd = xd.copy()
+    K.FftPlan(256, K.FftStrategy.Radix4, plain).fft(yd)
     assert bits_equal(yd, oracle.fft(xd))
-    assert np.abs(yd - np.fft.fft(xd)).max() < 1e-10  # ... which IS the DFT, unlike the reference's radix-4 arm
+    assert np.abs(yd - np.fft.fft(xd)).max() < 1e-10
 
 
 def test_host_pointer_pipeline_large_batches(fft32, fft64, oracle):
@@ -1555,35 +1570,68 @@ def test_stft_keeps_special_values(fft32, oracle, win_len, frames):
     assert bits_equal(np.where(ng, np.float32(0), g), np.where(nw, np.float32(0), w))
 
 
-# ---- FftStrategy::Radix4, the reference's bytes (opt-in compatibility arm) -----------------------------
-@pytest.mark.parametrize("n", [1, 4, 16, 64, 256, 1024, 4096, 65536, 8, 32, 12])
-def test_radix4_compat_reproduces_the_reference_arm(oracle, n):
-    """kofft_hip_fft_radix4_* = ScalarFftImpl::fft_radix4 (fft.rs:1455-1548) byte for byte, f32 and f64: powers of four run
-    the reference's swap loop, butterfly4 and running-product twiddles; other lengths fall back to fft() (fft.rs:1457-1460).
-    Default behaviour is unchanged: without the flag fft_with_strategy(.., Radix4) is the true transform."""
+# ---- FftStrategy::Radix4: the reference's bytes BY DEFAULT (strict drop-in) ---------------------------
+def _plan_ifft_reference(oracle, x, forward):
+    """FftPlan::ifft (fft.rs:2040-2055) around ``forward``: conj, fft, conj * 1/(n as f32 -> T) -- IEEE elementwise."""
+    real = np.float32 if x.dtype == np.complex64 else np.float64
+    y = forward(np.conj(x))
+    scale = real(1) / real(np.float32(x.shape[-1]))
+    out = np.empty_like(y)
+    out.real = y.real * scale
+    out.imag = (-y.imag) * scale
+    return out
+
+
+@pytest.mark.parametrize("n", [1, 4, 16, 64, 256, 1024, 4096, 65536, 1 << 20, 8, 32, 12])
+def test_radix4_compat_reproduces_the_reference_arm(oracle, n, monkeypatch):
+    """A DEFAULT-CONSTRUCTED implementation (no flag, no environment) sends fft_with_strategy(.., Radix4) to
+    ScalarFftImpl::fft_radix4 (fft.rs:1356, 1455-1548) and returns its bytes, f32 and f64: powers of four run the reference's
+    swap loop, butterfly4 and running-product twiddles; other lengths fall back to fft() (fft.rs:1457-1460).  FftPlan
+    follows fft.rs:2012-2055: the f32 Radix4 plan is the Stockham transform (the *_with_twiddles shortcut), the f64 one is
+    fft_radix4, and plan.ifft is conj / that fft / conj * scale.  radix4_compat=False / KOFFT_HIP_RADIX4_COMPAT=0 opts out."""
     import kofft_amd as K
 
+    monkeypatch.delenv("KOFFT_HIP_RADIX4_COMPAT", raising=False)
+    pow4 = n >= 16 and (n & (n - 1)) == 0 and (n.bit_length() - 1) % 2 == 0
     for dt, cdt in ((np.float32, np.complex64), (np.float64, np.complex128)):
-        rng = seeded(8800 + n)
+        rng = seeded(8800 + n % 9973)
         x = rand_c(rng, (3, n), cdt)
         want = oracle.fft_radix4(x)
-        compat = K.HipFftImpl(dt, radix4_compat=True)
+        dflt = K.HipFftImpl(dt)
+        assert dflt.radix4_compat is True
         y = x.copy()
-        compat.fft_radix4_batch(y)
+        dflt.fft_radix4_batch(y)
         assert bits_equal(y, want), f"fft_radix4 {cdt.__name__} n={n}"
         z = x[0].copy()
-        compat.fft_with_strategy(z, K.FftStrategy.Radix4)
+        dflt.fft_with_strategy(z, K.FftStrategy.Radix4)
         assert bits_equal(z, want[0])
+        for strat in (K.FftStrategy.Radix2, K.FftStrategy.SplitRadix, K.FftStrategy.Auto):
+            z = x[0].copy()
+            dflt.fft_with_strategy(z, strat)
+            assert bits_equal(z, oracle.fft(x[:1])[0])
+        # FftPlan::fft / ifft
+        plan = K.FftPlan(n, K.FftStrategy.Radix4, dflt)
         z = x[1].copy()
-        K.FftPlan(n, K.FftStrategy.Radix4, compat).fft(z)  # FftPlan::fft goes through fft_with_strategy (fft.rs:2020-2030)
-        assert bits_equal(z, want[1])
-        plain = K.HipFftImpl(dt)
-        assert plain.radix4_compat is False
+        plan.fft(z)
+        plan_fwd = (lambda a: oracle.fft(a)) if dt == np.float32 else (lambda a: oracle.fft_radix4(a))
+        assert bits_equal(z, plan_fwd(x[1:2])[0]), f"plan.fft {cdt.__name__} n={n}"
+        z = x[2].copy()
+        plan.ifft(z)
+        assert bits_equal(z, _plan_ifft_reference(oracle, x[2:3], plan_fwd)[0]), f"plan.ifft {cdt.__name__} n={n}"
+        if pow4:
+            assert not bits_equal(want[0], oracle.fft(x[:1])[0])  # the reference's arm is not the transform
+        # the opt-out: flag, then environment
+        plain = K.HipFftImpl(dt, radix4_compat=False)
         v = x[0].copy()
         plain.fft_with_strategy(v, K.FftStrategy.Radix4)
-        assert bits_equal(v, oracle.fft(x[:1])[0])  # the correct transform
-        if n >= 16 and (n & (n - 1)) == 0 and (n.bit_length() - 1) % 2 == 0:
-            assert not bits_equal(want[0], oracle.fft(x[:1])[0])  # ... which the reference's arm is not
+        assert bits_equal(v, oracle.fft(x[:1])[0])
+        v = x[0].copy()
+        K.FftPlan(n, K.FftStrategy.Radix4, plain).ifft(v)
+        assert bits_equal(v, oracle.ifft(x[:1])[0])
+    monkeypatch.setenv("KOFFT_HIP_RADIX4_COMPAT", "0")
+    assert K.HipFftImpl(np.float32).radix4_compat is False
+    monkeypatch.setenv("KOFFT_HIP_RADIX4_COMPAT", "1")
+    assert K.HipFftImpl(np.float32).radix4_compat is True
 
 
 def test_radix4_compat_env_and_device_pointers(oracle, monkeypatch):
@@ -1591,10 +1639,9 @@ def test_radix4_compat_env_and_device_pointers(oracle, monkeypatch):
 
     import kofft_amd as K
 
-    monkeypatch.setenv("KOFFT_HIP_RADIX4_COMPAT", "1")
+    monkeypatch.delenv("KOFFT_HIP_RADIX4_COMPAT", raising=False)
     f = K.HipFftImpl(np.float32)
     assert f.radix4_compat is True
-    monkeypatch.delenv("KOFFT_HIP_RADIX4_COMPAT")
     x = rand_c(seeded(8899), (5, 1024))
     want = oracle.fft_radix4(x)
     d = torch.from_numpy(x.view(np.float32).reshape(5, 1024, 2)).to("cuda")
@@ -1605,7 +1652,29 @@ def test_radix4_compat_env_and_device_pointers(oracle, monkeypatch):
     f.synchronize() if hasattr(f, "synchronize") else lib.kofft_hip_synchronize(f._ctx)
     assert bits_equal(o.cpu().numpy().view(np.complex64).reshape(5, 1024), want)
     assert bits_equal(d.cpu().numpy().view(np.complex64).reshape(5, 1024), want)
-    assert lib.kofft_hip_fft_radix4_c32_dev(f._ctx, C_void(d.data_ptr()), C_void(o.data_ptr()), 1 << 22, 1) == -2  # UNSUPPORTED
+    # the plan's inverse loop, device pointers, out of place and in place
+    d = torch.from_numpy(x.view(np.float32).reshape(5, 1024, 2)).to("cuda")
+    wanti = _plan_ifft_reference(oracle, x, oracle.fft_radix4)
+    assert lib.kofft_hip_ifft_radix4_c32_dev(f._ctx, C_void(d.data_ptr()), C_void(o.data_ptr()), 1024, 5) == 0
+    assert lib.kofft_hip_ifft_radix4_c32_dev(f._ctx, C_void(d.data_ptr()), C_void(d.data_ptr()), 1024, 5) == 0
+    f.synchronize()
+    assert bits_equal(o.cpu().numpy().view(np.complex64).reshape(5, 1024), wanti)
+    assert bits_equal(d.cpu().numpy().view(np.complex64).reshape(5, 1024), wanti)
+    assert lib.kofft_hip_fft_radix4_c32_dev(f._ctx, C_void(d.data_ptr()), C_void(o.data_ptr()), 1 << 28, 1) == -2  # UNSUPPORTED, like fft
+
+
+def test_radix4_arm_beyond_2p20(oracle):
+    """Powers of four past 2^20 (round 5 returned UNSUPPORTED there): 4^11 = 2^22 f32 and f64, one transform each, byte for
+    byte against the oracle's restatement of fft_radix4; tables are O(n) host work once per (context, n)."""
+    import kofft_amd as K
+
+    n = 1 << 22
+    for dt, cdt in ((np.float32, np.complex64), (np.float64, np.complex128)):
+        x = rand_c(seeded(8877), (1, n), cdt)
+        f = K.HipFftImpl(dt)
+        y = x[0].copy()
+        f.fft_with_strategy(y, K.FftStrategy.Radix4)
+        assert bits_equal(y, oracle.fft_radix4(x)[0]), cdt.__name__
 
 
 def C_void(p):
