@@ -410,6 +410,7 @@ class Workload:
         if name == "fft4096":
             n, batch = 4096, batch_override or 65536
             form = getattr(args, "form", "inplace")
+            self.form = form
             # ONE pristine batch for both forms: uniform(-1, 1) x 1e-18 (the in-place form needs the head-room; the twin reads the
             # same values so that the two differ in nothing but where the spectra go)
             pristine = torch.empty((batch, n, 2), dtype=torch.float32, device=dev).uniform_(-1.0, 1.0, generator=gen).mul_(INPLACE_SCALE)
@@ -694,18 +695,35 @@ def measure(w: Workload, steps, warmup, ramp_ms, min_seconds, dev, stream, barri
     total_units = reduce_sum(float(w.units_per_step)) * steps
     avg_kernel_s = float(np.mean(kern_ms)) / 1e3
     achieved = w.alg_bytes / avg_kernel_s / 1e9
-    traffic, traffic_from, traffic_stale = None, None, None
+    traffic, traffic_from, traffic_stale, issue = None, None, None, {}
     tfile = ROOT / "profiles" / f"traffic_{w.name}.json"
     if tfile.exists():
         try:
             tj = json.loads(tfile.read_text())
-            if tj.get("workload") == w.name:
+            # the profile is of ONE form of the workload (config #2: in place); a twin measured in another form carries no counters
+            tform = tj.get("form", "inplace" if w.name == "fft4096" else None)  # (files without the key: config #2 was profiled in place)
+            if tj.get("workload") == w.name and tform == getattr(w, "form", None):
                 traffic = tj.get("hbm_bytes_per_step", tj.get("hbm_bytes_per_launch"))
                 traffic_from = tj.get("from")
                 # the counters were collected with one version of the kernels: say so when the sources have changed since
                 traffic_stale = tj.get("csrc_sha16") != csrc_sha16()
+                issue = {k: tj[k] for k in ("valu_insts_per_step", "lds_active_cycles_per_step", "shader_clock_ghz") if tj.get(k)}
         except Exception:
             traffic = None
+    # Which roofline binds: instruction and LDS-cycle counts per step and the shader clock come from the PMC
+    # passes of tools/profile.sh (clock = GRBM_GUI_ACTIVE / 8 XCDs / dispatch duration under this very workload: measured, not the
+    # data-sheet's); the time is this run's own HIP-event kernel time.  VALU: 4 cycles per wave64 instruction on each of 1024 SIMDs;
+    # LDS: one pipe per CU.  `bound` = the largest of the three utilisations (HBM's is the PMC traffic, or the algorithmic bytes).
+    valu_frac = lds_frac = None
+    hbm_util = (traffic or w.alg_bytes) / avg_kernel_s / 1e9 / HBM_PEAK_GBS
+    bound = "hbm"
+    if issue.get("shader_clock_ghz"):
+        cyc = issue["shader_clock_ghz"] * 1e9 * avg_kernel_s
+        if issue.get("valu_insts_per_step"):
+            valu_frac = issue["valu_insts_per_step"] * 4.0 / (1024 * cyc)
+        if issue.get("lds_active_cycles_per_step"):
+            lds_frac = issue["lds_active_cycles_per_step"] / (256 * cyc)
+        bound = max((hbm_util, "hbm"), (valu_frac or 0.0, "valu"), (lds_frac or 0.0, "lds"))[1]
     if count_launches is not None:
         count_launches.append(launches)
     finite = None
@@ -726,7 +744,7 @@ def measure(w: Workload, steps, warmup, ramp_ms, min_seconds, dev, stream, barri
         "dtype": w.dtype,
         "config": w.cfg,
         "roofline": {
-            "bound": "hbm",
+            "bound": bound,
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -734,6 +752,10 @@ def measure(w: Workload, steps, warmup, ramp_ms, min_seconds, dev, stream, barri
             "traffic": traffic,
             "traffic_from": traffic_from,
             "traffic_stale": traffic_stale,
+            "hbm_util": hbm_util,
+            "issue_frac": valu_frac,
+            "lds_frac": lds_frac,
+            "shader_clock_ghz": issue.get("shader_clock_ghz"),
             "kernel_ms_avg": avg_kernel_s * 1e3,
             "kernel_ms_min": float(np.min(kern_ms)),
             "algorithmic_bytes_per_launch": w.alg_bytes,
@@ -756,7 +778,17 @@ def summarise(name: str, r: dict) -> dict:
     if "error" in r:
         return {"error": r["error"][:100]}
     rf = r["roofline"]
-    out = {"value": sig(r["value"]), "unit": r["unit"], "ms": sig(r["ms_per_step"]), "frac": sig(rf["frac"], 4)}
+    # ONE clock per entry: `ms` is the step time `value` is computed from (wall clock between barriers, or the
+    # steps' HIP events where a block holds untimed restores) and `frac` = algorithmic bytes / THAT time / 8 TB/s; `kernel_ms` is the
+    # HIP-event average of the kernels alone (the headline roofline object's clock, as the contract prescribes), for comparison.
+    # `bound` names the roofline that binds; `issue_frac` / `lds_frac` = VALU issue / LDS pipe utilisation (measure(): from PMC counts).
+    out = {"value": sig(r["value"]), "unit": r["unit"], "ms": sig(r["ms_per_step"]),
+           "frac": sig(rf["algorithmic_bytes_per_launch"] / (r["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "kernel_ms": sig(rf["kernel_ms_avg"]), "bound": rf["bound"]}
+    if rf.get("issue_frac") is not None:
+        out["issue_frac"] = sig(rf["issue_frac"], 3)
+    if rf.get("lds_frac") is not None:
+        out["lds_frac"] = sig(rf["lds_frac"], 3)
     if rf.get("traffic"):
         out["traffic_ratio"] = sig(rf["traffic"] / rf["algorithmic_bytes_per_launch"], 4)
         if rf.get("traffic_stale"):
@@ -764,6 +796,12 @@ def summarise(name: str, r: dict) -> dict:
     if name == "c64_2p20":
         out["cap"] = 0.5  # two passes over HBM (the 512 MiB intermediate does not stay in the Infinity Cache): frac / cap is the share of the achievable
         out["passes"] = 2
+        pp = r.get("placement_probe")
+        if pp and pp.get("n"):
+            # the library timed its two factor kernels through n candidate placements of its 512 MiB intermediate and kept the fastest:
+            # [first factor us, whole chunk us] of the pick and of the slowest candidate -- the spread a blind hipMalloc would draw from
+            i, j = pp["pick"], max(range(pp["n"]), key=lambda k: pp["total_us"][k])
+            out["probe"] = {"n": pp["n"], "pick_us": [pp["first_us"][i], pp["total_us"][i]], "worst_us": [pp["first_us"][j], pp["total_us"][j]]}
     if "allgather" in r:
         out["allgather_ms"] = sig(r["allgather"]["ms_per_step"])
         out["allgather_GBps"] = sig(r["allgather"]["algbw_GBps"], 4)
@@ -1003,6 +1041,8 @@ def run_rank(args) -> None:
                 r["allgather"] = we.time_allgather(dist, dev, world, barrier)
             if name == "stft1024" and world == 1:
                 r["shard_ms"] = we.shard_kernel_ms(fft32, stream, dev)
+            if name == "c64_2p20":
+                r["placement_probe"] = fft64.big_probe_info()  # the intermediate's candidates (us per 512 MiB chunk) and the pick
             extras[name] = r
             del we
         except Exception as e:  # the headline must survive a failing extra

@@ -79,6 +79,13 @@ int kofft_hip_synchronize(kofft_hip_ctx *ctx);
 /* The context's scratch (host-pointer staging, the large-n intermediate, the Bluestein and composed-length work buffers)
  * only grows with the largest call seen; this synchronises the stream and frees it all (tables stay cached). */
 int kofft_hip_release_scratch(kofft_hip_ctx *ctx);
+/* (no counterpart in kofft) The large-n path (n beyond one workgroup: two or three factor kernels through an intermediate the
+ * context owns) chooses the PLACEMENT of that intermediate: the first call that needs it (full chunks of >= 128 MiB) allocates
+ * KOFFT_HIP_BIG_PROBE (default 5, at most 8; 0 / 1 = off) candidates, times its own factor kernels on one chunk of scratch data
+ * through each and keeps the fastest (the same kernel reads a 512 MiB hipMalloc at 188 or at 225 us depending on
+ * where it lies, for the allocation's lifetime).  This reports the last probe: n candidates, per candidate the first factor's
+ * and the whole chunk's time in microseconds (arrays of `cap` floats, may be NULL), and which one was kept (n = 0: no probe ran). */
+int kofft_hip_big_probe_info(kofft_hip_ctx *ctx, float *first_us, float *total_us, int cap, int *n, int *pick);
 
 /* ---- tables: the planner recipes, on the host --------------------------------
  * kofft_hip_twiddles_*: FftPlanner::get_twiddles(n) (fft.rs:370-408), n/2 complex.

@@ -37,6 +37,7 @@ SIGNATURES = {
     "kofft_hip_set_stream": (C.c_int, [_ctx, C.c_void_p]),
     "kofft_hip_synchronize": (C.c_int, [_ctx]),
     "kofft_hip_release_scratch": (C.c_int, [_ctx]),
+    "kofft_hip_big_probe_info": (C.c_int, [_ctx, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "kofft_hip_twiddles_f32": (C.c_int, [_sz, C.c_void_p]),
     "kofft_hip_twiddles_f64": (C.c_int, [_sz, C.c_void_p]),
     "kofft_hip_rfft_table_f32": (C.c_int, [_sz, C.c_void_p]),

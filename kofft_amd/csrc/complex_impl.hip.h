@@ -298,6 +298,93 @@ inline int rows_persist_xpb(int LS)
     }
 }
 
+// Placement probe of the factor path's intermediate (round 6; fft_big_core explains why).  K candidate allocations of `need`
+// bytes; `run(in, out, cand, ev_mid)` enqueues the caller's own factor kernels for one full chunk from the scratch input through
+// the candidate to the scratch output (ev_mid is recorded behind the first factor).  Keeps the candidate with the smallest chunk
+// time in ctx->big_tmp, frees the others, leaves the figures in ctx->big_probe_* (kofft_hip_big_probe_info).  Allocation
+// failures shrink K; with fewer than two candidates (or no scratch) nothing is measured and the caller allocates as before.
+template <class Run>
+int big_probe_pick(kofft_hip_ctx *ctx, size_t need, size_t io_bytes, int K, Run run)
+{
+    if (K > KOFFT_BIG_PROBE_MAX) K = KOFFT_BIG_PROBE_MAX;
+    void *io[2] = {nullptr, nullptr};
+    void *cand[KOFFT_BIG_PROBE_MAX] = {};
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    int got = 0, rc = KOFFT_OK, best = -1;
+    auto cleanup = [&](int keep) {
+        for (int i = 0; i < got; ++i)
+            if (i != keep && cand[i]) (void)hipFree(cand[i]);
+        for (void *p : io)
+            if (p) (void)hipFree(p);
+        for (hipEvent_t e : ev)
+            if (e) (void)hipEventDestroy(e);
+    };
+    if (hipMalloc(&io[0], io_bytes) != hipSuccess || hipMalloc(&io[1], io_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        cleanup(-1);
+        return KOFFT_OK;  // no room for the scratch pair: no probe
+    }
+    for (; got < K; ++got)
+        if (hipMalloc(&cand[got], need) != hipSuccess) {
+            (void)hipGetLastError();
+            cand[got] = nullptr;
+            break;
+        }
+    if (got < 2) {
+        if (got == 1) {
+            ctx->big_tmp = cand[0];
+            ctx->big_tmp_bytes = need;
+        }
+        cleanup(0);
+        return KOFFT_OK;
+    }
+    hipError_t he = hipMemsetAsync(io[0], 0, io_bytes, ctx->stream);
+    for (int i = 0; i < 3 && he == hipSuccess; ++i) he = hipEventCreate(&ev[i]);
+    if (he != hipSuccess) {
+        ctx->last_error = std::string("placement probe: ") + hipGetErrorString(he);
+        cleanup(-1);
+        return KOFFT_ERR_HIP;
+    }
+    float best_us = 0.f;
+    for (int i = 0; i < got && rc == KOFFT_OK; ++i) {
+        float first_us = 0.f, total_us = 0.f;
+        for (int rep = 0; rep < 3 && rc == KOFFT_OK; ++rep) {  // rep 0: warm (tables, code, clocks)
+            he = hipEventRecord(ev[0], ctx->stream);
+            if (he == hipSuccess) rc = run(io[0], io[1], cand[i], ev[1]);
+            if (rc == KOFFT_OK && he == hipSuccess) he = hipEventRecord(ev[2], ctx->stream);
+            if (rc == KOFFT_OK && he == hipSuccess) he = hipEventSynchronize(ev[2]);
+            float a_ms = 0.f, t_ms = 0.f;
+            if (rc == KOFFT_OK && he == hipSuccess) he = hipEventElapsedTime(&a_ms, ev[0], ev[1]);
+            if (rc == KOFFT_OK && he == hipSuccess) he = hipEventElapsedTime(&t_ms, ev[0], ev[2]);
+            if (he != hipSuccess) {
+                ctx->last_error = std::string("placement probe: ") + hipGetErrorString(he);
+                rc = KOFFT_ERR_HIP;
+            }
+            if (rep >= 1 && (rep == 1 || t_ms * 1e3f < total_us)) {
+                total_us = t_ms * 1e3f;
+                first_us = a_ms * 1e3f;
+            }
+        }
+        ctx->big_probe_first_us[i] = first_us;
+        ctx->big_probe_total_us[i] = total_us;
+        if (rc == KOFFT_OK && (best < 0 || total_us < best_us)) {
+            best = i;
+            best_us = total_us;
+        }
+    }
+    if (rc != KOFFT_OK) {
+        (void)hipStreamSynchronize(ctx->stream);
+        cleanup(-1);
+        return rc;
+    }
+    ctx->big_probe_n = got;
+    ctx->big_probe_pick = best;
+    ctx->big_tmp = cand[best];
+    ctx->big_tmp_bytes = need;
+    cleanup(best);
+    return KOFFT_OK;
+}
+
 // The factor path with the policies of its first and last factor as parameters (round 3): ColsIO / RowsIO are BigColsIO /
 // BigRowsIO instances, possibly with a folded pointwise factor (PRE / POST) whose extra fields fix_cols / fix_rows fill in;
 // such policies may read input rows of in_row values and write output rows of out_row values (the transform itself is n).
@@ -332,28 +419,11 @@ int fft_big_core(kofft_hip_ctx *ctx, const cpx<T> *in_base, size_t in_row, cpx<T
     if (chunk < 1) chunk = 1;
     if (chunk > batch) chunk = batch;
     const size_t need = chunk * xf_bytes * (three ? 2 : 1);
-    if (ctx->big_tmp_bytes < need) {
-        if (ctx->big_tmp_external) return KOFFT_ERR_ALLOC;
-        if (ctx->big_tmp) KOFFT_HIP_TRY(ctx, hipFree(ctx->big_tmp));
-        ctx->big_tmp = nullptr;
-        ctx->big_tmp_bytes = 0;
-        // (Round 4, tools/exp_c64_alloc.py: a physically contiguous buffer -- hipExtMallocWithFlags(hipDeviceMallocContiguous) -- made
-        // the last factor's reads fast on one box (188-192 us per 512 MiB chunk on 16 of 16 buffers against 217-231 us on most plain
-        // ones) but not on the next (4 of 5 slow), slowed the first factor's writes by 10 % on both, and small contiguous buffers
-        // returned stale data to the plain loads of the narrow-tile kernels: not used.)
-        KOFFT_HIP_TRY(ctx, hipMalloc(&ctx->big_tmp, need));
-        ctx->big_tmp_bytes = need;
-    }
-    cpx<T> *mid = static_cast<cpx<T> *>(ctx->big_tmp);
-#ifdef KOFFT_EXP_TMP_PRINT
-    fprintf(stderr, "kofft big_tmp %p mid %p\n", ctx->big_tmp, (void *)mid);
-#endif
-    cpx<T> *mid2 = mid + chunk * n;
     const T scale = (T)1 / (T)(float)n;
-    for (size_t b0 = 0; b0 < batch; b0 += chunk) {
-        const size_t nb = (batch - b0 < chunk) ? batch - b0 : chunk;
-        const cpx<T> *src = in_base + b0 * in_row;
-        cpx<T> *dst = out_base + b0 * out_row;
+    // one chunk of nb transforms: src -> mid [-> mid2] -> dst
+    auto run_chunk = [&](const cpx<T> *src, cpx<T> *dst, cpx<T> *mid, size_t nb, hipEvent_t ev_mid) -> int {
+        cpx<T> *mid2 = mid + chunk * n;
+        int rc = KOFFT_OK;
         // first factor: stages 0 .. L1-1 down the columns of a 2^L1 x 2^(L-L1) matrix
         ColsIO a{src, mid, L - L1, L - L1, n};
         fix_cols(a);
@@ -387,6 +457,7 @@ int fft_big_core(kofft_hip_ctx *ctx, const cpx<T> *in_base, size_t in_row, cpx<T
         }
         rc = launch_sub<T>(ctx, a, tw, L1, nb << (L - L1), first_persist);
         if (rc) return rc;
+        if (ev_mid) KOFFT_HIP_TRY(ctx, hipEventRecord(ev_mid, ctx->stream));  // (the probe below: first factor | the rest)
         const cpx<T> *last_in = mid;
         if (three) {
             BigMidIO<T> m{mid, mid2, L1, L2, L3, L - L2, L - 1 - L1, n};
@@ -415,8 +486,7 @@ int fft_big_core(kofft_hip_ctx *ctx, const cpx<T> *in_base, size_t in_row, cpx<T
                 case 10: rc = launch_rows_persist<f32x2, 10>(ctx, bp, twp, nb); break;
                 default: break;
                 }
-                if (rc) return rc;
-                continue;
+                return rc;
             }
         }
         b.blk_r = a.blk_r;
@@ -449,6 +519,43 @@ int fft_big_core(kofft_hip_ctx *ctx, const cpx<T> *in_base, size_t in_row, cpx<T
             if (b.blk_r != 0) return KOFFT_ERR_UNSUPPORTED;  // (never: the blocked layout is only chosen where the rows kernel runs)
             rc = launch_sub<T>(ctx, b, tw, L3, nb << LP, last_mode >= 1);
         }
+        return rc;
+    };
+    if (ctx->big_tmp_bytes < need) {
+        if (ctx->big_tmp_external) return KOFFT_ERR_ALLOC;
+        if (ctx->big_tmp) KOFFT_HIP_TRY(ctx, hipFree(ctx->big_tmp));
+        ctx->big_tmp = nullptr;
+        ctx->big_tmp_bytes = 0;
+        ctx->big_probe_n = 0;
+        // (Round 4, tools/exp_c64_alloc.py: a physically contiguous buffer -- hipExtMallocWithFlags(hipDeviceMallocContiguous) -- made
+        // the last factor's reads fast on one box (188-192 us per 512 MiB chunk on 16 of 16 buffers against 217-231 us on most plain
+        // ones) but not on the next (4 of 5 slow), slowed the first factor's writes by 10 % on both, and small contiguous buffers
+        // returned stale data to the plain loads of the narrow-tile kernels: not used.)
+        //
+        // Round 6: the PLACEMENT of this buffer decides whether the last factor reads it at 188 or at 225 us per
+        // 512 MiB chunk (a property of the allocation, for its lifetime; 2-3 of 8 allocations are slow).  The library owns
+        // the buffer, so it chooses: K candidate allocations, this call's own factor kernels timed on one full chunk of scratch data
+        // through each (one warm pass, then the better of two), the fastest kept, the rest freed.  Only where it matters and costs
+        // little next to the call: full chunks of at least 128 MiB.  Once per (context, buffer size); KOFFT_HIP_BIG_PROBE=0 / 1: off.
+        const int K = (chunk * xf_bytes >= (size_t(128) << 20) && batch >= chunk) ? ctx->big_probe : 1;
+        if (K >= 2) {
+            const int prc = big_probe_pick(ctx, need, chunk * xf_bytes, K, [&](void *in_s, void *out_s, void *cand, hipEvent_t ev_mid) {
+                return run_chunk(static_cast<const cpx<T> *>(in_s), static_cast<cpx<T> *>(out_s), static_cast<cpx<T> *>(cand), chunk, ev_mid);
+            });
+            if (prc) return prc;
+        }
+        if (!ctx->big_tmp) {
+            KOFFT_HIP_TRY(ctx, hipMalloc(&ctx->big_tmp, need));
+            ctx->big_tmp_bytes = need;
+        }
+    }
+    cpx<T> *mid0 = static_cast<cpx<T> *>(ctx->big_tmp);
+#ifdef KOFFT_EXP_TMP_PRINT
+    fprintf(stderr, "kofft big_tmp %p mid %p\n", ctx->big_tmp, (void *)mid0);
+#endif
+    for (size_t b0 = 0; b0 < batch; b0 += chunk) {
+        const size_t nb = (batch - b0 < chunk) ? batch - b0 : chunk;
+        rc = run_chunk(in_base + b0 * in_row, out_base + b0 * out_row, mid0, nb, nullptr);
         if (rc) return rc;
     }
     return KOFFT_OK;

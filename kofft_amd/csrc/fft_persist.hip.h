@@ -385,20 +385,41 @@ __device__ __forceinline__ void persist_transform(const typename persist_raw<IO,
         // been issued: vmcnt counts loads and stores in issue order, so it assumed they had not and waited for them to COMPLETE before the
         // current transform's inputs could be used -- `s_waitcnt vmcnt(23 .. 16)` in the n = 4096 kernel where vmcnt(47 .. 32) is enough,
         // vmcnt(15 .. 0) in the n = 1024 STFT kernel: every step began by draining its predecessor's stores.
-        (void)active;
         const rsrc_t od = io.out_desc_n(xf0, cnt);
         const int lane_bytes = tau * (int)sizeof(cpx<T>);
         const int row_off = sub * (int)io.out_row_bytes();
+        if constexpr (io_half_spectrum<IO>::value) {
+            // which registers hold bins below N/2 is a compile-time fact (round 5): gather them, take their magnitudes together (round 6:
+            // StftMagIO::mags_of), store, and fold the transform's maximum into the accumulator -- for lanes that HAVE a transform only
+            // (an inactive lane's loads may land inside the group's descriptor and must not reach the maximum)
+            static_assert((LastG::out_index(0, 1) % TPT) == 0 && TPT <= N / 2, "register part and thread part of the index: disjoint bit fields");
+            constexpr int NK = R / 2;
+            cpx<T> kept[NK];
+            int ki = 0;
+#pragma unroll
+            for (int u = 0; u < R; ++u)
+                if (LastG::out_index(0, u) < N / 2) kept[ki++] = cur[u];  // (a constant per u)
+            float m[NK];
+            IO::template mags_of<NK>(kept, m);
+            typename IO::Acc top = m[0];
+            ki = 0;
+#pragma unroll
+            for (int u = 0; u < R; ++u)
+                if (LastG::out_index(0, u) < N / 2) {
+                    io.store_d_mag(od, lane_bytes, LastG::out_index(0, u), m[ki], row_off);
+                    top = __builtin_fmaxf(top, m[ki]);  // (NaN never selected, like `if mag > max_mag`, spectrogram.rs:68-70; magnitudes are >= +0)
+                    ++ki;
+                }
+            if (active) acc = __builtin_fmaxf(acc, top);
+        } else {
 #ifdef KOFFT_PERSIST_ACTIVE_BRANCH /* measurement only (tools/build_variant.sh): rounds 1-4's branch around the stores, for same-box A/Bs */
         if (active)
 #endif
 #pragma unroll
         for (int u = 0; u < R; ++u) {
-            if constexpr (io_half_spectrum<IO>::value) {
-                static_assert((LastG::out_index(0, 1) % TPT) == 0 && TPT <= N / 2, "register part and thread part of the index: disjoint bit fields");
-                if (LastG::out_index(0, u) < N / 2) io.store_d_acc_kept(od, lane_bytes, LastG::out_index(0, u), cur[u], row_off, acc);  // (a constant per u)
-            } else if constexpr (io_has_acc<IO>::value) io.store_d_acc(od, lane_bytes, LastG::out_index(0, u), cur[u], row_off, acc);
+            if constexpr (io_has_acc<IO>::value) io.store_d_acc(od, lane_bytes, LastG::out_index(0, u), cur[u], row_off, acc);
             else io.store_d(od, lane_bytes, LastG::out_index(0, u), cur[u], row_off);
+        }
         }
     }
 }

@@ -314,6 +314,52 @@ struct StftMagIO : StftIO {
         buf_store_f32(m, d, row_off + (lane_bytes >> 1), ou * 4);
         if (m > acc) acc = m;
     }
+    // Round 6: the NK kept magnitudes of one transform together.  sqrtf's expansion costs ~16 VALU instructions per
+    // root -- 3 to scale arguments below 2^-96 up by 2^32, v_sqrt_f32, 8 for the +-1 ulp correction (two fma residuals against the
+    // neighbours of the estimate), 2 to scale back, 2 to pass +-0 / +inf through -- and the kernel is VALU-bound (0.69 of the issue rate at
+    // 0.26 of HBM's).  The guard and the pass-through are decided ONCE per transform and wavefront here: when every sum of squares of the
+    // wavefront is a normal number >= 2^-96 or a NaN (min3 / max3 skip NaNs, and a NaN takes the same way through both forms), the roots
+    // are v_sqrt_f32 + the two-sided correction alone; otherwise (silence: zeros; subnormal or infinite sums) sqrtf as before.  Any
+    // correctly rounded root has the same bits: tools/ubench_sqrt.hip compares the short form with sqrtf on EVERY f32 in [2^-96, inf)
+    // (1 879 048 192 values, 0 mismatches; v_sqrt_f32 alone is 1 ulp low on 15 % and 1 ulp high on 0.006 % of them -- both corrections are needed).
+    __device__ __forceinline__ static float sqrt_cr_normal(const float x)
+    {
+        const float r = __builtin_amdgcn_sqrtf(x);
+        const float dn = __builtin_bit_cast(float, __builtin_bit_cast(int, r) - 1), up = __builtin_bit_cast(float, __builtin_bit_cast(int, r) + 1);
+        float y = r;
+        if (__builtin_fmaf(-dn, r, x) <= 0.0f) y = dn;
+        if (__builtin_fmaf(-up, r, x) > 0.0f) y = up;
+        return y;
+    }
+    template <int NK>
+    __device__ __forceinline__ static void mags_of(const cpx<float> (&v)[NK], float (&m)[NK])
+    {
+        float s[NK];
+#pragma unroll
+        for (int i = 0; i < NK; ++i) s[i] = v[i].re * v[i].re + v[i].im * v[i].im;
+        float lo = s[0], hi = s[0];
+#pragma unroll
+        for (int i = 1; i < NK; ++i) {
+            lo = __builtin_fminf(lo, s[i]);
+            hi = __builtin_fmaxf(hi, s[i]);
+        }
+#ifdef KOFFT_MAG_SQRTF /* measurement only (tools/build_variant.sh): round 5's roots, for same-box A/Bs */
+        const bool plain = false;
+#else
+        const bool plain = lo >= 0x1p-96f && hi < __builtin_inff();  // (all NaN: false)
+#endif
+        if (__builtin_amdgcn_ballot_w64(!plain) == 0) {  // wave-uniform
+#pragma unroll
+            for (int i = 0; i < NK; ++i) m[i] = sqrt_cr_normal(s[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NK; ++i) m[i] = sqrtf(s[i]);
+        }
+    }
+    __device__ __forceinline__ void store_d_mag(rsrc_t d, int lane_bytes, int ou, float m, int row_off) const
+    {
+        buf_store_f32(m, d, row_off + (lane_bytes >> 1), ou * 4);
+    }
     __device__ __forceinline__ rsrc_t out_desc_n(size_t xf0, int cnt) const
     {
         return make_rsrc(mags + (cnt > 0 ? xf0 : 0) * (size_t)(n / 2), (unsigned)(cnt > 0 ? cnt : 0) * (unsigned)(n / 2) * 4u);

@@ -29,6 +29,7 @@
 // ---------------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------------
+#define KOFFT_BIG_PROBE_MAX 8  /* candidates of the intermediate's placement probe (big_probe_pick) */
 struct kofft_hip_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -83,6 +84,10 @@ struct kofft_hip_ctx {
     bool big_row_pairs = true;       // KOFFT_HIP_BIG_ROW_PAIRS=0: c32 last factor one row per thread slot (8-row tiles) instead of row pairs (A/B)
     bool big_blocked = true;         // KOFFT_HIP_BIG_BLOCKED=0: natural layout of the two-factor intermediate (A/B)
     bool big_tmp_external = false;  // KOFFT_EXP_API builds only: the intermediate belongs to the experiment script
+    // placement probe of big_tmp (round 6, complex_impl.hip.h: big_probe_pick): candidates timed, figures of the last probe
+    int big_probe = 5;               // KOFFT_HIP_BIG_PROBE: candidate allocations per probe (0 / 1: take what hipMalloc hands out)
+    int big_probe_n = 0, big_probe_pick = -1;
+    float big_probe_first_us[KOFFT_BIG_PROBE_MAX] = {}, big_probe_total_us[KOFFT_BIG_PROBE_MAX] = {};
     // small host-pointer calls (one frame, one transform): a pinned, device-mapped buffer the kernels read and write
     // directly over PCIe -- one launch and one synchronisation instead of two staged copies around them
     void *pinned = nullptr;      // host address

@@ -8,6 +8,16 @@ template int fft_dev<float>(kofft_hip_ctx *, const float *, float *, size_t, siz
 template int fft_axis2_dev<float>(kofft_hip_ctx *, float *, int, int, size_t, int);
 template int fft_radix4_dev<float>(kofft_hip_ctx *, const float *, float *, size_t, size_t, int);
 template int fft_big_windowed_dev<float>(kofft_hip_ctx *, const float *, float *, const float *, size_t, size_t);
+// the column-tile pass of the fused 2-D route (k_nd_fused.hip declares these extern: one copy of the kernels in the library)
+#define KOFFT_CASE(LL)                                                                                                       \
+    template int launch_tile_persist<float, LL, AxisLastIO<float, false>>(kofft_hip_ctx *, const AxisLastIO<float, false> &, \
+                                                                          const cpx<float> *, size_t);                      \
+    template int launch_tile_persist<float, LL, AxisLastIO<float, true>>(kofft_hip_ctx *, const AxisLastIO<float, true> &,   \
+                                                                         const cpx<float> *, size_t);
+KOFFT_CASE(8)
+KOFFT_CASE(9)
+KOFFT_CASE(10)
+#undef KOFFT_CASE
 }  // namespace host
 }  // namespace kofft
 

@@ -7,6 +7,17 @@
 namespace kofft {
 namespace host {
 
+// the column-tile kernels live in k_complex_f32.o (explicit instantiations there): one copy in the library, not one per translation unit
+#define KOFFT_CASE(LL)                                                                                                              \
+    extern template int launch_tile_persist<float, LL, AxisLastIO<float, false>>(kofft_hip_ctx *, const AxisLastIO<float, false> &, \
+                                                                                 const cpx<float> *, size_t);                      \
+    extern template int launch_tile_persist<float, LL, AxisLastIO<float, true>>(kofft_hip_ctx *, const AxisLastIO<float, true> &,   \
+                                                                                const cpx<float> *, size_t);
+KOFFT_CASE(8)
+KOFFT_CASE(9)
+KOFFT_CASE(10)
+#undef KOFFT_CASE
+
 // fft2d_inplace of c32 images with 1024 / 2048 / 4096-point rows in TWO passes (fft_nd_fused.hip.h): rows + the columns' first two
 // stages into the scratch, the columns' remaining stages (frequency prefix K = 2 bits) back into the image.
 template <int LC, bool INVERSE>
@@ -44,8 +55,7 @@ int fft2d_fused_core(kofft_hip_ctx *ctx, cpx<float> *data, int LT)
     switch (LS) {
 #define KOFFT_CASE(LL) \
     case LL: return launch_tile_persist<float, LL, AxisLastIO<float, INVERSE>>(ctx, m, tw_col, units);
-        KOFFT_CASE(7)
-        KOFFT_CASE(8)
+        KOFFT_CASE(8)  // LS = LT - 2, LT = 10 .. 12 (fft2d_fused_ok)
         KOFFT_CASE(9)
         KOFFT_CASE(10)
 #undef KOFFT_CASE
@@ -56,7 +66,10 @@ int fft2d_fused_core(kofft_hip_ctx *ctx, cpx<float> *data, int LT)
 bool fft2d_fused_ok(const kofft_hip_ctx *ctx, size_t rows, size_t cols)
 {
     // (fewer than one group of four rows per CU: the three-pass route is faster -- 512 x 4096: 0.034 against 0.026 ms)
-    return ctx->nd_fused && ctx->big_persist && (cols == 1024 || cols == 2048 || cols == 4096) && is_pow2(rows) && rows >= 1024 && rows <= 4096 &&
+    // (KOFFT_HIP_NO_PERSIST=1 forces the generic kernels here too.  The units-per-CU floor of the factor path's tile kernels
+    // (big_persist_min_units) is NOT applied: its 4 x cols column units are 16 .. 64 per CU, and the route measured faster down to
+    // 1024-point rows on images of at least 32 MiB -- 4096 x 1024: 0.044 -> 0.034 ms -- which is the rule below.)
+    return ctx->nd_fused && ctx->use_persist && ctx->big_persist && (cols == 1024 || cols == 2048 || cols == 4096) && is_pow2(rows) && rows >= 1024 && rows <= 4096 &&
            rows / 4 >= (size_t)ctx->num_cus && rows * cols >= (size_t(1) << 22);  // (16 MiB images: 1024 x 2048 0.031 against 0.029 ms, 1024 x 1024 a tie)
 }
 

@@ -504,6 +504,7 @@ int kofft_hip_create(int device, kofft_hip_ctx **out)
     if (const char *e = getenv("KOFFT_HIP_ND_FUSED")) ctx->nd_fused = !(e[0] == '0');
     if (const char *e = getenv("KOFFT_HIP_BIG_ROW_PAIRS")) ctx->big_row_pairs = !(e[0] == '0');
     if (const char *e = getenv("KOFFT_HIP_BIG_BLOCKED")) ctx->big_blocked = !(e[0] == '0');
+    if (const char *e = getenv("KOFFT_HIP_BIG_PROBE")) ctx->big_probe = atoi(e);
     if (const char *e = getenv("KOFFT_HIP_BIG_CHUNK_MB")) {
         const long mb = atol(e);
         if (mb > 0) ctx->big_chunk_bytes = (size_t)mb << 20;
@@ -579,6 +580,18 @@ int kofft_hip_exp_malloc(size_t bytes, unsigned flags, void **out)
 int kofft_hip_exp_free(void *p) { return hipFree(p) == hipSuccess ? KOFFT_OK : KOFFT_ERR_HIP; }
 #endif
 
+int kofft_hip_big_probe_info(kofft_hip_ctx *ctx, float *first_us, float *total_us, int cap, int *n, int *pick)
+{
+    if (!ctx || !n || !pick) return KOFFT_ERR_NULL;
+    *n = ctx->big_probe_n;
+    *pick = ctx->big_probe_pick;
+    for (int i = 0; i < ctx->big_probe_n && i < cap; ++i) {
+        if (first_us) first_us[i] = ctx->big_probe_first_us[i];
+        if (total_us) total_us[i] = ctx->big_probe_total_us[i];
+    }
+    return KOFFT_OK;
+}
+
 int kofft_hip_release_scratch(kofft_hip_ctx *ctx)
 {
     if (!ctx) return KOFFT_ERR_NULL;
@@ -597,6 +610,8 @@ int kofft_hip_release_scratch(kofft_hip_ctx *ctx)
         *sizes[i] = 0;
     }
     ctx->big_tmp_external = false;  // (KOFFT_EXP_API builds: the script's intermediate is forgotten, the next call allocates its own)
+    ctx->big_probe_n = 0;
+    ctx->big_probe_pick = -1;
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     ctx->pinned = ctx->pinned_dev = nullptr;
     ctx->pinned_bytes = 0;

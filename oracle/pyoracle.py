@@ -199,6 +199,8 @@ def host_threads() -> int:
 
 def _run_blocks(total: int, threads: int | None, work) -> None:
     """work(first, count) over `total` units split into contiguous blocks, one thread each; the first failure is re-raised."""
+    if total <= 0:
+        return  # an empty batch: nothing to do, like the serial entries
     k = max(1, min(threads or host_threads(), total))
     per = -(-total // k)
     errs: list[BaseException] = []

@@ -207,6 +207,17 @@ def case_chunk(oracle):  # several chunks, the last one short
     _complex(oracle, "c32", 1 << 19, 40, 192, check=[0, 15, 16, 39], inverse=False)
 
 
+def case_probe_off(oracle):  # 160 MiB chunks: K candidate placements of the intermediate timed by default, none here
+    import kofft_amd
+
+    f = kofft_amd.HipFftImpl(np.float64)
+    x = rand_c(seeded(195), (10, 1 << 20), np.complex128)
+    y = x.copy()
+    f.fft_batch(y)
+    assert f.big_probe_info()["n"] == 0
+    assert bits_equal(y[[0, 9]], oracle.fft(x[[0, 9]]))
+
+
 KNOBS = [
     ("KOFFT_HIP_NO_PERSIST", "1", case_no_persist),
     ("KOFFT_HIP_PERSIST_GRID_PCT", "50", case_grid_pct),
@@ -234,6 +245,7 @@ KNOBS = [
     ("KOFFT_HIP_BIG_BLOCKED", "0", case_blocked),
     ("KOFFT_HIP_BIG_ROW_PAIRS", "0", case_big_persist),
     ("KOFFT_HIP_BIG_CHUNK_MB", "64", case_chunk),
+    ("KOFFT_HIP_BIG_PROBE", "0", case_probe_off),
 ]
 
 
@@ -241,3 +253,41 @@ KNOBS = [
 def test_route_switch_in_its_non_default_setting(oracle, monkeypatch, name, value, case):
     monkeypatch.setenv(name, value)
     case(oracle)
+
+
+def test_placement_probe_of_the_intermediate_runs_once_and_touches_nothing(oracle, monkeypatch):
+    """Round 6: the first large-n call of a context (full chunks of >= 128 MiB) times its factor kernels through K candidate
+    allocations of the intermediate -- on scratch input / output, so an IN-PLACE call's data is not transformed twice -- and keeps
+    the fastest.  Results are those of the oracle; the probe reports its candidates; a second call does not probe again; a smaller
+    call (no full 128 MiB chunk) does not probe at all; release_scratch forgets the pick."""
+    import torch
+
+    import kofft_amd as K
+
+    monkeypatch.delenv("KOFFT_HIP_BIG_PROBE", raising=False)
+    for dt, cdt, n, batch in ((np.float64, np.complex128, 1 << 20, 9), (np.float32, np.complex64, 1 << 20, 17)):
+        f = K.HipFftImpl(dt)
+        small = rand_c(seeded(301), (2, n), cdt)
+        y = small.copy()
+        f.fft_batch(y)
+        assert f.big_probe_info()["n"] == 0, "a 2-transform call is below the probe's threshold"
+        assert bits_equal(y, oracle.fft(small))
+        x = rand_c(seeded(302), (batch, n), cdt)
+        d = torch.from_numpy(x.view(dt).reshape(batch, n, 2)).to("cuda")
+        fn = f._fn(f"fft_{f._cplx}_dev")
+        import ctypes as C
+
+        assert fn(f._ctx, C.c_void_p(d.data_ptr()), n, batch, 0) == 0  # IN PLACE: the buffer grows, the probe runs
+        f.synchronize()
+        info = f.big_probe_info()
+        assert info["n"] == 5 and 0 <= info["pick"] < 5, info
+        assert info["total_us"][info["pick"]] == min(info["total_us"]) and min(info["first_us"]) > 0, info
+        got = d.cpu().numpy().view(cdt).reshape(batch, n)
+        pick = [0, batch // 2, batch - 1]
+        assert bits_equal(got[pick], oracle.fft(x[pick])), f"{cdt.__name__}: in-place result after the probe"
+        assert fn(f._ctx, C.c_void_p(d.data_ptr()), n, batch, 1) == 0  # no second probe: same figures
+        f.synchronize()
+        assert f.big_probe_info() == info
+        f.release_scratch()
+        assert f.big_probe_info()["n"] == 0
+        f.close()

@@ -80,7 +80,8 @@ def main():
     agg = defaultdict(list)
     per_kernel = defaultdict(lambda: defaultdict(list))
     steps_launched = {}
-    for tag in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    clk_samples = []  # (GRBM_GUI_ACTIVE summed over the 8 XCDs) / 8 / the dispatch's own duration = shader clock under this load, GHz
+    for tag in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_clk"):
         log = src / f"{tag}.log"
         if log.exists():  # the bench line of that pass says how many steps (C-ABI calls) it launched
             js = [ln for ln in log.read_text().splitlines() if ln.startswith("{")]
@@ -91,6 +92,10 @@ def main():
                 if "kofft" in r["Kernel_Name"]:
                     agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
                     per_kernel[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                    if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and r.get("End_Timestamp"):
+                        dur = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+                        if dur > 20000:  # (kernels of a few microseconds: the counter's bracket is wider than the kernel)
+                            clk_samples.append(float(r["Counter_Value"]) / 8.0 / dur)
     lines += ["", "## PMC (mean per launch of a kofft kernel)", "", "| counter | launches | mean |", "|---|---|---|"]
     for k, v in sorted(agg.items()):
         summary["pmc"][k] = sum(v) / len(v)
@@ -115,9 +120,31 @@ def main():
         lines += ["", f"HBM traffic per bench step ({len(agg['FETCH_SIZE']) / nf:.2f} kernel launches per step; guide's gfx950 correction: "
                   f"FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024): "
                   f"read {fetch / 1e9:.4f} GB + write {write / 1e9:.4f} GB = **{(fetch + write) / 1e9:.4f} GB**"]
+        issue = {}
+        tl = src / "trace_bench.log"
+        if tl.exists():  # which FORM of the workload the counters belong to (config #2: in place / out of place)
+            js = [ln for ln in tl.read_text().splitlines() if ln.startswith("{")]
+            ftxt = (json.loads(js[-1]).get("config", {}).get("form") or "") if js else ""
+            if ftxt:
+                issue["form"] = "inplace" if ftxt.startswith("in place") else "oop"
+        nsq = steps_launched.get("pmc_sq") or len(agg.get("SQ_INSTS_VALU", [])) or 1
+        if "SQ_INSTS_VALU" in agg:  # per bench STEP, like the traffic (a step may be several kernels)
+            issue["valu_insts_per_step"] = sum(agg["SQ_INSTS_VALU"]) / nsq
+        if "SQ_LDS_IDX_ACTIVE" in agg:
+            issue["lds_active_cycles_per_step"] = sum(agg["SQ_LDS_IDX_ACTIVE"]) / nsq
+        if clk_samples:
+            clk_samples.sort()
+            # /opt/skills/guides/MI355X_MICROARCH.md ("DVFS give-back"): the quotient reads HIGH on dispatches shorter than ~0.3 ms (the
+            # counter's bracket is a few microseconds wider than the kernel) and within 3 % on long ones: clamped to the 2400 MHz max clock
+            issue["shader_clock_ghz_raw"] = clk_samples[len(clk_samples) // 2]
+            issue["shader_clock_ghz"] = min(issue["shader_clock_ghz_raw"], 2.4)
+            issue["shader_clock_from"] = "median over dispatches of GRBM_GUI_ACTIVE / 8 XCDs / dispatch duration under this workload, clamped to the 2.4 GHz max clock"
+        if issue:
+            summary["issue"] = issue
+            lines += ["", "Issue-side figures per bench step: " + ", ".join(f"{k} {v:.6g}" for k, v in issue.items() if not isinstance(v, str))]
         (out_dir / f"traffic_{workload}.json").write_text(json.dumps(
             {"workload": workload, "hbm_bytes_per_step": fetch + write, "read_bytes": fetch, "write_bytes": write,
-             "kernels_per_step": len(agg["FETCH_SIZE"]) / nf, "from": f"profiles/{name}.md", **provenance(src)}) + "\n")
+             "kernels_per_step": len(agg["FETCH_SIZE"]) / nf, **issue, "from": f"profiles/{name}.md", **provenance(src)}) + "\n")
     if "SQ_LDS_BANK_CONFLICT" in agg:
         lines += ["", f"LDS bank-conflict cycles / LDS active cycles: {summary['pmc']['SQ_LDS_BANK_CONFLICT']:.0f} / "
                   f"{summary['pmc'].get('SQ_LDS_IDX_ACTIVE', 0):.0f}"]
@@ -142,6 +169,17 @@ def main():
                     lines += ["", f"Roofline fraction (algorithmic {alg / 1e9:.4f} GB per step / 8 TB/s): **{frac_stats:.4f}** from the --stats "
                               f"averages ({step_ns / 1e3:.1f} us of kofft kernels per step, all {steps_total} launches incl. ramp and warm-up), "
                               f"**{b['roofline']['frac']:.4f}** from bench.py's HIP events (timed steps only)."]
+                    iss = summary.get("issue", {})
+                    if "valu_insts_per_step" in iss and "shader_clock_ghz" in iss:
+                        # 4 cycles per wave64 VALU instruction on a SIMD16, 1024 SIMDs; one LDS pipe per CU, 256 CUs
+                        cyc = iss["shader_clock_ghz"] * step_ns
+                        valu = iss["valu_insts_per_step"] * 4 / (1024 * cyc)
+                        lds = iss.get("lds_active_cycles_per_step", 0.0) / (256 * cyc)
+                        hbm = summary.get("hbm_bytes_per_step", alg) / (step_ns * 1e-9) / 8e12
+                        summary["issue_frac"] = {"valu": valu, "lds": lds, "hbm_traffic": hbm}
+                        lines += ["", f"Which roofline binds (per step, {iss['shader_clock_ghz']:.3f} GHz measured): VALU issue **{valu:.3f}** "
+                                  f"(SQ_INSTS_VALU x 4 / (1024 SIMDs x clock x time)), LDS **{lds:.3f}** (SQ_LDS_IDX_ACTIVE / (256 CUs x clock x time)), "
+                                  f"HBM **{hbm:.3f}** (PMC traffic / time / 8 TB/s) -> bound: **{max((valu, 'valu'), (lds, 'lds'), (hbm, 'hbm'))[1]}**"]
     (out_dir / f"{name}.md").write_text("\n".join(lines) + "\n")
     (out_dir / f"{name}.json").write_text(json.dumps(summary, indent=1) + "\n")
     print("\n".join(lines))
