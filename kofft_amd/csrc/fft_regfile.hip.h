@@ -121,6 +121,13 @@ struct RfGeom {
         const int g = u >> QB1, c = u & ((1 << QB1) - 1);
         return (bitrev(c, QB1) << (QB0 + LA)) | ((g * TB) << LA);
     }
+    // the register that holds block sb of the output row (block = out_reg / TPT: every thread holds one position of every block)
+    __host__ __device__ static constexpr int u_of_block(int sb)
+    {
+        for (int u = 0; u < R; ++u)
+            if ((out_reg(u) / TPT) == sb) return u;
+        return 0;
+    }
 };
 
 template <class Gm, typename T>
@@ -175,6 +182,49 @@ struct IrfftRowIO : ComplexIO<T, true> {  // in: rows of n + 1 bins; out: rows o
     __device__ __forceinline__ rsrc_t in_desc_n(size_t xf0, int cnt) const
     {
         return make_rsrc(this->in + (cnt > 0 ? xf0 : 0) * (size_t)(this->n + 1), (unsigned)(cnt > 0 ? cnt : 0) * (unsigned)(this->n + 1) * (unsigned)sizeof(cpx<T>));
+    }
+};
+
+// rfft_direct (rfft.rs:425-465) of 2 N reals in ONE pass (round 6): the N-point transform of the packed row z[e] =
+// (x[2e], x[2e+1]) (optionally times the row window's pairs, as RowWindowIO) with the post-pass of rfft.rs:450-463 as the kernel's
+// epilogue -- out: rows of N + 1 bins.  Y[k] and Y[N - k] are in the same workgroup (the whole transform is), so after pass B1 the results go
+// through the exchange region once more, in NATURAL order, the real parts and then the imaginary parts (one real per cell), and every thread
+// computes X[k] for k = kk + 1024 s, kk = (thread - a) mod 1024 with a = the output row's offset into its 128-byte line: every wavefront
+// stores whole lines although rows are N + 1 values long (the lane rotation of the smaller kernels' EPI_RFFT).
+template <class IO, class = void>
+struct rf_rfft_epi { static constexpr bool value = false; };
+template <class IO>
+struct rf_rfft_epi<IO, decltype((void)IO::kRfftEpi)> { static constexpr bool value = IO::kRfftEpi; };
+template <typename T, bool WIN>
+struct RfftRowIO : ComplexIO<T, false> {  // in: rows of n complex = 2n reals; `out`: rows of n + 1 bins
+    static constexpr bool kRowWindow = WIN;
+    static constexpr bool kRfftEpi = true;
+    const cpx<T> *__restrict__ win;   // the row window as n pairs (WIN), else unused
+    const cpx<T> *__restrict__ rtab;  // build_twiddle_table(n), rfft.rs:172-183
+    __device__ __forceinline__ rsrc_t out_desc_row(size_t xf) const
+    {
+        return make_rsrc(this->out + xf * (size_t)(this->n + 1), (unsigned)(this->n + 1) * (unsigned)sizeof(cpx<T>));
+    }
+    // elements between the start of output row xf and the previous 128-byte line boundary
+    __device__ __forceinline__ int row_misalign(size_t xf) const
+    {
+        return (int)((reinterpret_cast<size_t>(this->out) / sizeof(cpx<T>) + xf * (size_t)(this->n + 1)) & (128 / sizeof(cpx<T>) - 1));
+    }
+    __device__ __forceinline__ static cpx<T> post_w(cpx<T> w, cpx<T> a, cpx<T> ymk)  // X[k], 1 <= k < n (rfft.rs:454-463)
+    {
+#ifndef KOFFT_BFLY_NOASM
+        if constexpr (sizeof(T) == 4) {
+            const v2f wv = {w.re, w.im}, av = {a.re, a.im}, yv = {ymk.re, ymk.im};
+            const v2f x = rfft_post_f32_pk(wv, av, yv);
+            return mk<T>(x.x, x.y);
+        }
+#endif
+        const T half = T(0.5f);
+        const cpx<T> b = mk<T>(ymk.re, -ymk.im);
+        const cpx<T> sum = cadd(a, b), diff = csub(a, b);
+        const cpx<T> t = cmul(w, diff);
+        const cpx<T> temp = cadd(sum, mk<T>(t.im, -t.re));
+        return mk<T>(temp.re * half, temp.im * half);
     }
 };
 
@@ -453,6 +503,103 @@ __global__ __launch_bounds__(1024, 4) void fft_regfile_persist_kernel(const IO i
 #pragma unroll
             for (int u = 0; u < R; ++u) cur[u].im = Cell::ld(a ^ Gm::b1_in_reg(u));
         }
+        if constexpr (rf_rfft_epi<IO>::value) {
+            // ---- rfft epilogue.  Pass B1 on every group first (results stay in registers), then two rounds through the exchange region.
+#pragma unroll
+            for (int g = 0; g < GB1; ++g) {
+                reg_pass_r<T, QB1>(cur + g * (1 << QB1), twb[g % NTW]);
+                split_pin();
+                if (g + NTW < GB1) load_twb(g + NTW, twb[g % NTW]);
+                split_pin();
+            }
+            KOFFT_RF_STAMP(8)
+            // Two rounds through the exchange region, WHOLE complex values in natural order: half the row fills it.  The row is STEPS blocks of
+            // TPT elements, k = s TPT + p; X[k] needs Y[k] and Y[N - k] = block STEPS - 1 - s, position TPT - p (p != 0).  Round 1 carries the
+            // blocks s < H and s >= 3H, round 2 the blocks H <= s < 3H (H = STEPS / 4): both sets are closed under s -> STEPS - 1 - s, and with
+            // sp = the block's rank in its round the mirror block is 2H - 1 - sp in both.  Every thread holds ONE position of every block after
+            // pass B1 (tauB; block = out_reg(u) / TPT, a constant per register), so it writes half of its registers in each round -- no thread
+            // and no wavefront sits a round out, and after round 1's writes half of cur[] is dead everywhere -- and it computes the outputs of
+            // position kk = (thread - a) mod TPT (a = the output row's offset into its 128-byte line: every 16 lanes store whole lines although
+            // rows are N + 1 values long), half of the blocks per round.  Consecutive lanes touch consecutive cells both ways: no conflict.
+            // Position 0 is the exception: its mirror is position 0 of block STEPS - s, i.e. rank 2H - sp instead of 2H - 1 - sp -- one block
+            // further (folded into its thread's mirror base) -- which stays inside the round for every block but the pair (H, 3H): those two
+            // outputs are computed by the thread that HOLDS both values after pass B1 (tauB = 0: thread 0 has position 0 of every block).
+            constexpr int STEPS = Gm::N / Gm::TPT, H = STEPS / 4, BLK = Gm::TPT * ES, TPT_LOG = Gm::L - Gm::RLOG;
+            static_assert(STEPS == R && (1 << TPT_LOG) == Gm::TPT && 2 * H * BLK == Gm::N * Gm::CELL, "epilogue geometry: half the row fills the region");
+            const int a = io.row_misalign(xf);
+            const int kk = (int)((fresh((unsigned)tid) - (unsigned)a) & (unsigned)(Gm::TPT - 1));
+            const rsrc_t wd = make_rsrc(io.rtab, (unsigned)Gm::N * (unsigned)ES);
+            const rsrc_t xd = io.out_desc_row(xf);
+            const int wr = tau_b() * ES;                                      // this thread's position in every block
+            const int ry = kk * ES;                                           // Y[kk + s TPT]
+            const int rm = ((Gm::TPT - kk) & (Gm::TPT - 1)) * ES + (kk == 0 ? BLK : 0);  // Y[N - k]: position TPT - kk of the mirror block (position 0: one block further)
+            const int lane_w = kk * ES;
+            const int lane_x = kk == 0 ? 0x40000000 : kk * ES;                // blocks H and 3H of position 0 are thread 0's: beyond the descriptor, dropped
+            const int in_lane_bytes = tau_a() * (int)IO::kRawBytes;
+            constexpr int CH = sizeof(T) == 4 ? 4 : 2;
+#pragma unroll
+            for (int rnd = 0; rnd < 2; ++rnd) {
+                // block s -> (its round, its rank there)
+                auto in_round = [&](const int sb) { return ((sb < H) || (sb >= 3 * H)) == (rnd == 0); };
+                auto rank = [&](const int sb) { return rnd == 0 ? (sb < H ? sb : sb - 2 * H) : sb - H; };
+                auto block_of = [&](const int sp) { return rnd == 0 ? (sp < H ? sp : sp + 2 * H) : sp + H; };
+                __syncthreads();  // the region is free: every wavefront has gathered its last values (round 1) / computed round 1's outputs (round 2)
+#pragma unroll
+                for (int u = 0; u < R; ++u)
+                    if (in_round(Gm::out_reg(u) >> TPT_LOG)) Lds::st(wr + rank(Gm::out_reg(u) >> TPT_LOG) * BLK, cur[u]);
+                if (rnd == 0 && tid == 0) {  // X[H TPT] and X[3H TPT] (rfft.rs:454-463)
+                    const cpx<T> y1 = cur[Gm::u_of_block(H)], y3 = cur[Gm::u_of_block(3 * H)];
+                    const cpx<T> w1 = buf_load_cpx<T, AUX_DEFAULT>(wd, 0, H * BLK), w3 = buf_load_cpx<T, AUX_DEFAULT>(wd, 0, 3 * H * BLK);
+                    io.store_d(xd, 0, H * Gm::TPT, IO::post_w(w1, y1, y3), 0);
+                    io.store_d(xd, 0, 3 * H * Gm::TPT, IO::post_w(w3, y3, y1), 0);
+                }
+                // the table entries of this round's outputs travel across the barrier (half of cur[] is dead after round 1's writes, all of it
+                // after round 2's); in round 2 the next transform's inputs follow them into cur[]'s registers -- BEHIND the table loads: vmcnt
+                // counts in issue order, a table entry requested after them would wait for them
+                cpx<T> wv[2 * H];
+                split_pin();
+#pragma unroll
+                for (int j = 0; j < 2 * H; ++j) wv[j] = buf_load_cpx<T, AUX_DEFAULT>(wd, lane_w, block_of(j) * BLK);
+                if (rnd == 1) {  // (the first half now, the second when half of this round's table entries have been used: registers)
+#pragma unroll
+                    for (int u = 0; u < R / 2; ++u) raw[u] = io.fetch_d(nd, in_lane_bytes, u * Gm::TPT, 0);
+                }
+                split_pin();
+                __syncthreads();
+#pragma unroll
+                for (int c = 0; c < 2 * H; c += CH) {
+                    if (rnd == 1 && c == H) {
+                        split_pin();
+#pragma unroll
+                        for (int u = R / 2; u < R; ++u) raw[u] = io.fetch_d(nd, in_lane_bytes, u * Gm::TPT, 0);
+                        split_pin();
+                    }
+                    cpx<T> ya[CH], yb[CH];
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) {
+                        ya[j] = Lds::ld(ry + (c + j) * BLK);
+                        yb[j] = Lds::ld(rm + (2 * H - 1 - c - j) * BLK);
+                    }
+                    if (rnd == 1 && c + CH >= 2 * H) {
+                        if constexpr (SPLITBAR) {
+                            // arrive: this wavefront has read the transform out of the region (the counter add follows the reads in the LDS
+                            // queue only if it is issued after the wait)
+                            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                            if (lane == 0) __hip_atomic_fetch_add((lds_u32 *)(size_t)(unsigned)COUNTER, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) {
+                        const int sb = block_of(c + j);
+                        cpx<T> x = IO::post_w(wv[c + j], ya[j], yb[j]);
+                        if (sb == 0 && kk == 0) x = mk<T>(ya[j].re + ya[j].im, T(0));  // X[0] (rfft.rs:451)
+                        io.store_d(xd, (sb == H || sb == 3 * H) ? lane_x : lane_w, sb * Gm::TPT, x, 0);
+                        if (sb == 0 && kk == 0) io.store_d(xd, 0, Gm::N, mk<T>(ya[j].re - ya[j].im, T(0)), 0);  // X[N] (rfft.rs:452)
+                    }
+                }
+            }
+        } else {
         if constexpr (SPLITBAR) {
         // arrive: this wavefront's rows are free (the values just gathered have landed: the counter add follows them in the LDS queue
         // only if it is issued after the wait)
@@ -480,6 +627,7 @@ __global__ __launch_bounds__(1024, 4) void fft_regfile_persist_kernel(const IO i
             for (int u = g << QB1; u < ((g + 1) << QB1); ++u) raw[u] = io.fetch_d(nd, in_lane_bytes, u * Gm::TPT, 0);
 #endif
             split_pin();
+        }
         }
         KOFFT_RF_STAMP(9)
         if (!more) break;

@@ -69,6 +69,7 @@ struct kofft_hip_ctx {
     int persist64 = 1;         // KOFFT_HIP_PERSIST64=0: c64 n = 4096 / 8192 on the generic kernel (A/B measurements)
     bool persist_small = true; // KOFFT_HIP_PERSIST_SMALL=0: n = 128, 256 on the generic kernels (A/B measurements)
                                // double-buffered one (measured, same box: c32 0.52-0.53 against 0.61-0.63, STFT 0.41 against 0.43)
+    bool rfft_regfile_epi = true;  // KOFFT_HIP_RFFT_REGFILE_EPI=0: rfft of 65536 (f32) / 32768 (f64) reals as register-file transform + post-pass kernel (two passes) instead of one (A/B)
     bool use_regfile = true;   // KOFFT_HIP_REGFILE=0: c32 2^15 / c64 2^14 on the two-factor path instead of the register-file-resident kernel (A/B)
     bool use_split = true;     // KOFFT_HIP_SPLIT=0: n = 8192 on the block-synchronised persistent kernel instead of the wave-split one (A/B)
     std::string last_error;

@@ -493,6 +493,7 @@ int kofft_hip_create(int device, kofft_hip_ctx **out)
     if (const char *e = getenv("KOFFT_HIP_PERSIST_SMALL")) ctx->persist_small = !(e[0] == '0');
     if (const char *e = getenv("KOFFT_HIP_SPLIT")) ctx->use_split = !(e[0] == '0');
     if (const char *e = getenv("KOFFT_HIP_REGFILE")) ctx->use_regfile = !(e[0] == '0');
+    if (const char *e = getenv("KOFFT_HIP_RFFT_REGFILE_EPI")) ctx->rfft_regfile_epi = !(e[0] == '0');
     if (const char *e = getenv("KOFFT_HIP_HOST_PIPELINE")) ctx->host_pipeline = !(e[0] == '0');
     if (const char *e = getenv("KOFFT_HIP_ZERO_COPY")) ctx->zero_copy = !(e[0] == '0');
     if (const char *e = getenv("KOFFT_HIP_ND_TRANSPOSE")) ctx->nd_transpose = !(e[0] == '0');

@@ -139,6 +139,24 @@ int rfft_composed_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, const T *d_wi
     for (size_t b0 = 0; b0 < batch; b0 += chunk) {
         const size_t nb = (batch - b0 < chunk) ? batch - b0 : chunk;
         const T *src = d_in + b0 * n;
+        if (m == (size_t(2) << max_log2<T>()) && ctx->use_regfile && ctx->rfft_regfile_epi && nb >= (size_t)ctx->num_cus * 2) {
+            // Round 6: m = 2^15 (f32) / 2^14 (f64) in ONE pass -- the register-file kernel with the post-pass as its epilogue (fft_regfile.hip.h:
+            // RfftRowIO; Y[k] and Y[m - k] are in the same workgroup), the window on its loads: no intermediate, no rfft_post_kernel launch
+            const cpx<T> *tw = nullptr;
+            rc = get_table<T>(ctx, Kind<T>::tw, m, &tw);
+            if (rc) return rc;
+            constexpr int RLA = sizeof(T) == 4 ? 8 : 7, RLB = 7, RQB0 = 4;  // as fft_dev routes the plain transform
+            cpx<T> *dst = reinterpret_cast<cpx<T> *>(d_out) + b0 * (m + 1);
+            if (d_window) {
+                RfftRowIO<T, true> io{{{}, reinterpret_cast<const cpx<T> *>(src), dst, (int)m, (T)1}, reinterpret_cast<const cpx<T> *>(d_window), rtab};
+                rc = launch_regfile<T, RLA, RLB, RQB0>(ctx, io, tw, nb);
+            } else {
+                RfftRowIO<T, false> io{{{}, reinterpret_cast<const cpx<T> *>(src), dst, (int)m, (T)1}, nullptr, rtab};
+                rc = launch_regfile<T, RLA, RLB, RQB0>(ctx, io, tw, nb);
+            }
+            if (rc) return rc;
+            continue;
+        }
         if (regfile_window && nb >= (size_t)ctx->num_cus * 2) {
             const cpx<T> *tw = nullptr;
             rc = get_table<T>(ctx, Kind<T>::tw, m, &tw);

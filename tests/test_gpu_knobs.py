@@ -207,6 +207,18 @@ def case_chunk(oracle):  # several chunks, the last one short
     _complex(oracle, "c32", 1 << 19, 40, 192, check=[0, 15, 16, 39], inverse=False)
 
 
+def case_rfft_regfile_two_passes(oracle):  # rfft of 65536 (f32) / 32768 (f64) reals: one pass by default (post-pass = the kernel's epilogue), two here
+    import kofft_amd
+
+    for dt, n in ((np.float32, 65536), (np.float64, 32768)):
+        f = kofft_amd.HipFftImpl(dt)
+        rows = seeded(64 + n).uniform(-1, 1, (530, n)).astype(dt)
+        win = seeded(65 + n).uniform(0.1, 1, n).astype(dt)
+        pick = _edges(530)
+        assert bits_equal(f.rfft_batch(rows)[pick], oracle.rfft(rows[pick])), f"rfft {n}"
+        assert bits_equal(f.rfft_batch(rows, win)[pick], oracle.rfft(rows[pick], win)), f"windowed rfft {n}"
+
+
 def case_probe_off(oracle):  # 160 MiB chunks: K candidate placements of the intermediate timed by default, none here
     import kofft_amd
 
@@ -231,6 +243,7 @@ KNOBS = [
     ("KOFFT_HIP_PERSIST_SMALL", "0", case_persist_small),
     ("KOFFT_HIP_SPLIT", "0", case_split),
     ("KOFFT_HIP_REGFILE", "0", case_regfile),
+    ("KOFFT_HIP_RFFT_REGFILE_EPI", "0", case_rfft_regfile_two_passes),
     ("KOFFT_HIP_HOST_PIPELINE", "0", case_host_pipeline),
     ("KOFFT_HIP_ZERO_COPY", "0", case_zero_copy),
     ("KOFFT_HIP_ND_TRANSPOSE", "0", case_nd_transpose),
