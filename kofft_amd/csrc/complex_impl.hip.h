@@ -133,6 +133,11 @@ int launch_sub_one_tile(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size
     return launch_wg<T, LL, EPI_STORE, IO, B0>(ctx, io, tw, units);
 }
 
+// smallest sub-transform a policy is launched with (launch_sub): 2^5 for the plain first-factor policy (ndfft's two-pass axes), 2^7 otherwise
+template <class IO> struct sub_min_ls_of { static constexpr int value = 7; };
+template <typename T, bool INVERSE> struct sub_min_ls_of<BigColsIO<T, INVERSE, 0>> { static constexpr int value = 5; };
+template <class IO> constexpr int sub_min_ls() { return sub_min_ls_of<IO>::value; }
+
 // Launch the generic kernel for a sub-transform of log2 size LS with an arbitrary IO policy.
 template <typename T, class IO>
 int launch_sub(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, int LS, size_t units, bool persist)
@@ -155,23 +160,27 @@ int launch_sub(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, int LS, size_
         default: break;  // 2^11 .. 2^13-point factors: tiles of 4, 2, 1 units -- the one-tile-per-workgroup kernel
         }
     }
+    // Sizes a default route can reach (round 6: the instantiations nothing reaches are gone).  The factor path's sub-transforms are 2^7 .. 2^11
+    // points: two factors up to 2^22 = 2^11 x 2^11 (fft_big_core forces three factors from 2^23 whatever KOFFT_HIP_BIG_THREE_MIN says), three
+    // factors of 7 .. 9 bits beyond.  2^5 / 2^6 only as the first pass of ndfft's two-pass axes, i.e. a first-factor policy without a folded
+    // pointwise factor (sub_min_ls).
     switch (LS) {
     // 16 (c32) / 8 (c64) adjacent columns or rows per workgroup = 128-byte segments while the tile fits the LDS budget
     // (sub-transforms up to 2^9 points; 2^10: 8; larger ones fewer still -- big_block).
-    case 5: return launch_wg<T, 5, EPI_STORE, IO, big_block<T, IO, 5>()>(ctx, io, tw, units);  // (ndfft's two-pass axes only)
-    case 6: return launch_wg<T, 6, EPI_STORE, IO, big_block<T, IO, 6>()>(ctx, io, tw, units);
+    case 5:
+        if constexpr (sub_min_ls<IO>() <= 5) return launch_wg<T, 5, EPI_STORE, IO, big_block<T, IO, 5>()>(ctx, io, tw, units);
+        break;
+    case 6:
+        if constexpr (sub_min_ls<IO>() <= 6) return launch_wg<T, 6, EPI_STORE, IO, big_block<T, IO, 6>()>(ctx, io, tw, units);
+        break;
     case 7: return launch_sub_one_tile<T, 7, IO>(ctx, io, tw, units);
     case 8: return launch_sub_one_tile<T, 8, IO>(ctx, io, tw, units);
     case 9: return launch_sub_one_tile<T, 9, IO>(ctx, io, tw, units);
     case 10: return launch_sub_one_tile<T, 10, IO>(ctx, io, tw, units);
-#define KOFFT_CASE(LL) \
-    case LL: return launch_wg<T, LL, EPI_STORE, IO, big_block<T, IO, LL>()>(ctx, io, tw, units);
-        KOFFT_CASE(11)
-        KOFFT_CASE(12)
-        KOFFT_CASE(13)
-#undef KOFFT_CASE
-    default: return KOFFT_ERR_UNSUPPORTED;
+    case 11: return launch_wg<T, 11, EPI_STORE, IO, big_block<T, IO, 11>()>(ctx, io, tw, units);
+    default: break;
     }
+    return KOFFT_ERR_UNSUPPORTED;
 }
 
 // Sub-transforms of the middle factor are at most 2^9 points (three factors cover 2^21 .. 2^26 with 7..9 bits each).
@@ -396,7 +405,8 @@ int fft_big_core(kofft_hip_ctx *ctx, const cpx<T> *in_base, size_t in_row, cpx<T
     // Two factors while both stay <= 2^10 points (tiles of 8 adjacent columns / rows, 64..128-byte segments); from 2^22
     // on, three factors of 7..9 bits: one more pass over HBM, but every pass keeps full-width tiles (two factors of
     // 11..13 bits shrink the tiles to 4, 2, 1 columns and fall to 0.05..0.16 of the roofline).
-    const bool three = L >= ctx->big_three_min && !ctx->big_two_only;  // measured crossover, KOFFT_HIP_BIG_THREE_MIN
+    // measured crossover, KOFFT_HIP_BIG_THREE_MIN; from 2^23 always three (two factors would need 2^12-point sub-transforms: tiles of 2 columns)
+    const bool three = (L >= ctx->big_three_min && !ctx->big_two_only) || L >= 23;
     // two factors of an odd L: the larger one first when the persistent first-factor kernel covers it (c32, 2^11 points)
     // (only for batches the persistent kernels take: a single 2^21-point transform is faster as 2^10 x 2^11, 31.7 vs 33.6 us)
     const bool first11 = ctx->big_first11 && ctx->big_persist && L == 21 && !three &&

@@ -787,7 +787,10 @@ constexpr bool wg_split_lds()
 #define KOFFT_RFFT_CHUNK_STORE 1
 #endif
 template <typename T, int L, int RL, int BLOCK, int EPI, class IO>
-__global__ __launch_bounds__(BLOCK, (IO::kMinWaves > 1 && BLOCK == 512 && L >= 9 && L <= 11) ? IO::kMinWaves : (wg_split_lds<T, L, EPI, IO>() && !IO::kSplitLds ? 2 : 1)) void fft_wg_kernel(const IO io, const cpx<T> *__restrict__ tw, const size_t batch)
+// (round 6: the factor policies' two-workgroups-per-CU bound -- kMinWaves = 4 in f64, i.e. 128 registers -- now holds at L = 9 only: at L = 10 / 11 the
+// c64 kernels spilled 10 .. 38 registers under it (44 .. 156 bytes of scratch per lane); they are the fallback of batches of 2 .. 7 large transforms,
+// and one workgroup per CU without scratch replaces two with it)
+__global__ __launch_bounds__(BLOCK, (IO::kMinWaves > 1 && BLOCK == 512 && L == 9) ? IO::kMinWaves : (wg_split_lds<T, L, EPI, IO>() && !IO::kSplitLds ? 2 : 1)) void fft_wg_kernel(const IO io, const cpx<T> *__restrict__ tw, const size_t batch)
 {
     constexpr int N = 1 << L;
     constexpr int R = 1 << RL;

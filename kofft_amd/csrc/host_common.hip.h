@@ -40,19 +40,19 @@ struct kofft_hip_ctx {
     bool istft_fused = true;  // KOFFT_HIP_ISTFT_FUSED=0: ISTFT always as inverse transforms + the overlap-add kernel
     bool blue_persist = true; // KOFFT_HIP_BLUESTEIN_PERSIST=0: the one-launch Bluestein arm always as one workgroup per XPB transforms
     int persist_grid_pct = 0; // KOFFT_HIP_PERSIST_GRID_PCT: scale the persistent grids (measurements only)
-    bool big_two_only = false; // KOFFT_HIP_BIG_TWO_FACTORS=1: never split into three factors (A/B measurements)
+    bool big_two_only = false; // (a member only -- no environment variable since round 4) never split into three factors (A/B measurements)
     int big_three_min = 22;    // KOFFT_HIP_BIG_THREE_MIN: smallest log2 n split into three factors
     bool small32 = true;       // KOFFT_HIP_SMALL32=0: f32 n = 32 on the thread-group kernel instead of one thread per transform (A/B)
     bool big_first11 = true;   // KOFFT_HIP_BIG_FIRST11=0: 2^21 as 2^10 x 2^11 with the one-tile-per-workgroup kernel for the 2^11 factor (A/B)
-    bool big_mid_group = true; // KOFFT_HIP_BIG_MID_GROUP=0: the middle factor reloads its table entries for every tile (A/B)
-    int big_first_larger = -1; // KOFFT_HIP_BIG_FIRST_LARGER=0/1: odd log2 n: which factor takes the extra bit (default: the first in f32)
+    bool big_mid_group = true; // (a member only -- no environment variable since round 4) the middle factor reloads its table entries for every tile (A/B)
+    int big_first_larger = -1; // (a member only -- no environment variable since round 4) odd log2 n: which factor takes the extra bit (default: the first in f32)
     bool big_narrow = true;    // KOFFT_HIP_BIG_NARROW=0: full-width tiles even when they leave CUs without a workgroup (A/B)
-    int big_narrow_per_cu = 1; // KOFFT_HIP_BIG_NARROW_PER_CU: workgroups per CU the narrowing aims for
+    int big_narrow_per_cu = 1; // (a member only -- no environment variable since round 4) workgroups per CU the narrowing aims for
     bool big_persist = true;   // KOFFT_HIP_BIG_PERSIST=0: factors on the one-tile-per-workgroup kernel (A/B measurements)
-    size_t big_persist_min_units = 32;  // KOFFT_HIP_BIG_PERSIST_MIN_UNITS: units (columns / rows) per CU from which the persistent factor kernels run
-    int big_first_persist = -1;  // KOFFT_HIP_BIG_FIRST_PERSIST=0/1: first factor one tile per workgroup / persistent (default: big_persist)
+    size_t big_persist_min_units = 32;  // (a member only -- no environment variable since round 4) units (columns / rows) per CU from which the persistent factor kernels run
+    int big_first_persist = -1;  // (a member only -- no environment variable since round 4) first factor one tile per workgroup / persistent (default: big_persist)
     int big_last_mode = -1;      // (compile-time only since round 4; no getenv) last factor one tile per workgroup / generic persistent / rows resident
-    bool big_rows_resident = true;  // KOFFT_HIP_BIG_ROWS_RESIDENT=0: last factor on the generic tile kernel (A/B measurements)
+    bool big_rows_resident = true;  // (a member only -- no environment variable since round 4) last factor on the generic tile kernel (A/B measurements)
     int big_mid_nt = -1;       // (compile-time only since round 4; no getenv) force plain / streaming loads of the intermediate (default: by chunk size)
     bool blue_fused = true;    // KOFFT_HIP_BLUESTEIN_FUSED=0: pointwise steps as separate kernels at every size
     bool blue_one_kernel = true;  // KOFFT_HIP_BLUESTEIN_ONE=0: two launches through a scratch even where one workgroup holds m points
@@ -60,10 +60,10 @@ struct kofft_hip_ctx {
     bool nd_fused = true;      // KOFFT_HIP_ND_FUSED=0: 2-D c32 images with 1024 .. 4096-point rows through rows + two column-tile passes instead of the fused two passes (A/B)
     bool nd_two_pass = true;   // KOFFT_HIP_ND_TWO_PASS=0: power-of-two axes of 4096 .. 16384 points through the transposes instead of two column-tile passes (A/B)
     int nd_two_pass_l1 = 0;    // (compile-time only since round 4; no getenv) log2 of the first pass's sub-transform (default LT - 7)
-    int nd_transpose_min = 4096;  // KOFFT_HIP_ND_TRANSPOSE_MIN: shortest axis that takes the transpose route (measured: 1024 loses, 2048 ties)
+    int nd_transpose_min = 4096;  // (a member only -- no environment variable since round 4) shortest axis that takes the transpose route (measured: 1024 loses, 2048 ties)
     bool zero_copy = true;     // KOFFT_HIP_ZERO_COPY=0: small host calls through staged copies like large ones
     bool host_pipeline = true; // KOFFT_HIP_HOST_PIPELINE=0: host-pointer batches in one upload / kernel / download
-    int host_chunks = 0;       // KOFFT_HIP_HOST_CHUNKS: pieces of a pipelined host batch (default 8)
+    int host_chunks = 0;       // (a member only -- no environment variable since round 4) pieces of a pipelined host batch (default 8)
     bool rfft14_wide = true;    // KOFFT_HIP_RFFT14_WIDE=0: rfft / irfft of 32768 reals on the generic kernel
     bool rfft13_persist = true; // KOFFT_HIP_RFFT13_PERSIST=0: rfft / irfft n = 16384 on the generic kernel
     int persist64 = 1;         // KOFFT_HIP_PERSIST64=0: c64 n = 4096 / 8192 on the generic kernel (A/B measurements)

@@ -2,7 +2,7 @@
 """Bit-equality of two dispatch routes of the same call, on one box: the environment knobs named on the command line are
 set for context B only (contexts read them when they are created).
 
-usage: python3 tools/ab_route_equal.py KOFFT_HIP_SPLIT14=1 [--kinds fft,rfft,rfftw,irfft,stft,stftmag,fft64,ifft64] [--n 16384] [--batch 1300]"""
+usage: python3 tools/ab_route_equal.py KOFFT_HIP_SPLIT=0 [--kinds fft,rfft,rfftw,irfft,stft,stftmag,fft64,ifft64] [--n 16384] [--batch 1300]"""
 import argparse
 import os
 import sys
