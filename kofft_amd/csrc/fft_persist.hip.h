@@ -400,16 +400,11 @@ __device__ __forceinline__ void persist_transform(const typename persist_raw<IO,
             for (int u = 0; u < R; ++u)
                 if (LastG::out_index(0, u) < N / 2) kept[ki++] = cur[u];  // (a constant per u)
             float m[NK];
-            IO::template mags_of<NK>(kept, m);
-            typename IO::Acc top = m[0];
+            const typename IO::Acc top = IO::template mags_of<NK>(kept, m);  // the largest sum of squares (StftMagIO: the accumulator's unit)
             ki = 0;
 #pragma unroll
             for (int u = 0; u < R; ++u)
-                if (LastG::out_index(0, u) < N / 2) {
-                    io.store_d_mag(od, lane_bytes, LastG::out_index(0, u), m[ki], row_off);
-                    top = __builtin_fmaxf(top, m[ki]);  // (NaN never selected, like `if mag > max_mag`, spectrogram.rs:68-70; magnitudes are >= +0)
-                    ++ki;
-                }
+                if (LastG::out_index(0, u) < N / 2) io.store_d_mag(od, lane_bytes, LastG::out_index(0, u), m[ki++], row_off);
             if (active) acc = __builtin_fmaxf(acc, top);
         } else {
 #ifdef KOFFT_PERSIST_ACTIVE_BRANCH /* measurement only (tools/build_variant.sh): rounds 1-4's branch around the stores, for same-box A/Bs */

@@ -36,7 +36,7 @@ template <class IO, class = void>
 struct io_frame_rem { static constexpr bool value = false; };
 template <class IO>
 struct io_frame_rem<IO, decltype((void)IO::kFrameRem)> { static constexpr bool value = IO::kFrameRem; };
-// policies that keep bins 0 .. n/2-1 only and offer store_d_acc_kept (StftMagIO)
+// policies that keep bins 0 .. n/2-1 only and offer mags_of / store_d_mag (StftMagIO)
 template <class IO, class = void>
 struct io_half_spectrum { static constexpr bool value = false; };
 template <class IO>
@@ -267,30 +267,29 @@ struct StftIO : PlainTw {
 struct StftMagIO : StftIO {
     float *__restrict__ mags;  // frames x n/2
     unsigned *__restrict__ max_bits;  // the maximum magnitude, as the bit pattern of a non-negative f32 (zeroed by the caller)
-    // The maximum rides on the stores: every thread keeps the largest magnitude it has stored (`if mag > max_mag`,
-    // spectrogram.rs:68-70: a NaN is never selected), and when the kernel is done each wavefront reduces its lanes and
-    // issues ONE atomicMax.  Non-negative floats order like their bit patterns, so the unsigned maximum is exact whatever
-    // the order of arrival; no second pass over the magnitudes.
+    // The maximum rides on the stores (`if mag > max_mag`, spectrogram.rs:68-70: a NaN is never selected).  Round 6: what every thread
+    // keeps is the largest SUM OF SQUARES it has rooted -- a correctly rounded square root is monotone, so the largest magnitude IS the root of
+    // the largest sum, bit for bit (fmaxf skips NaNs like the reference's comparison; sums are >= +0) -- and the one root is taken when the
+    // kernel is done: each wavefront reduces its lanes and issues ONE atomicMax.  Non-negative floats order like their bit patterns, so the
+    // unsigned maximum is exact whatever the order of arrival; no second pass over the magnitudes.
     static constexpr bool kHasAcc = true;
     using Acc = float;
     __device__ __forceinline__ Acc acc_init() const { return 0.0f; }
-    __device__ __forceinline__ void acc_finish(Acc m) const
+    __device__ __forceinline__ void acc_finish(Acc s) const
     {
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const float o = __shfl_xor(m, off);
-            if (o > m) m = o;
-        }
+        for (int off = 32; off > 0; off >>= 1) s = __builtin_fmaxf(s, __shfl_xor(s, off));
+        const float m = sqrtf(s);
         if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(max_bits, __builtin_bit_cast(unsigned, m));
     }
     // sqrtf is correctly rounded here (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt); __fsqrt_rn is not
-    __device__ __forceinline__ static float mag(cpx<float> c) { return sqrtf(c.re * c.re + c.im * c.im); }
+    __device__ __forceinline__ static float sumsq(cpx<float> c) { return c.re * c.re + c.im * c.im; }
     __device__ __forceinline__ void store_acc(size_t xf, int o, cpx<float> v, Acc &acc) const
     {
         if (o < n / 2) {
-            const float m = mag(v);
-            st_stream(mags + xf * (size_t)(n / 2) + o, m);
-            if (m > acc) acc = m;
+            const float s = sumsq(v);
+            st_stream(mags + xf * (size_t)(n / 2) + o, sqrtf(s));
+            acc = __builtin_fmaxf(acc, s);
         }
     }
     __device__ __forceinline__ rsrc_t out_desc(size_t xf) const { return make_rsrc(mags + xf * (size_t)(n / 2), (unsigned)(n / 2) * 4u); }
@@ -298,22 +297,15 @@ struct StftMagIO : StftIO {
     {
         // lane_bytes = 8 * tau (complex offset); the magnitude row has 4-byte elements
         if (ou + (lane_bytes >> 3) < n / 2) {
-            const float m = mag(v);
-            buf_store_f32(m, d, row_off + (lane_bytes >> 1), ou * 4);
-            if (m > acc) acc = m;
+            const float s = sumsq(v);
+            buf_store_f32(sqrtf(s), d, row_off + (lane_bytes >> 1), ou * 4);
+            acc = __builtin_fmaxf(acc, s);
         }
     }
-    // The same store where the CALLER has decided, at compile time, that bin ou + tau is below n/2 (round 5, fft_persist.hip.h: the
-    // register part ou of the last pass's output index and the thread part tau are disjoint bit fields, so ou + tau < n/2 <=> ou < n/2,
-    // a constant per register): no range test per store -- 16 runtime branches less per transform -- and the discarded half of the last
-    // stage's butterflies is dead code.
+    // (round 5) Which REGISTERS hold bins below n/2 is a compile-time fact in the persistent kernel (fft_persist.hip.h: the register part ou of
+    // the last pass's output index and the thread part tau are disjoint bit fields, so ou + tau < n/2 <=> ou < n/2, a constant per register): no
+    // range test per store -- 16 runtime branches less per transform -- and the discarded half of the last stage's butterflies is dead code.
     static constexpr bool kHalfSpectrum = true;
-    __device__ __forceinline__ void store_d_acc_kept(rsrc_t d, int lane_bytes, int ou, cpx<float> v, int row_off, Acc &acc) const
-    {
-        const float m = mag(v);
-        buf_store_f32(m, d, row_off + (lane_bytes >> 1), ou * 4);
-        if (m > acc) acc = m;
-    }
     // Round 6: the NK kept magnitudes of one transform together.  sqrtf's expansion costs ~16 VALU instructions per
     // root -- 3 to scale arguments below 2^-96 up by 2^32, v_sqrt_f32, 8 for the +-1 ulp correction (two fma residuals against the
     // neighbours of the estimate), 2 to scale back, 2 to pass +-0 / +inf through -- and the kernel is VALU-bound (0.69 of the issue rate at
@@ -331,8 +323,9 @@ struct StftMagIO : StftIO {
         if (__builtin_fmaf(-up, r, x) > 0.0f) y = up;
         return y;
     }
+    // returns the largest of the NK sums of squares (NaNs skipped): what the accumulator keeps
     template <int NK>
-    __device__ __forceinline__ static void mags_of(const cpx<float> (&v)[NK], float (&m)[NK])
+    __device__ __forceinline__ static float mags_of(const cpx<float> (&v)[NK], float (&m)[NK])
     {
         float s[NK];
 #pragma unroll
@@ -355,6 +348,7 @@ struct StftMagIO : StftIO {
 #pragma unroll
             for (int i = 0; i < NK; ++i) m[i] = sqrtf(s[i]);
         }
+        return hi;
     }
     __device__ __forceinline__ void store_d_mag(rsrc_t d, int lane_bytes, int ou, float m, int row_off) const
     {
