@@ -17,6 +17,7 @@ template int fft_big_windowed_dev<float>(kofft_hip_ctx *, const float *, float *
 KOFFT_CASE(8)
 KOFFT_CASE(9)
 KOFFT_CASE(10)
+KOFFT_CASE(11)
 #undef KOFFT_CASE
 }  // namespace host
 }  // namespace kofft

@@ -16,6 +16,7 @@ namespace host {
 KOFFT_CASE(8)
 KOFFT_CASE(9)
 KOFFT_CASE(10)
+KOFFT_CASE(11)
 #undef KOFFT_CASE
 
 // fft2d_inplace of c32 images with 1024 / 2048 / 4096-point rows in TWO passes (fft_nd_fused.hip.h): rows + the columns' first two
@@ -55,9 +56,10 @@ int fft2d_fused_core(kofft_hip_ctx *ctx, cpx<float> *data, int LT)
     switch (LS) {
 #define KOFFT_CASE(LL) \
     case LL: return launch_tile_persist<float, LL, AxisLastIO<float, INVERSE>>(ctx, m, tw_col, units);
-        KOFFT_CASE(8)  // LS = LT - 2, LT = 10 .. 12 (fft2d_fused_ok)
+        KOFFT_CASE(8)  // LS = LT - 2, LT = 10 .. 13 (fft2d_fused_ok)
         KOFFT_CASE(9)
         KOFFT_CASE(10)
+        KOFFT_CASE(11)  // 8192 rows (round 6): tiles of 8 columns at 1024 threads, 64-byte runs
 #undef KOFFT_CASE
     default: return KOFFT_ERR_UNSUPPORTED;
     }
@@ -66,10 +68,12 @@ int fft2d_fused_core(kofft_hip_ctx *ctx, cpx<float> *data, int LT)
 bool fft2d_fused_ok(const kofft_hip_ctx *ctx, size_t rows, size_t cols)
 {
     // (fewer than one group of four rows per CU: the three-pass route is faster -- 512 x 4096: 0.034 against 0.026 ms)
+    // (8192 rows, round 6: the column pass runs 2^11-point tiles of 8 columns = 64-byte runs -- 8192 x 2048 0.140 -> 0.124 ms, 8192 x 1024 0.076 -> 0.061; a 256 MiB
+    // image, 8192 x 4096, no longer fits the Infinity Cache between the passes and LOSES, 0.307 -> 0.369 ms: it keeps rows + two column-tile passes)
     // (KOFFT_HIP_NO_PERSIST=1 forces the generic kernels here too.  The units-per-CU floor of the factor path's tile kernels
     // (big_persist_min_units) is NOT applied: its 4 x cols column units are 16 .. 64 per CU, and the route measured faster down to
     // 1024-point rows on images of at least 32 MiB -- 4096 x 1024: 0.044 -> 0.034 ms -- which is the rule below.)
-    return ctx->nd_fused && ctx->use_persist && ctx->big_persist && (cols == 1024 || cols == 2048 || cols == 4096) && is_pow2(rows) && rows >= 1024 && rows <= 4096 &&
+    return ctx->nd_fused && ctx->use_persist && ctx->big_persist && (cols == 1024 || cols == 2048 || cols == 4096) && is_pow2(rows) && rows >= 1024 && (rows <= 4096 || (rows == 8192 && cols <= 2048)) &&
            rows / 4 >= (size_t)ctx->num_cus && rows * cols >= (size_t(1) << 22);  // (16 MiB images: 1024 x 2048 0.031 against 0.029 ms, 1024 x 1024 a tie)
 }
 

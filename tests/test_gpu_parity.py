@@ -847,11 +847,12 @@ def test_rfft_of_2p17_to_2p22_reals_every_row(oracle, n, batch, windowed):
 
 
 @pytest.mark.parametrize("rows,cols", [(1024, 4096), (2048, 4096), (4096, 4096), (1024, 1024), (2048, 1024), (4096, 1024), (1024, 2048),
-                                       (2048, 2048), (4096, 2048), (512, 4096)])
+                                       (2048, 2048), (4096, 2048), (512, 4096), (8192, 2048), (8192, 1024), (8192, 4096)])
 def test_fft2d_fused_two_passes(fft32, oracle, rows, cols):
     """Round 5 (fft_nd_fused.hip.h): c32 images with rows of 1024 / 2048 / 4096 points and 1024 .. 4096 rows -- the row transforms and
     the columns' first two Stockham stages in one pass (four rows per workgroup step), the remaining column stages as one column-tile
-    pass with the frequency prefix K = 2 bits (512 rows: below one group per CU, the three-pass route).  Forward and inverse, EVERY
+    pass with the frequency prefix K = 2 bits (512 rows: below one group per CU, the three-pass route; 8192 rows, round 6: the column pass
+    on 2^11-point tiles of 8 columns).  Forward and inverse, EVERY
     value against the oracle's rows-then-columns (ndfft.rs:89-98) bit for bit; an impulse image with its exact answer (ndfft.rs tests)."""
     rng = seeded(5200 + rows + 3 * cols)
     x = rand_c(rng, (rows, cols))
