@@ -183,6 +183,11 @@ struct IrfftRowIO : ComplexIO<T, true> {  // in: rows of n + 1 bins; out: rows o
     {
         return make_rsrc(this->in + (cnt > 0 ? xf0 : 0) * (size_t)(this->n + 1), (unsigned)(cnt > 0 ? cnt : 0) * (unsigned)(this->n + 1) * (unsigned)sizeof(cpx<T>));
     }
+    // elements between the start of input row xf and the previous 128-byte line boundary (rows are n + 1 bins long: every row starts elsewhere)
+    __device__ __forceinline__ int in_row_misalign(size_t xf) const
+    {
+        return (int)((reinterpret_cast<size_t>(this->in) / sizeof(cpx<T>) + xf * (size_t)(this->n + 1)) & (128 / sizeof(cpx<T>) - 1));
+    }
 };
 
 // rfft_direct (rfft.rs:425-465) of 2 N reals in ONE pass (round 6): the N-point transform of the packed row z[e] =
@@ -310,10 +315,18 @@ __global__ __launch_bounds__(1024, 4) void fft_regfile_persist_kernel(const IO i
     size_t base = blockIdx.x;
     if (base >= batch) return;
 
+    // which position of every block a thread LOADS for transform xf: its phase-A position tauA -- except for irfft's rows of N + 1 bins, which
+    // start anywhere in a 128-byte line: there thread t loads position (t - a) mod TPT (a = the row's offset into its line), so that every 16
+    // lanes cover whole lines (streaming loads of partial lines were fetched from HBM again by the neighbouring instruction: 1.6x the row's
+    // bytes, rocprofv3 FETCH_SIZE), and the pre-pass's exchange hands every thread its own position back (below)
+    auto load_lane_bytes = [&](const size_t xf_) {
+        if constexpr (rf_irfft_pre<IO>::value) return (int)((fresh((unsigned)tid) - (unsigned)io.in_row_misalign(xf_)) & (unsigned)(Gm::TPT - 1)) * (int)IO::kRawBytes;
+        else return tau_a() * (int)IO::kRawBytes;
+    };
     Raw raw[R];
     {
         const rsrc_t d0 = io.in_desc_n(base, 1);
-        const int in_lane_bytes = tau_a() * (int)IO::kRawBytes;
+        const int in_lane_bytes = load_lane_bytes(base);
 #pragma unroll
         for (int u = 0; u < R; ++u) raw[u] = io.fetch_d(d0, in_lane_bytes, u * Gm::TPT, 0);
     }
@@ -341,34 +354,67 @@ __global__ __launch_bounds__(1024, 4) void fft_regfile_persist_kernel(const IO i
                 for (int j = 0; j < WC; ++j) cur[c + j] = mk<T>(raw[c + j].re * wv[j].re, raw[c + j].im * wv[j].im);
             }
         } else if constexpr (rf_irfft_pre<IO>::value) {
+            // Round 6: element e = u TPT + p of the pre-pass needs bin e (this thread's prefetched raw[u]: it holds position p = tauA of every
+            // block u) and bin N - e = block STEPS - 1 - u, position TPT - p -- ANOTHER thread's prefetched value.  Rounds 4-5 loaded it again
+            // (an L2 hit, but a third of the kernel's load instructions: irfft ran 0.30 where the plain transform runs 0.45).  Now the row goes
+            // through the exchange region like the rfft epilogue's (below): whole values in natural order, half the blocks per round (round 1:
+            // u < H and u >= 3H; both halves closed under u -> STEPS - 1 - u, the mirror's rank is 2H - 1 - rank), every thread writes its
+            // value of each block and reads its partner's.  Position 0 mirrors itself one block further (block STEPS - u: folded into its mirror
+            // base), inside the round for every block but the pair (H, 3H) -- both are thread 0's own registers -- and block 0 pairs with bin N.
+            constexpr int STEPS = Gm::N / Gm::TPT, H = STEPS / 4, BLK = Gm::TPT * ES;
+            static_assert(STEPS == R && 2 * H * BLK == Gm::N * Gm::CELL, "pre-pass geometry: half the row fills the region");
             const rsrc_t rd = io.in_desc_n(xf, 1);  // this transform's row: bins 0 .. N
             const rsrc_t td = make_rsrc(io.rtab, (unsigned)Gm::N * (unsigned)ES);
             const int ta = tau_a();
-            // bins and table entries in chunks of WC, the next chunk's loads in flight while this one is computed (all at once would be 2 R values)
+            const int wcell = load_lane_bytes(xf);  // the position this thread loaded (kRawBytes == ES)
+            const int ocell = ta * ES;
+            const int mcell = ((Gm::TPT - ta) & (Gm::TPT - 1)) * ES + (ta == 0 ? BLK : 0);
+            // thread 0's three odd partners, straight from the row (every lane reads the same elements: one request each)
+            const cpx<T> bin_n = buf_load_cpx<T, AUX_DEFAULT>(rd, 0, Gm::N * ES);
+            const cpx<T> own_h = buf_load_cpx<T, AUX_DEFAULT>(rd, 0, H * BLK), own_3h = buf_load_cpx<T, AUX_DEFAULT>(rd, 0, 3 * H * BLK);
             constexpr int WC = sizeof(T) == 4 ? 4 : 2;
-            cpx<T> mv[2][WC], tv[2][WC];
-            auto issue = [&](const int c, cpx<T> *m_, cpx<T> *t_) {
+            if constexpr (SPLITBAR) {  // the region is free: every wavefront has read the previous transform out of its rows (see phase A below)
+                const unsigned target = 16u * (unsigned)iter;
+                while (__builtin_amdgcn_readfirstlane(*(volatile lds_u32 *)(size_t)(unsigned)COUNTER) < target) __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            } else {
+                __syncthreads();
+            }
 #pragma unroll
-                for (int j = 0; j < WC; ++j) {
-                    m_[j] = buf_load_cpx<T, AUX_DEFAULT>(rd, (Gm::N - ta - (c + j) * Gm::TPT) * ES, 0);  // bin N - e (e = 0: bin N)
-                    t_[j] = buf_load_cpx<T, AUX_DEFAULT>(td, ta * ES, (c + j) * Gm::TPT * ES);
-                }
-            };
-            issue(0, mv[0], tv[0]);
+            for (int rnd = 0; rnd < 2; ++rnd) {
+                auto in_round = [&](const int sb) { return ((sb < H) || (sb >= 3 * H)) == (rnd == 0); };
+                auto rank = [&](const int sb) { return rnd == 0 ? (sb < H ? sb : sb - 2 * H) : sb - H; };
+                auto block_of = [&](const int sp) { return rnd == 0 ? (sp < H ? sp : sp + 2 * H) : sp + H; };
+                if (rnd == 1) __syncthreads();  // every wavefront has read round 1's partners
 #pragma unroll
-            for (int c = 0; c < R; c += WC) {
-                const int cb = (c / WC) & 1;
-                if (c + WC < R) issue(c + WC, mv[cb ^ 1], tv[cb ^ 1]);
+                for (int u = 0; u < R; ++u)
+                    if (in_round(u)) Lds::st(wcell + rank(u) * BLK, raw[u]);
+                // the round's table entries travel across the barrier (in chunks between the computations every chunk waited an L2 round trip)
+                cpx<T> tv[2 * H];
+                split_pin();
 #pragma unroll
-                for (int j = 0; j < WC; ++j) {
-                    cpx<T> sv = irfft_pre_one<T>(raw[c + j], mv[cb][j], tv[cb][j]);
-                    if (c + j == 0) {  // e = 0 (rfft.rs:491-493): only the real parts of bins 0 and N
-                        const T half = T(0.5f);
-                        const cpx<T> s0 = mk<T>((raw[0].re + mv[0][0].re) * half, (raw[0].re - mv[0][0].re) * half);
-                        sv = ta == 0 ? s0 : sv;
+                for (int j = 0; j < 2 * H; ++j) tv[j] = buf_load_cpx<T, AUX_DEFAULT>(td, ta * ES, block_of(j) * Gm::TPT * ES);
+                split_pin();
+                __syncthreads();
+#pragma unroll
+                for (int c = 0; c < 2 * H; c += WC) {
+#pragma unroll
+                    for (int j = 0; j < WC; ++j) {
+                        const int u = block_of(c + j);
+                        cpx<T> mv = Lds::ld(mcell + (2 * H - 1 - (c + j)) * BLK);
+                        if (u == H) mv = ta == 0 ? own_3h : mv;
+                        if (u == 3 * H) mv = ta == 0 ? own_h : mv;
+                        if (u == 0) mv = ta == 0 ? bin_n : mv;
+                        const cpx<T> ov = Lds::ld(ocell + (c + j) * BLK);  // bin e, loaded by whichever thread the row's alignment gave it to
+                        cpx<T> sv = irfft_pre_one<T>(ov, mv, tv[c + j]);
+                        if (u == 0) {  // e = 0 (rfft.rs:491-493): only the real parts of bins 0 and N
+                            const T half = T(0.5f);
+                            const cpx<T> s0 = mk<T>((ov.re + mv.re) * half, (ov.re - mv.re) * half);
+                            sv = ta == 0 ? s0 : sv;
+                        }
+                        sv.im = -sv.im;  // ifft: conj on the way in (fft.rs:1163-1165)
+                        cur[u] = sv;
                     }
-                    sv.im = -sv.im;  // ifft: conj on the way in (fft.rs:1163-1165)
-                    cur[c + j] = sv;
                 }
             }
         } else {
@@ -378,7 +424,7 @@ __global__ __launch_bounds__(1024, 4) void fft_regfile_persist_kernel(const IO i
 #ifdef KOFFT_RF_COPY_ONLY /* measurement only: loads and stores alone */
         if (true) {
             const rsrc_t od = io.out_desc_n(xf, 1);
-            const int out_lane_bytes = tau_b() * ES, in_lane_bytes = tau_a() * (int)IO::kRawBytes;
+            const int out_lane_bytes = tau_b() * ES, in_lane_bytes = load_lane_bytes(nbase);
 #pragma unroll
             for (int u = 0; u < R; ++u) io.store_d(od, out_lane_bytes, Gm::out_reg(u), cur[u], 0);
 #pragma unroll
@@ -395,7 +441,9 @@ __global__ __launch_bounds__(1024, 4) void fft_regfile_persist_kernel(const IO i
         // ---- phase A
         reg_pass<T, LA, 0, QA0, true>(cur, 0, tw, TwSubFirst{LB});
         KOFFT_RF_STAMP(2)
-        if constexpr (SPLITBAR) {
+        if constexpr (rf_irfft_pre<IO>::value) {
+            __syncthreads();  // every wavefront has read round 2's partners out of the region (the split-barrier wait was taken before round 1)
+        } else if constexpr (SPLITBAR) {
         // Every wavefront has read the previous transform out of its rows -- a SPLIT barrier: a wavefront arrives (below) as soon as
         // its last gathers are done, long before it has stored its results, loaded the next inputs and run pass A0, and only waits
         // here.  With s_barrier in this place the wavefronts whose memory instructions were queued first sat out those of the last
@@ -535,7 +583,7 @@ __global__ __launch_bounds__(1024, 4) void fft_regfile_persist_kernel(const IO i
             const int rm = ((Gm::TPT - kk) & (Gm::TPT - 1)) * ES + (kk == 0 ? BLK : 0);  // Y[N - k]: position TPT - kk of the mirror block (position 0: one block further)
             const int lane_w = kk * ES;
             const int lane_x = kk == 0 ? 0x40000000 : kk * ES;                // blocks H and 3H of position 0 are thread 0's: beyond the descriptor, dropped
-            const int in_lane_bytes = tau_a() * (int)IO::kRawBytes;
+            const int in_lane_bytes = load_lane_bytes(nbase);
             constexpr int CH = sizeof(T) == 4 ? 4 : 2;
 #pragma unroll
             for (int rnd = 0; rnd < 2; ++rnd) {
@@ -609,7 +657,7 @@ __global__ __launch_bounds__(1024, 4) void fft_regfile_persist_kernel(const IO i
         }
         KOFFT_RF_STAMP(8)
         const rsrc_t od = io.out_desc_n(xf, 1);
-        const int out_lane_bytes = tau_b() * ES, in_lane_bytes = tau_a() * (int)IO::kRawBytes;
+        const int out_lane_bytes = tau_b() * ES, in_lane_bytes = load_lane_bytes(nbase);
 #pragma unroll
         for (int g = 0; g < GB1; ++g) {  // results leave as each group completes; its registers take the next transform's loads
             reg_pass_r<T, QB1>(cur + g * (1 << QB1), twb[g % NTW]);
