@@ -785,6 +785,38 @@ int stft_bluestein_dev(kofft_hip_ctx *ctx, const float *d_signal, size_t len, co
 }
 #endif
 
+// The two fused launches (BlueFirstIO / BlueSecondIO through a scratch) exist at the m no one-launch kernel serves whatever the batch
+// (round 6, library diet: the general dispatch instantiated both policies at every size from 1 to 2^14 -- 120 kernels, 100 of them
+// reachable only with KOFFT_HIP_BLUESTEIN_ONE=0): m = 8 / 16 (n = 3 .. 8: the straight-line kernels), and where bluestein_wg_kernel
+// stops: c32 m = 8192 (batches the persistent form does not take) / 16384, c64 m = 2048 / 4096 (likewise) / 8192.  Any other m:
+// KOFFT_ERR_UNSUPPORTED before anything is launched -- the caller takes the separate pointwise kernels.
+template <typename T, class IO>
+int dispatch_blue(kofft_hip_ctx *ctx, const IO &io, size_t m, size_t batch)
+{
+    if (batch == 0) return KOFFT_OK;
+    const int L = ilog2(m);
+    if (L == 3) return launch_small<T, 8, EPI_STORE>(ctx, io, batch);
+    if (L == 4) return launch_small<T, 16, EPI_STORE>(ctx, io, batch);
+    if (L < (sizeof(T) == 4 ? 13 : 11) || L > max_log2<T>()) return KOFFT_ERR_UNSUPPORTED;
+    const cpx<T> *tw = nullptr;
+    const int rc = get_table<T>(ctx, Kind<T>::tw, m, &tw);
+    if (rc) return rc;
+    switch (L) {
+    case 11:
+        if constexpr (sizeof(T) == 8) return launch_wg<T, 11, EPI_STORE>(ctx, io, tw, batch);
+        break;
+    case 12:
+        if constexpr (sizeof(T) == 8) return launch_wg<T, 12, EPI_STORE>(ctx, io, tw, batch);
+        break;
+    case 13: return launch_wg<T, 13, EPI_STORE>(ctx, io, tw, batch);
+    case 14:
+        if constexpr (sizeof(T) == 4) return launch_wg<T, 14, EPI_STORE>(ctx, io, tw, batch);
+        break;
+    default: break;
+    }
+    return KOFFT_ERR_UNSUPPORTED;
+}
+
 template <typename T, bool INVERSE>
 int fft_bluestein_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, size_t batch)
 {
@@ -845,12 +877,14 @@ int fft_bluestein_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, size_t n, siz
         cpx<T> *dst = reinterpret_cast<cpx<T> *>(d_out) + b0 * n;
         if (ctx->blue_fused && m <= (size_t(1) << max_log2<T>())) {
             BlueFirstIO<T, INVERSE> io1{{}, src, a, chirp, bfft, (int)n, (int)m};
-            rc = dispatch<T, EPI_STORE>(ctx, io1, m, nb);
-            if (rc) return rc;
-            BlueSecondIO<T, INVERSE> io2{{}, a, dst, chirp, (int)n, (int)m, scale_m, scale_n};
-            rc = dispatch<T, EPI_STORE>(ctx, io2, m, nb);
-            if (rc) return rc;
-            continue;
+            rc = dispatch_blue<T>(ctx, io1, m, nb);
+            if (rc == KOFFT_OK) {
+                BlueSecondIO<T, INVERSE> io2{{}, a, dst, chirp, (int)n, (int)m, scale_m, scale_n};
+                rc = dispatch_blue<T>(ctx, io2, m, nb);
+                if (rc) return rc;
+                continue;
+            }
+            if (rc != KOFFT_ERR_UNSUPPORTED) return rc;  // (unsupported: no fused pair at this m -- the separate kernels below)
         }
         if (ctx->blue_fused && is_pow2(m) && m > (size_t(1) << max_log2<T>())) {
             // m beyond one workgroup's transform (round 3): the three pointwise steps ride on the factor kernels -- x * chirp and

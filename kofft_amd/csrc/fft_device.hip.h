@@ -122,6 +122,30 @@ __device__ __forceinline__ cpx<T> buf_load_cpx(rsrc_t r, int voff, int coff)
 #ifndef KOFFT_STORE_AUX
 #define KOFFT_STORE_AUX AUX_NT  // outputs are written once and not read back by the kernel (see st_stream)
 #endif
+// A 16-byte store of a Complex<f64> whose data registers the next f64 VALU instruction overwrites (round 6).  The compiler reuses ONE
+// register quadruple for a loop of "value * scale -> store" (ifft's scaling, the rfft post-pass, Bluestein's products):
+//     v_mul_f64 v[66:67], ..   v_mul_f64 v[68:69], ..   buffer_store_dwordx4 v[66:69], v1, s[12:15], s61 offen
+//     v_mul_f64 v[66:67], ..   <- overwrites the first half of the data the store is still reading
+// LLVM knows this hazard (GCNHazardRecognizer: a store of more than 64 bits followed by a VALU write of its data registers) and
+// inserts `s_nop 1` -- but only when the store's soffset field is NOT an SGPR, as the SI-era documents say; every store here carries
+// its compile-time offset in an SGPR soffset (one VGPR of address for all of a thread's stores).  On gfx950 with f64 VALU
+// instructions the hazard is real with an SGPR soffset too: large c64 batches returned, in a few transforms per thousand, ONE
+// register's real part replaced by the next store's in lanes 12-15 of every row of 16 (tools/dbg_f64.py; the imaginary part, written
+// one instruction later, always arrived).  Found when tools/kernel_coverage.sh showed that the parity tests had stopped reaching
+// these kernels (the host pipeline cut their batches into eight).  The wait states are pinned to the store by an asm statement that
+// READS the stored registers: side effects keep it behind the store, the anti-dependence keeps every overwrite behind it.
+// Packed-f32 data (the c32 row pairs' 16-byte stores) never showed it in the every-transform tests; it is the same instruction with the
+// same soffset form and gets the same two wait states.
+#ifndef KOFFT_F64_STORE_NOP
+#define KOFFT_F64_STORE_NOP 1 /* s_nop argument: wait states - 1 (LLVM's own choice for the hazard it knows on gfx940+: 2 wait states); < 0: none */
+#endif
+template <typename V>
+__device__ __forceinline__ void b128_store_guard(const V bits)
+{
+#if KOFFT_F64_STORE_NOP >= 0
+    asm volatile("s_nop %1" ::"v"(bits), "n"(KOFFT_F64_STORE_NOP));
+#endif
+}
 template <typename T>
 __device__ __forceinline__ void buf_store_cpx(cpx<T> c, rsrc_t r, int voff, int coff)
 {
@@ -134,7 +158,9 @@ __device__ __forceinline__ void buf_store_cpx(cpx<T> c, rsrc_t r, int voff, int 
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, f), r, voff, coff, KOFFT_STORE_AUX);
     } else {
         typedef unsigned v4u __attribute__((ext_vector_type(4)));
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, f), r, voff, coff, KOFFT_STORE_AUX);
+        const v4u bits = __builtin_bit_cast(v4u, f);
+        __builtin_amdgcn_raw_buffer_store_b128(bits, r, voff, coff, KOFFT_STORE_AUX);
+        b128_store_guard(bits);
     }
 }
 
@@ -146,7 +172,9 @@ __device__ __forceinline__ void buf_store_cpx_aux(cpx<T> c, rsrc_t r, int voff, 
         typedef float v4f __attribute__((ext_vector_type(4)));
         v4f f4;
         f4.x = c.re.x; f4.y = c.im.x; f4.z = c.re.y; f4.w = c.im.y;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, f4), r, voff, coff, AUX);
+        const v4u bits = __builtin_bit_cast(v4u, f4);
+        __builtin_amdgcn_raw_buffer_store_b128(bits, r, voff, coff, AUX);
+        b128_store_guard(bits);  // (same instruction, same soffset form: guarded too, although packed-f32 arithmetic never showed the hazard)
         return;
     } else {
     typedef T vec2 __attribute__((ext_vector_type(2)));
@@ -158,7 +186,9 @@ __device__ __forceinline__ void buf_store_cpx_aux(cpx<T> c, rsrc_t r, int voff, 
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, f), r, voff, coff, AUX);
     } else {
         typedef unsigned v4u __attribute__((ext_vector_type(4)));
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, f), r, voff, coff, AUX);
+        const v4u bits = __builtin_bit_cast(v4u, f);
+        __builtin_amdgcn_raw_buffer_store_b128(bits, r, voff, coff, AUX);
+        b128_store_guard(bits);
     }
     }
 }

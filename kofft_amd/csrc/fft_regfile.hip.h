@@ -165,6 +165,8 @@ struct rf_irfft_pre { static constexpr bool value = false; };
 template <class IO>
 struct rf_irfft_pre<IO, decltype((void)IO::kIrfftPre)> { static constexpr bool value = IO::kIrfftPre; };
 template <typename T>
+__device__ __forceinline__ cpx<T> csel(const bool c, const cpx<T> a, const cpx<T> b) { return mk<T>(c ? a.re : b.re, c ? a.im : b.im); }
+template <typename T>
 __device__ __forceinline__ cpx<T> irfft_pre_one(const cpx<T> a, const cpx<T> rb, const cpx<T> tw)
 {
     const T half = T(0.5f);
@@ -402,15 +404,17 @@ __global__ __launch_bounds__(1024, 4) void fft_regfile_persist_kernel(const IO i
                     for (int j = 0; j < WC; ++j) {
                         const int u = block_of(c + j);
                         cpx<T> mv = Lds::ld(mcell + (2 * H - 1 - (c + j)) * BLK);
-                        if (u == H) mv = ta == 0 ? own_3h : mv;
-                        if (u == 3 * H) mv = ta == 0 ? own_h : mv;
-                        if (u == 0) mv = ta == 0 ? bin_n : mv;
+                        // (field by field: `ta == 0 ? own_3h : mv` on whole values is a select between two OBJECTS -- the f64 build kept them on the
+                        // stack and indexed it per lane, 96 of this kernel's 128 bytes of scratch)
+                        if (u == H) mv = csel(ta == 0, own_3h, mv);
+                        if (u == 3 * H) mv = csel(ta == 0, own_h, mv);
+                        if (u == 0) mv = csel(ta == 0, bin_n, mv);
                         const cpx<T> ov = Lds::ld(ocell + (c + j) * BLK);  // bin e, loaded by whichever thread the row's alignment gave it to
                         cpx<T> sv = irfft_pre_one<T>(ov, mv, tv[c + j]);
                         if (u == 0) {  // e = 0 (rfft.rs:491-493): only the real parts of bins 0 and N
                             const T half = T(0.5f);
                             const cpx<T> s0 = mk<T>((ov.re + mv.re) * half, (ov.re - mv.re) * half);
-                            sv = ta == 0 ? s0 : sv;
+                            sv = csel(ta == 0, s0, sv);
                         }
                         sv.im = -sv.im;  // ifft: conj on the way in (fft.rs:1163-1165)
                         cur[u] = sv;

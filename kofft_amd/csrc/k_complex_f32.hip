@@ -1,24 +1,16 @@
-// k_complex_f32.hip -- Complex<float> transforms (fft.rs:1054-1174): every kernel instance of the family.
-#define KOFFT_BLUE_STFT_UNIT 1  // stft_bluestein_dev (float only) is defined in this translation unit
+// k_complex_f32.hip -- Complex<float> transforms (fft.rs:1054-1174): the single-pass kernels (one workgroup per transform, the CU's
+// register file) and the Radix4 arm.  The factor path lives in k_big_f32.hip and the Bluestein arm in k_blue_f32.hip: three translation
+// units per element type so that `make -j` builds them side by side (round 6: one unit took 70 s of a 90 s build).
 #include "complex_impl.hip.h"
 
 namespace kofft {
 namespace host {
+extern template int fft_big_dev<float, false>(kofft_hip_ctx *, const float *, float *, size_t, size_t);       // k_big_f32.hip
+extern template int fft_big_dev<float, true>(kofft_hip_ctx *, const float *, float *, size_t, size_t);
+extern template int fft_bluestein_dev<float, false>(kofft_hip_ctx *, const float *, float *, size_t, size_t);  // k_blue_f32.hip
+extern template int fft_bluestein_dev<float, true>(kofft_hip_ctx *, const float *, float *, size_t, size_t);
 template int fft_dev<float>(kofft_hip_ctx *, const float *, float *, size_t, size_t, int);
-template int fft_axis2_dev<float>(kofft_hip_ctx *, float *, int, int, size_t, int);
 template int fft_radix4_dev<float>(kofft_hip_ctx *, const float *, float *, size_t, size_t, int);
-template int fft_big_windowed_dev<float>(kofft_hip_ctx *, const float *, float *, const float *, size_t, size_t);
-// the column-tile pass of the fused 2-D route (k_nd_fused.hip declares these extern: one copy of the kernels in the library)
-#define KOFFT_CASE(LL)                                                                                                       \
-    template int launch_tile_persist<float, LL, AxisLastIO<float, false>>(kofft_hip_ctx *, const AxisLastIO<float, false> &, \
-                                                                          const cpx<float> *, size_t);                      \
-    template int launch_tile_persist<float, LL, AxisLastIO<float, true>>(kofft_hip_ctx *, const AxisLastIO<float, true> &,   \
-                                                                         const cpx<float> *, size_t);
-KOFFT_CASE(8)
-KOFFT_CASE(9)
-KOFFT_CASE(10)
-KOFFT_CASE(11)
-#undef KOFFT_CASE
 }  // namespace host
 }  // namespace kofft
 

@@ -1,16 +1,21 @@
-// k_complex_f64.hip -- Complex<double> transforms (fft.rs:1054-1174): every kernel instance of the family.
+// k_complex_f64.hip -- Complex<double> transforms (fft.rs:1054-1174): the single-pass kernels (one workgroup per transform, the CU's
+// register file) and the Radix4 arm.  The factor path lives in k_big_f64.hip and the Bluestein arm in k_blue_f64.hip: three translation
+// units per element type so that `make -j` builds them side by side (round 6: one unit took 70 s of a 90 s build).
 #include "complex_impl.hip.h"
 
 namespace kofft {
 namespace host {
+extern template int fft_big_dev<double, false>(kofft_hip_ctx *, const double *, double *, size_t, size_t);       // k_big_f64.hip
+extern template int fft_big_dev<double, true>(kofft_hip_ctx *, const double *, double *, size_t, size_t);
+extern template int fft_bluestein_dev<double, false>(kofft_hip_ctx *, const double *, double *, size_t, size_t);  // k_blue_f64.hip
+extern template int fft_bluestein_dev<double, true>(kofft_hip_ctx *, const double *, double *, size_t, size_t);
 template int fft_dev<double>(kofft_hip_ctx *, const double *, double *, size_t, size_t, int);
-template int fft_axis2_dev<double>(kofft_hip_ctx *, double *, int, int, size_t, int);
 template int fft_radix4_dev<double>(kofft_hip_ctx *, const double *, double *, size_t, size_t, int);
-template int fft_big_windowed_dev<double>(kofft_hip_ctx *, const double *, double *, const double *, size_t, size_t);
 }  // namespace host
 }  // namespace kofft
 
 #if defined(KOFFT_RF_STAMPS)
+// diagnostic builds only: the s_memtime stamps of fft_regfile_persist_kernel<double, ...> (this translation unit's copy)
 extern "C" int kofft_hip_exp_rf_stamps_f64(void *out, size_t bytes)
 {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(kofft::g_rf_stamps), bytes) == hipSuccess ? 0 : -1;

@@ -118,7 +118,7 @@ def case_regfile(oracle):
 
 
 def case_host_pipeline(oracle):
-    _complex(oracle, "c32", 4096, 5000, 111, check=_edges(5000), inverse=False)  # 160 MB: the chunked host path otherwise
+    _complex(oracle, "c32", 4096, 5000, 111, check=_edges(5000), inverse=False)  # 160 MB: eight chunks through the pipeline
 
 
 def case_zero_copy(oracle):
@@ -244,7 +244,7 @@ KNOBS = [
     ("KOFFT_HIP_SPLIT", "0", case_split),
     ("KOFFT_HIP_REGFILE", "0", case_regfile),
     ("KOFFT_HIP_RFFT_REGFILE_EPI", "0", case_rfft_regfile_two_passes),
-    ("KOFFT_HIP_HOST_PIPELINE", "0", case_host_pipeline),
+    ("KOFFT_HIP_HOST_PIPELINE", "1", case_host_pipeline),  # (conftest.py runs the session with the pipeline off: ON is the setting to flip here)
     ("KOFFT_HIP_ZERO_COPY", "0", case_zero_copy),
     ("KOFFT_HIP_ND_TRANSPOSE", "0", case_nd_transpose),
     ("KOFFT_HIP_ND_TWO_PASS", "0", case_nd_two_pass),

@@ -166,6 +166,47 @@ def test_two_contexts_in_two_threads(oracle):
     assert not errors, errors
 
 
+def test_host_pipeline_on_every_entry_point(oracle, monkeypatch):
+    """The host-pointer entry points move batches of 128 MiB and more in eight chunks -- upload of chunk c + 1, kernels of chunk c and
+    download of chunk c - 1 in flight together (kofft_hip.hip: pipeline_chunks).  The session runs with the pipeline OFF (conftest.py:
+    so that every test's batch reaches the kernel it names); here it is ON, on every entry point that has it -- complex in place
+    (c32 / c64, forward and inverse), rfft with and without a row window, irfft -- with batches that do not divide by eight, EVERY row
+    against the oracle, and byte for byte against the same calls with the pipeline off."""
+    import kofft_amd
+
+    rng = seeded(4242)
+    xc = rand_c(rng, (4100 + 3, 4096))                              # 2 x 134 MB
+    xz = rand_c(rng, (1025 + 6, 8192), np.complex128)               # 2 x 135 MB
+    xr = rng.uniform(-1, 1, (8200 + 5, 4096)).astype(np.float32)    # 134 MB in, 134 MB out
+    xd = rng.uniform(-1, 1, (4100 + 1, 4096)).astype(np.float64)
+    win = rng.uniform(0.1, 1, 4096).astype(np.float32)
+    outs = []
+    for pipe in ("1", "0"):
+        monkeypatch.setenv("KOFFT_HIP_HOST_PIPELINE", pipe)  # read when the context is created
+        f32, f64 = kofft_amd.HipFftImpl(np.float32), kofft_amd.HipFftImpl(np.float64)
+        yc = xc.copy()
+        f32.fft_batch(yc)
+        ic = yc.copy()
+        f32.fft_batch(ic, inverse=True)
+        yz = xz.copy()
+        f64.fft_batch(yz)
+        iz = yz.copy()
+        f64.fft_batch(iz, inverse=True)
+        rw, rp = f32.rfft_batch(xr, win), f32.rfft_batch(xr)
+        back = f32.irfft_batch(rp, 4096)
+        rd = f64.rfft_batch(xd)
+        outs.append((yc, ic, yz, iz, rw, rp, back, rd))
+        f32.close()
+        f64.close()
+    on, off = outs
+    assert all(bits_equal(a, b) for a, b in zip(on, off)), "pipeline on / off differ"
+    yc, ic, yz, iz, rw, rp, back, rd = on
+    assert bits_equal(yc, oracle.fft(xc)) and bits_equal(ic, oracle.ifft(yc))
+    assert bits_equal(yz, oracle.fft(xz)) and bits_equal(iz, oracle.ifft(yz))
+    assert bits_equal(rw, oracle.rfft(xr, win)) and bits_equal(rp, oracle.rfft(xr))
+    assert bits_equal(back, oracle.irfft(rp, 4096)) and bits_equal(rd, oracle.rfft(xd))
+
+
 def test_bench_two_rank_rehearsal_carries_the_single_process_gather_ab():
     """bench.py's N > 1 line on a one-GPU box: `--gpus 2 --rehearse-one-card` runs the whole two-rank protocol with
     both ranks on cuda:0 (gloo process group: NOT a measurement) and, after the per-rank part, rank 0 alone drives config #4 through
