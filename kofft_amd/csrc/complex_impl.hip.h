@@ -138,10 +138,17 @@ template <class IO> struct sub_min_ls_of { static constexpr int value = 7; };
 template <typename T, bool INVERSE> struct sub_min_ls_of<BigColsIO<T, INVERSE, 0>> { static constexpr int value = 5; };
 template <class IO> constexpr int sub_min_ls() { return sub_min_ls_of<IO>::value; }
 
+// policies of the LAST factor (BigRowsIO): their persistent form is fft_rows_persist_kernel (launch_rows_persist), taken by fft_big_core
+// whenever the conditions of the tile kernel hold -- the generic persistent tile kernel is never their route (round 6: its 40
+// BigRowsIO instantiations, reachable only through round 4's compile-time measurement switch, are gone)
+template <class IO> struct sub_tile_persist_of { static constexpr bool value = true; };
+template <typename T, bool INVERSE, int POST> struct sub_tile_persist_of<BigRowsIO<T, INVERSE, POST>> { static constexpr bool value = false; };
+
 // Launch the generic kernel for a sub-transform of log2 size LS with an arbitrary IO policy.
 template <typename T, class IO>
 int launch_sub(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, int LS, size_t units, bool persist)
 {
+    if constexpr (sub_tile_persist_of<IO>::value)
     if (persist && units >= (size_t)ctx->num_cus * ctx->big_persist_min_units) {  // every resident workgroup gets several tiles
         switch (LS) {
 #define KOFFT_CASE(LL) \
@@ -438,11 +445,10 @@ int fft_big_core(kofft_hip_ctx *ctx, const cpx<T> *in_base, size_t in_row, cpx<T
         ColsIO a{src, mid, L - L1, L - L1, n};
         fix_cols(a);
         const bool first_persist = ctx->big_first_persist >= 0 ? ctx->big_first_persist != 0 : ctx->big_persist;
-        const int last_mode = ctx->big_last_mode >= 0 ? ctx->big_last_mode : (!ctx->big_persist ? 0 : (ctx->big_rows_resident ? 2 : 1));
         const size_t persist_units = (size_t)ctx->num_cus * ctx->big_persist_min_units;
         // Both factors on their persistent kernels (the conditions of launch_sub and of the rows branch below): the intermediate
         // is then block-interleaved -- see BigColsIO::out_lane.
-        const bool rows_resident = last_mode == 2 && (nb << (L - L3)) >= persist_units && L3 >= 7 && L3 <= 10;
+        const bool rows_resident = ctx->big_persist && (nb << (L - L3)) >= persist_units && L3 >= 7 && L3 <= 10;
         // c64 only.  On identical buffers (tools/exp_c64_blocked.py, profiles/r04_c64_blocked_ab.txt): equal where the intermediate's
         // placement is fast, last factor 218-223 -> 203-207 us per chunk where it is slow, never slower.  c32 2^18 .. 2^20
         // lost 4-6 % in process-level A/Bs (0.324 / 0.315 / 0.284 -> 0.305 / 0.295 / 0.269) and keeps the natural layout.
@@ -514,8 +520,8 @@ int fft_big_core(kofft_hip_ctx *ctx, const cpx<T> *in_base, size_t in_row, cpx<T
 #endif
         b.nt_load = ctx->big_mid_nt >= 0 ? ctx->big_mid_nt != 0 : (nb * xf_bytes > (size_t(192) << 20) && load_piece >= 64);
         rc = KOFFT_ERR_UNSUPPORTED;
-        // last factor: 2 = rows resident (table entries per row tile in LDS), 1 = the generic persistent tile kernel, 0 = one tile
-        // per workgroup (two 512-thread workgroups per CU at 128 registers) (big_last_mode: compile-time constant since round 4, no environment knob)
+        // last factor: rows resident (table entries per row tile in LDS) for batches, else one tile per workgroup (two 512-thread workgroups
+        // per CU at 128 registers).  (The generic persistent tile kernel as a third form was round 4's measurement switch: removed in round 6.)
         if (rows_resident) {
             switch (L3) {
             case 7: rc = launch_rows_persist<T, 7>(ctx, b, tw, nb); break;
@@ -527,7 +533,7 @@ int fft_big_core(kofft_hip_ctx *ctx, const cpx<T> *in_base, size_t in_row, cpx<T
         }
         if (rc == KOFFT_ERR_UNSUPPORTED) {
             if (b.blk_r != 0) return KOFFT_ERR_UNSUPPORTED;  // (never: the blocked layout is only chosen where the rows kernel runs)
-            rc = launch_sub<T>(ctx, b, tw, L3, nb << LP, last_mode >= 1);
+            rc = launch_sub<T>(ctx, b, tw, L3, nb << LP, false);
         }
         return rc;
     };

@@ -51,8 +51,6 @@ struct kofft_hip_ctx {
     bool big_persist = true;   // KOFFT_HIP_BIG_PERSIST=0: factors on the one-tile-per-workgroup kernel (A/B measurements)
     size_t big_persist_min_units = 32;  // (a member only -- no environment variable since round 4) units (columns / rows) per CU from which the persistent factor kernels run
     int big_first_persist = -1;  // (a member only -- no environment variable since round 4) first factor one tile per workgroup / persistent (default: big_persist)
-    int big_last_mode = -1;      // (compile-time only since round 4; no getenv) last factor one tile per workgroup / generic persistent / rows resident
-    bool big_rows_resident = true;  // (a member only -- no environment variable since round 4) last factor on the generic tile kernel (A/B measurements)
     int big_mid_nt = -1;       // (compile-time only since round 4; no getenv) force plain / streaming loads of the intermediate (default: by chunk size)
     bool blue_fused = true;    // KOFFT_HIP_BLUESTEIN_FUSED=0: pointwise steps as separate kernels at every size
     bool blue_one_kernel = true;  // KOFFT_HIP_BLUESTEIN_ONE=0: two launches through a scratch even where one workgroup holds m points

@@ -66,12 +66,37 @@ def case_three_min_low(oracle):  # 2^21 as THREE factors
 
 
 def case_small32(oracle):
+    import kofft_amd
+
     _complex(oracle, "c32", 32, 5000, 41)
+    # the real transforms and the STFT whose inner length is 32 (fft_wg_kernel<float, 5, .., RfftIO / IrfftIO / StftIO / StftMagIO>)
+    f = kofft_amd.HipFftImpl(np.float32)
+    rows = seeded(42).uniform(-1, 1, (3001, 64)).astype(np.float32)
+    got = f.rfft_batch(rows)
+    assert bits_equal(got, oracle.rfft(rows))
+    assert bits_equal(f.irfft_batch(got, 64), oracle.irfft(got, 64))
+    sig = seeded(43).uniform(-1, 1, 40_000).astype(np.float32)
+    win = kofft_amd.hann(32)
+    frames = -(-sig.size // 8)
+    assert bits_equal(f.stft_into(sig, win, 8, frames), oracle.stft(sig, win, 8, frames))
+    mags, mx = f.stft_magnitudes(sig, 32, 8)
+    want, want_max = oracle.stft_magnitudes(sig, 32, 8)
+    assert bits_equal(mags, want) and mx == want_max
 
 
 def case_big_persist(oracle):
     _complex(oracle, "c64", 1 << 16, 300, 51, check=_edges(300))
     _complex(oracle, "c32", 1 << 17, 200, 52, check=_edges(200))
+
+
+def case_big_persist_three(oracle):
+    case_big_persist(oracle)
+    # three factors, every one of them one tile per workgroup (fft_wg_kernel<T, 7 .. 9, .., BigMidIO<T>>: by default even ONE such transform
+    # has enough units for the persistent kernels)
+    _complex(oracle, "c32", 1 << 22, 3, 53)
+    _complex(oracle, "c32", 1 << 24, 1, 54)
+    _complex(oracle, "c64", 1 << 23, 2, 55)
+    _complex(oracle, "c32", 1 << 26, 1, 56, inverse=False)
 
 
 def case_rfft_wide(oracle):  # rfft / irfft of 32768 and 16384 reals
@@ -108,8 +133,18 @@ def case_persist_small(oracle):
 
 
 def case_split(oracle):
+    import kofft_amd
+
     _complex(oracle, "c32", 8192, 1100, 91, check=_edges(1100))
     _complex(oracle, "c32", 16384, 1100, 92, check=_edges(1100))
+    # STFT with an 8192-sample window: fft_persist_kernel<float, 13, .., StftIO> (the wave-split kernel otherwise)
+    f = kofft_amd.HipFftImpl(np.float32)
+    sig = seeded(93).uniform(-1, 1, 1100 * 2048 + 77).astype(np.float32)
+    win = kofft_amd.hann(8192)
+    frames = -(-sig.size // 2048)
+    got = f.stft_into(sig, win, 2048, frames)
+    for first, count in ((0, 2), (frames // 2, 2), (frames - 4, 4)):
+        assert bits_equal(got[first:first + count], oracle.stft_range(sig, win, 2048, first, count)), (first, count)
 
 
 def case_regfile(oracle):
@@ -236,7 +271,7 @@ KNOBS = [
     ("KOFFT_HIP_BIG_THREE_MIN", "23", case_three_min_high),
     ("KOFFT_HIP_BIG_THREE_MIN", "21", case_three_min_low),
     ("KOFFT_HIP_SMALL32", "0", case_small32),
-    ("KOFFT_HIP_BIG_PERSIST", "0", case_big_persist),
+    ("KOFFT_HIP_BIG_PERSIST", "0", case_big_persist_three),
     ("KOFFT_HIP_RFFT14_WIDE", "0", case_rfft_wide),
     ("KOFFT_HIP_RFFT13_PERSIST", "0", case_rfft_wide),
     ("KOFFT_HIP_PERSIST64", "0", case_persist64),

@@ -680,7 +680,7 @@ def test_istft_matches_oracle(fft32, oracle, win_len, hop, length):
         assert np.max(np.abs(out[ok] - signal[ok])) < 1e-3
 
 
-@pytest.mark.parametrize("win_len,hop,frames", [(12, 5, 300_000), (30, 10, 150_000), (60, 20, 90_000), (100, 40, 60_000), (400, 160, 20_001),
+@pytest.mark.parametrize("win_len,hop,frames", [(12, 5, 300_000), (30, 10, 150_000), (60, 20, 90_000), (100, 40, 60_000), (200, 80, 40_001), (400, 160, 20_001),
                                                 (500, 125, 14_003), (1000, 250, 5_001), (1102, 441, 2_600), (2500, 625, 1_100)])
 def test_stft_window_not_a_power_of_two_large_frame_counts(oracle, monkeypatch, win_len, hop, frames):
     """stft.rs:91-103 calls fft.fft(frame) for ANY window length: lengths that are not powers of two take the Bluestein arm.  With enough
@@ -707,6 +707,8 @@ def test_stft_window_not_a_power_of_two_large_frame_counts(oracle, monkeypatch, 
     (512, 256, 9001, 0), (2048, 512, 4101, 5), (2048, 1024, 4100, -3000), (4096, 1024, 2101, 0), (4096, 2048, 2100, 4097),
     (256, 128, 33001, 3), (256, 64, 33000, -70), (256, 32, 33003, 0), (512, 512, 9001, 0), (512, 128, 9002, 1), (512, 64, 9003, -9),
     (1024, 1024, 9000, 17), (1024, 128, 9001, 0), (2048, 2048, 4100, 0), (2048, 256, 4101, -1), (4096, 4096, 2100, 0), (4096, 512, 2101, 100),
+    # (round 6, tools/kernel_coverage.sh: runs of at least 2 x (win / hop) frames per workgroup -- the counts above left <11, 3>, <12, 2>, <12, 3> on the two-kernel route)
+    (2048, 256, 8301, 0), (4096, 1024, 4101, 5), (4096, 512, 8201, -9),
 ])
 def test_istft_fused_kernel_large_frame_counts(oracle, monkeypatch, win_len, hop, nframes, out_delta):
     """Frame counts that give every workgroup of the chip-sized grid a run of frames take istft_fused_kernel (inverse transform + ordered
