@@ -111,16 +111,22 @@ inline void narrow_tile_adjust(BigColsIO<T, INVERSE, PRE> &io, size_t segment_by
 {
     if (segment_bytes < 64) io.nt_in_pieces = false;  // pieces of less than half a line: the neighbours want the rest
 }
+// (Round 6, tools/kernel_coverage.sh: which narrowed forms a call can reach.  A 2^10-point factor is the FIRST factor of 2^20 / 2^21 points
+// only -- at least 1024 columns, i.e. 256 half-width tiles: never narrowed twice.  A 2^7-point LAST factor in f32 exists only as the third
+// of three factors (2^21 / 2^22: 2^14 rows and more -- full-width tiles fill the chip); in f64 it is the last factor of 2^14 points too.)
+template <class IO> struct sub_is_rows { static constexpr bool value = false; };
+template <typename T, bool INVERSE, int POST> struct sub_is_rows<BigRowsIO<T, INVERSE, POST>> { static constexpr bool value = true; };
 template <typename T, int LL, class IO>
 int launch_sub_one_tile(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size_t units)
 {
     constexpr int B0 = big_block<T, IO, LL>();
     constexpr int TPT = (1 << LL) >> rl_for(LL);
+    constexpr bool kNarrow = !(sizeof(T) == 4 && LL == 7 && sub_is_rows<IO>::value);
     const size_t cus = (size_t)ctx->num_cus * (size_t)ctx->big_narrow_per_cu;
-    if constexpr (B0 / 2 >= 64 && (B0 / 2) % TPT == 0) {
+    if constexpr (kNarrow && B0 / 2 >= 64 && (B0 / 2) % TPT == 0) {
         if (ctx->big_narrow && units / (B0 / TPT) < cus) {
             IO nio = io;
-            if constexpr (B0 / 4 >= 64 && (B0 / 4) % TPT == 0) {
+            if constexpr (LL <= 9 && B0 / 4 >= 64 && (B0 / 4) % TPT == 0) {
                 if (units / (B0 / 2 / TPT) < cus) {
                     narrow_tile_adjust(nio, (size_t)(B0 / 4 / TPT) * sizeof(cpx<T>));
                     return launch_wg<T, LL, EPI_STORE, IO, B0 / 4>(ctx, nio, tw, units);
@@ -133,9 +139,10 @@ int launch_sub_one_tile(kofft_hip_ctx *ctx, const IO &io, const cpx<T> *tw, size
     return launch_wg<T, LL, EPI_STORE, IO, B0>(ctx, io, tw, units);
 }
 
-// smallest sub-transform a policy is launched with (launch_sub): 2^5 for the plain first-factor policy (ndfft's two-pass axes), 2^7 otherwise
+// smallest sub-transform a policy is launched with (launch_sub): 2^7, except the plain first-factor policy in f32 -- ndfft's 2048-point axes
+// run as 2^6 x 2^5 (fft_axis2_dev; f64 axes take the two-pass route from 4096 points on: 2^7 first)
 template <class IO> struct sub_min_ls_of { static constexpr int value = 7; };
-template <typename T, bool INVERSE> struct sub_min_ls_of<BigColsIO<T, INVERSE, 0>> { static constexpr int value = 5; };
+template <bool INVERSE> struct sub_min_ls_of<BigColsIO<float, INVERSE, 0>> { static constexpr int value = 6; };
 template <class IO> constexpr int sub_min_ls() { return sub_min_ls_of<IO>::value; }
 
 // policies of the LAST factor (BigRowsIO): their persistent form is fft_rows_persist_kernel (launch_rows_persist), taken by fft_big_core
@@ -236,12 +243,10 @@ int fft_axis2_core(kofft_hip_ctx *ctx, cpx<T> *data, int LT, int I, size_t block
         AxisLastIO<T, INVERSE> m{mid, blk, L1, LS, I, LT - LS, LT - 1 - L1, block_elems, scale};
         const size_t units = nb << (L1 + I);
         rc = KOFFT_ERR_UNSUPPORTED;
-        if (ctx->big_persist && units >= (size_t)ctx->num_cus * ctx->big_persist_min_units) {
-            switch (LS) {
-            case 7: rc = launch_tile_persist<T, 7, AxisLastIO<T, INVERSE>>(ctx, m, tw, units); break;
-            case 8: rc = launch_tile_persist<T, 8, AxisLastIO<T, INVERSE>>(ctx, m, tw, units); break;
-            default: break;
-            }
+        // LS = LT - L1 with L1 = 7 from 4096 points on: 5 .. 7 in f32 (axes up to 2^14 points), 5 / 6 in f64 (up to 2^13) -- fft_axis2_dev
+        if constexpr (sizeof(T) == 4) {
+            if (ctx->big_persist && units >= (size_t)ctx->num_cus * ctx->big_persist_min_units && LS == 7)
+                rc = launch_tile_persist<T, 7, AxisLastIO<T, INVERSE>>(ctx, m, tw, units);
         }
         if (rc == KOFFT_ERR_UNSUPPORTED) {
             switch (LS) {
@@ -249,9 +254,11 @@ int fft_axis2_core(kofft_hip_ctx *ctx, cpx<T> *data, int LT, int I, size_t block
     case LL: rc = launch_wg<T, LL, EPI_STORE, AxisLastIO<T, INVERSE>, big_block<T, AxisLastIO<T, INVERSE>, LL>()>(ctx, m, tw, units); break;
                 KOFFT_CASE(5)
                 KOFFT_CASE(6)
-                KOFFT_CASE(7)
-                KOFFT_CASE(8)
 #undef KOFFT_CASE
+            case 7:
+                if constexpr (sizeof(T) == 4)
+                    rc = launch_wg<T, 7, EPI_STORE, AxisLastIO<T, INVERSE>, big_block<T, AxisLastIO<T, INVERSE>, 7>()>(ctx, m, tw, units);
+                break;
             default: break;
             }
         }
@@ -265,9 +272,8 @@ int fft_axis2_dev(kofft_hip_ctx *ctx, T *d_data, int LT, int I, size_t blocks, i
 {
     // 2^12 = 2^7 x 2^5, 2^13 = 2^7 x 2^6, 2^14 = 2^7 x 2^7: the first pass on the persistent prefetching tile kernel (4096 x 4096 c32,
     // same box: transposes 0.224 ms, 2^5 x 2^7 0.169-0.173, 2^6 x 2^6 0.178, 2^7 x 2^5 0.149)
-    int L1 = LT >= 12 ? 7 : LT - 5;  // (2^11 = 2^6 x 2^5, 2^10 = 2^5 x 2^5)
-    if (ctx->nd_two_pass_l1 >= 5 && ctx->nd_two_pass_l1 <= 8 && LT - ctx->nd_two_pass_l1 >= 5 && LT - ctx->nd_two_pass_l1 <= 8) L1 = ctx->nd_two_pass_l1;
-    if (L1 < 5 || L1 > 8 || LT - L1 < 5 || LT - L1 > 8) return KOFFT_ERR_UNSUPPORTED;
+    const int L1 = LT >= 12 ? 7 : LT - 5;  // (2^11 = 2^6 x 2^5, c32 only: k_nd.hip)
+    if (L1 < (sizeof(T) == 4 ? 6 : 7) || L1 > 7 || LT - L1 < 5 || LT - L1 > (sizeof(T) == 4 ? 7 : 6)) return KOFFT_ERR_UNSUPPORTED;
     cpx<T> *data = reinterpret_cast<cpx<T> *>(d_data);
     return inverse ? fft_axis2_core<T, true>(ctx, data, LT, I, blocks, L1) : fft_axis2_core<T, false>(ctx, data, LT, I, blocks, L1);
 }

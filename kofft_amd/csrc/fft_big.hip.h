@@ -899,6 +899,7 @@ struct StridedIO {
     static constexpr bool kPairXcd = false;
     static constexpr bool kSplitLds = sizeof(T) == 8;
     static constexpr int kMinWaves = 1;
+    static constexpr bool kLen1 = false;  // fft_axis_dev returns for an axis of one point
     cpx<T> *__restrict__ data;  // in place
     size_t inner, outer_stride, stride;
     T scale;  // 1 / (len as f32 as T)

@@ -64,6 +64,8 @@ struct PlainTw {
     // gains 22 % / 6 % (n = 64: 20 %), irfft 16 % / 29 % (m = 64: 5 %), rfft n = 128 .. 512 gains 4 .. 10 % once its grid
     // is halved -- PersistGrid in kofft_hip.hip)
     static constexpr int kPersistMinLog2 = 9;
+    // dispatch() is reached with n = 1 (rfft of two reals, a one-sample STFT window); policies whose callers return before it say false
+    static constexpr bool kLen1 = true;
     __host__ __device__ bool group_rows_ok() const { return true; }  // per-lane row offsets fit 32 bits
     __device__ __forceinline__ TwPlain tw_map(size_t) const { return {}; }
 };
@@ -89,6 +91,7 @@ struct ComplexIO : PlainTw {
     static constexpr bool kPersist = true;  // eligible for the persistent prefetching kernel
     static constexpr bool kInvInLds = false;
     static constexpr bool kLeanRegisters = true;
+    static constexpr bool kLen1 = false;  // fft_dev copies a one-point transform (fft.rs:1059)
     using Raw = cpx<T>;
     using Inv = NoInv;
     const cpx<T> *__restrict__ in;

@@ -57,7 +57,6 @@ struct kofft_hip_ctx {
     bool nd_transpose = true;  // KOFFT_HIP_ND_TRANSPOSE=0: long strided axes through the strided kernel
     bool nd_fused = true;      // KOFFT_HIP_ND_FUSED=0: 2-D c32 images with 1024 .. 4096-point rows through rows + two column-tile passes instead of the fused two passes (A/B)
     bool nd_two_pass = true;   // KOFFT_HIP_ND_TWO_PASS=0: power-of-two axes of 4096 .. 16384 points through the transposes instead of two column-tile passes (A/B)
-    int nd_two_pass_l1 = 0;    // (compile-time only since round 4; no getenv) log2 of the first pass's sub-transform (default LT - 7)
     int nd_transpose_min = 4096;  // (a member only -- no environment variable since round 4) shortest axis that takes the transpose route (measured: 1024 loses, 2048 ties)
     bool zero_copy = true;     // KOFFT_HIP_ZERO_COPY=0: small host calls through staged copies like large ones
     bool host_pipeline = true; // KOFFT_HIP_HOST_PIPELINE=0: host-pointer batches in one upload / kernel / download
@@ -568,7 +567,9 @@ int dispatch(kofft_hip_ctx *ctx, const IO &io, size_t n, size_t batch)
     const int L = ilog2(n);
     if (L > max_log2<T>()) return KOFFT_ERR_UNSUPPORTED;
     switch (L) {
-    case 0: return launch_small<T, 1, EPI>(ctx, io, batch);
+    case 0:
+        if constexpr (IO::kLen1) return launch_small<T, 1, EPI>(ctx, io, batch);
+        else return KOFFT_ERR_UNSUPPORTED;  // (never: the policy's callers handle n = 1 themselves)
     case 1: return launch_small<T, 2, EPI>(ctx, io, batch);
     case 2: return launch_small<T, 4, EPI>(ctx, io, batch);
     case 3: return launch_small<T, 8, EPI>(ctx, io, batch);

@@ -57,7 +57,19 @@ def case_grid_pct(oracle):
 
 
 def case_three_min_high(oracle):  # 2^22 as TWO factors
+    import kofft_amd
+
     _complex(oracle, "c32", 1 << 22, 2, 31)
+    # ... of 2^11 points each, also under Bluestein's pointwise steps and the row window (fft_wg_kernel<T, 11, .., BigColsIO<T, .., PRE_CHIRP /
+    # PRE_WINDOW>>; c64: BigRowsIO<double, .., POST_BLUE_*> at 2^11 too)
+    _complex(oracle, "c32", (1 << 21) - 1, 2, 34)
+    _complex(oracle, "c64", (1 << 21) - 1, 1, 35)
+    for dt, n in ((np.float32, 1 << 23), (np.float64, 1 << 23)):
+        f = kofft_amd.HipFftImpl(dt)
+        rng = seeded(36)
+        x = rng.uniform(-1, 1, (1, n)).astype(dt)
+        win = rng.uniform(0.1, 1, n).astype(dt)
+        assert bits_equal(f.rfft_batch(x, win), oracle.rfft(x, win)), f"windowed rfft {dt.__name__} n=2^23"
 
 
 def case_three_min_low(oracle):  # 2^21 as THREE factors
@@ -97,6 +109,26 @@ def case_big_persist_three(oracle):
     _complex(oracle, "c32", 1 << 24, 1, 54)
     _complex(oracle, "c64", 1 << 23, 2, 55)
     _complex(oracle, "c32", 1 << 26, 1, 56, inverse=False)
+    _complex(oracle, "c64", 1 << 22, 1, 57)
+    _complex(oracle, "c64", 1 << 26, 1, 58, inverse=False)
+    _complex(oracle, "c32", (1 << 21) - 1, 1, 59)  # Bluestein, m = 2^22 in three factors: the pointwise steps on one-tile-per-workgroup factors
+    _fft2d(oracle, "c32", 16384, 128)              # the column axis as 2^7 x 2^7, both passes one tile per workgroup
+
+
+def _fft2d(oracle, dtype, rows, cols):
+    import kofft_amd
+
+    cdt = np.complex64 if dtype == "c32" else np.complex128
+    f = kofft_amd.HipFftImpl(np.float32 if dtype == "c32" else np.float64)
+    x = rand_c(seeded(rows + cols), (rows, cols), cdt)
+    want = oracle.fft(np.ascontiguousarray(oracle.fft(x).T)).T
+    data = x.reshape(-1).copy()
+    kofft_amd.fft2d_inplace(data, rows, cols, f, np.zeros(rows, cdt))
+    assert bits_equal(data.reshape(rows, cols), np.ascontiguousarray(want)), f"fft2d {dtype} {rows} x {cols}"
+    f.fftnd(data, 1, rows, cols, inverse=True)
+    w = np.ascontiguousarray(want)
+    back = oracle.fft(np.ascontiguousarray(oracle.fft(w, inverse=True).T), inverse=True).T
+    assert bits_equal(data.reshape(rows, cols), np.ascontiguousarray(back)), f"inverse fft2d {dtype} {rows} x {cols}"
 
 
 def case_rfft_wide(oracle):  # rfft / irfft of 32768 and 16384 reals
@@ -145,6 +177,9 @@ def case_split(oracle):
     got = f.stft_into(sig, win, 2048, frames)
     for first, count in ((0, 2), (frames // 2, 2), (frames - 4, 4)):
         assert bits_equal(got[first:first + count], oracle.stft_range(sig, win, 2048, first, count)), (first, count)
+    mags, mx = f.stft_magnitudes(sig, 8192, 2048)  # ... and <.., StftMagIO>
+    want, want_max = oracle.stft_magnitudes(sig, 8192, 2048)
+    assert bits_equal(mags, want) and mx == want_max
 
 
 def case_regfile(oracle):

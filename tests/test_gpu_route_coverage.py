@@ -38,6 +38,15 @@ def _rows(batch):
     return sorted({0, batch // 2, batch - 1})
 
 
+def _ladder(log2_len):
+    """1, 2, 3, 5, 9, 17, ... up to the persistent kernels' batch: between one transform (tiles narrowed twice) and the persistent form the
+    factor path passes through every tile width -- narrowed once, full width one tile per workgroup -- at batch sizes that depend on the
+    length; a ladder of batches meets all of them."""
+    top = _persist_batch(log2_len)
+    steps = [1, 2] + [(1 << k) + 1 for k in range(1, 16) if (1 << k) + 1 < top] + [top]
+    return sorted(set(steps))
+
+
 # ---- complex, powers of two beyond one workgroup: single transforms and small batches at EVERY size ---------------------------------
 @pytest.mark.parametrize("dtype,log2n", [("c32", L) for L in range(15, 25)] + [("c64", L) for L in range(14, 24)])
 def test_large_pow2_one_and_three_transforms(fft32, fft64, oracle, dtype, log2n):
@@ -55,7 +64,24 @@ def test_large_pow2_one_and_three_transforms(fft32, fft64, oracle, dtype, log2n)
         assert bits_equal(y, oracle.fft_inplace_mt(want.copy(), inverse=True)), f"{dtype} 2^{log2n} x {batch} inverse"
 
 
-@pytest.mark.parametrize("dtype,log2n", [("c32", 26), ("c64", 25)])
+@pytest.mark.parametrize("dtype,log2n", [("c32", L) for L in range(15, 23)] + [("c64", L) for L in range(14, 22)])
+def test_large_pow2_batch_ladder(fft32, fft64, oracle, dtype, log2n):
+    """The plain factor path between three transforms and the persistent kernels: every tile width of fft_wg_kernel<.., BigColsIO<T, INV, 0> /
+    BigRowsIO<T, INV, 0>>; forward and inverse, first / middle / last transform of every batch."""
+    f = _impl(fft32, fft64, dtype)
+    n = 1 << log2n
+    for batch in _ladder(log2n)[3:]:
+        x = rand_c(seeded(9200 + 10 * log2n + batch), (batch, n), _cdt(dtype))
+        y = x.copy()
+        f.fft_batch(y)
+        rows = _rows(batch)
+        assert bits_equal(y[rows], oracle.fft(x[rows])), f"{dtype} 2^{log2n} x {batch} forward"
+        z = y.copy()
+        f.fft_batch(z, inverse=True)
+        assert bits_equal(z[rows], oracle.ifft(y[rows])), f"{dtype} 2^{log2n} x {batch} inverse"
+
+
+@pytest.mark.parametrize("dtype,log2n", [("c32", 26), ("c64", 25), ("c64", 26)])
 def test_largest_transforms(fft32, fft64, oracle, dtype, log2n):
     """The middle factor at 2^8 and 2^9 points (2^25 = 9 + 8 + 8, 2^26 = 9 + 9 + 8: fft_tile_persist_kernel<T, 8 / 9, BigMidIO<T>>), the
     largest length the library takes in c32: one transform, forward, every value (the oracle needs ~15 s for one of these)."""
@@ -67,14 +93,14 @@ def test_largest_transforms(fft32, fft64, oracle, dtype, log2n):
 
 
 # ---- Bluestein beyond one workgroup's m: the pointwise steps ride on the factor kernels (BigColsIO PRE_CHIRP, BigRowsIO POST_BLUE_*) ----
-@pytest.mark.parametrize("dtype,log2m", [("c32", L) for L in range(15, 22)] + [("c64", L) for L in range(14, 21)])
+@pytest.mark.parametrize("dtype,log2m", [("c32", L) for L in range(15, 22)] + [("c64", L) for L in range(14, 22)])
 def test_bluestein_large_m_every_tile_width(fft32, fft64, oracle, dtype, log2m):
-    """n = m / 2 - 1 (so that m = (2n - 1).next_power_of_two()): one transform, three, and a batch for the persistent factor kernels
+    """n = m / 2 - 1 (so that m = (2n - 1).next_power_of_two()): a ladder of batches from one transform to the persistent factor kernels
     (fft_tile_persist_kernel<.., BigColsIO<T, INV, PRE_CHIRP>>, fft_rows_persist_kernel<.., BigRowsIO<T, .., POST_BLUE_MID / _OUT>>)."""
     f = _impl(fft32, fft64, dtype)
     m = 1 << log2m
     n = m // 2 - 1
-    for batch in (1, 3, _persist_batch(log2m)):
+    for batch in _ladder(log2m):
         x = rand_c(seeded(9400 + 10 * log2m + batch), (batch, n), _cdt(dtype))
         y = x.copy()
         f.fft_batch(y)
@@ -101,14 +127,14 @@ def test_bluestein_two_fused_launches(fft32, fft64, oracle, dtype, n):
 
 
 # ---- real transforms beyond the fused kernels: the row window on the factor path's first load (BigColsIO PRE_WINDOW) ------------------
-@pytest.mark.parametrize("dtype,log2n", [("f32", L) for L in range(16, 23)] + [("f64", L) for L in range(15, 22)])
+@pytest.mark.parametrize("dtype,log2n", [("f32", L) for L in range(16, 23)] + [("f64", L) for L in range(15, 23)])
 def test_windowed_rfft_large_n_every_tile_width(fft32, fft64, oracle, dtype, log2n):
-    """rfft with a row window, n / 2 beyond one workgroup: one row, three, and a batch for the persistent factor kernels
+    """rfft with a row window, n / 2 beyond one workgroup: a ladder of batches from one row to the persistent factor kernels
     (fft_tile_persist_kernel<.., BigColsIO<T, false, PRE_WINDOW>>); irfft of the result on the same batches."""
     f = _impl(fft32, fft64, dtype)
     n = 1 << log2n
     win = seeded(9600 + log2n).uniform(0.1, 1, n).astype(_rdt(dtype))
-    for batch in (1, 3, _persist_batch(log2n - 1)):
+    for batch in _ladder(log2n - 1):
         x = seeded(9601 + 10 * log2n + batch).uniform(-1, 1, (batch, n)).astype(_rdt(dtype))
         got = f.rfft_batch(x, win)
         rows = _rows(batch)
@@ -125,7 +151,10 @@ def _oracle_axis(oracle, x, axis, inverse=False):
 
 @pytest.mark.parametrize("dtype,rows,cols", [("c32", 16384, 8), ("c32", 32768, 16), ("c32", 16384, 1024), ("c32", 32768, 512),
                                              ("c64", 16384, 8), ("c64", 32768, 16), ("c64", 16384, 512), ("c64", 32768, 256),
-                                             ("c64", 4096, 64), ("c64", 8192, 2048)])
+                                             ("c64", 4096, 64), ("c64", 8192, 2048),
+                                             # the strided kernel itself (fft_small_kernel / fft_wg_kernel<.., StridedIO<T, INV>>): column axes up to 2048 points, longer ones on small images
+                                             ("c64", 2, 8), ("c64", 8, 32), ("c64", 16, 4), ("c64", 32, 16), ("c64", 64, 16), ("c64", 128, 24), ("c64", 256, 8),
+                                             ("c64", 512, 40), ("c64", 1024, 8), ("c64", 2048, 8), ("c64", 8192, 4), ("c32", 128, 24), ("c32", 8192, 4), ("c32", 16384, 2), ("c32", 16, 4)])
 def test_fft2d_long_column_axes(fft32, fft64, oracle, dtype, rows, cols):
     """fft2d_inplace with 4096 .. 32768 rows: the column axis as 2^7 x 2^(LT - 7) in two passes -- fft_wg_kernel / fft_tile_persist_kernel
     <T, 5 .. 8, AxisLastIO<T, INV>> behind a BigColsIO<T, INV, 0> first pass (narrow images: one tile per workgroup; wide ones: the
@@ -162,7 +191,7 @@ def test_strided_every_length(fft32, fft64, oracle, dtype):
 
 
 # ---- stft_magnitudes at every window length, few frames and many --------------------------------------------------------------------
-@pytest.mark.parametrize("win_len", [2, 4, 8, 16, 32, 64, 128, 512, 2048, 4096, 8192])
+@pytest.mark.parametrize("win_len", [1, 2, 4, 8, 16, 32, 64, 128, 512, 2048, 4096, 8192])
 def test_stft_magnitudes_every_window_length(fft32, oracle, win_len):
     """fft_small_kernel / fft_wg_kernel / fft_persist_kernel<.., StftMagIO>: a short signal (the generic kernels) and one long enough for the
     streaming kernels (CUs x 512 >> log2 frames and more)."""
