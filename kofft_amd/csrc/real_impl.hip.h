@@ -115,7 +115,7 @@ int rfft_composed_dev(kofft_hip_ctx *ctx, const T *d_in, T *d_out, const T *d_wi
     // (Round 5: the last factor on mirrored tile PAIRS -- rows K and 2^LA - K in one workgroup -- with the post-pass in its epilogue, two
     // passes instead of three, was built, bit-exact on every row, and measured SLOWER: 453-678 us for the fused kernel against 185-227 us
     // (last factor on row pairs) + 217-227 us (post-pass kernel) at n = 2^17 .. 2^20 -- the mirror of a line-aligned tile starts 8 bytes into
-    // a line, and its partial-line stores cost more than the pass they save; commit 2191bc6 has it, DESIGN 9 item 4 the counters.)
+    // a line, and its partial-line stores cost more than the pass they save; commit 2191bc6 has it, DESIGN 10 item 4 the counters.)
     const cpx<T> *rtab = nullptr;
     int rc = get_table<T>(ctx, Kind<T>::rt, m, &rtab);
     if (rc) return rc;

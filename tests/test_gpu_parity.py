@@ -1389,7 +1389,7 @@ def test_single_large_transforms_narrow_tiles(fft32, fft64, oracle, log2n, batch
 
 def test_host_pointer_stft_large(fft32, oracle):
     """stft() from host memory with >= 128 MiB of spectra (one upload, one launch, one download: chunking the download
-    behind the kernels measured slower, DESIGN section 9) -- frames past the end of the signal included."""
+    behind the kernels measured slower, DESIGN section 13) -- frames past the end of the signal included."""
     import kofft_amd as K
 
     rng = seeded(9600)
