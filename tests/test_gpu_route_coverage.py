@@ -67,18 +67,17 @@ def test_large_pow2_one_and_three_transforms(fft32, fft64, oracle, dtype, log2n)
 @pytest.mark.parametrize("dtype,log2n", [("c32", L) for L in range(15, 23)] + [("c64", L) for L in range(14, 22)])
 def test_large_pow2_batch_ladder(fft32, fft64, oracle, dtype, log2n):
     """The plain factor path between three transforms and the persistent kernels: every tile width of fft_wg_kernel<.., BigColsIO<T, INV, 0> /
-    BigRowsIO<T, INV, 0>>; forward and inverse, first / middle / last transform of every batch."""
+    BigRowsIO<T, INV, 0>>; forward and inverse, every transform of every batch."""
     f = _impl(fft32, fft64, dtype)
     n = 1 << log2n
     for batch in _ladder(log2n)[3:]:
         x = rand_c(seeded(9200 + 10 * log2n + batch), (batch, n), _cdt(dtype))
         y = x.copy()
         f.fft_batch(y)
-        rows = _rows(batch)
-        assert bits_equal(y[rows], oracle.fft(x[rows])), f"{dtype} 2^{log2n} x {batch} forward"
-        z = y.copy()
-        f.fft_batch(z, inverse=True)
-        assert bits_equal(z[rows], oracle.ifft(y[rows])), f"{dtype} 2^{log2n} x {batch} inverse"
+        want = oracle.fft_inplace_mt(x.copy())  # EVERY transform: the store hazard of round 6 hit a few per thousand
+        assert bits_equal(y, want), f"{dtype} 2^{log2n} x {batch} forward"
+        f.fft_batch(y, inverse=True)
+        assert bits_equal(y, oracle.fft_inplace_mt(want, inverse=True)), f"{dtype} 2^{log2n} x {batch} inverse"
 
 
 @pytest.mark.parametrize("dtype,log2n", [("c32", 26), ("c64", 25), ("c64", 26)])
@@ -110,6 +109,13 @@ def test_bluestein_large_m_every_tile_width(fft32, fft64, oracle, dtype, log2m):
         z = y.copy()
         f.fft_batch(z, inverse=True)
         assert bits_equal(z[rows], oracle.ifft(y[rows])), f"bluestein {dtype} n={n} (m=2^{log2m}) x {batch} inverse"
+        # the rows the oracle did not see: a second run of the same calls must give the same bytes (a sporadic fault -- round 6's store
+        # hazard hit a few transforms per thousand, elsewhere on every run -- shows as a difference between two runs)
+        y2 = x.copy()
+        f.fft_batch(y2)
+        z2 = y2.copy()
+        f.fft_batch(z2, inverse=True)
+        assert bits_equal(y, y2) and bits_equal(z, z2), f"bluestein {dtype} n={n} x {batch}: two runs differ"
 
 
 @pytest.mark.parametrize("dtype,n", [("c64", 3000), ("c64", 4096 - 1), ("c32", 8191), ("c32", 6000)])
@@ -137,10 +143,11 @@ def test_windowed_rfft_large_n_every_tile_width(fft32, fft64, oracle, dtype, log
     for batch in _ladder(log2n - 1):
         x = seeded(9601 + 10 * log2n + batch).uniform(-1, 1, (batch, n)).astype(_rdt(dtype))
         got = f.rfft_batch(x, win)
-        rows = _rows(batch)
-        assert bits_equal(got[rows], oracle.rfft(x[rows], win)), f"windowed rfft {dtype} n=2^{log2n} x {batch}"
+        assert bits_equal(got, oracle.rfft_mt(x, win)), f"windowed rfft {dtype} n=2^{log2n} x {batch}"  # every row
         back = f.irfft_batch(got, n)
+        rows = _rows(batch)
         assert bits_equal(back[rows], oracle.irfft(got[rows], n)), f"irfft {dtype} n=2^{log2n} x {batch}"
+        assert bits_equal(back, f.irfft_batch(got, n)), f"irfft {dtype} n=2^{log2n} x {batch}: two runs differ"
 
 
 # ---- ndfft: strided axes of 16384 / 32768 points in two column-tile passes (AxisLastIO at 2^7 / 2^8-point tiles) ----------------------
