@@ -24,6 +24,59 @@ def pytest_configure(config):
     os.environ.setdefault("KOFFT_HIP_HOST_PIPELINE", "0")
 
 
+def _nan_safe_equal(a, b) -> bool:
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    return a.shape == b.shape and a.tobytes() == b.tobytes()
+
+
+@pytest.fixture(autouse=True, scope="session")
+def _every_batched_host_call_runs_twice():
+    """Round 6: the f64 store hazard corrupted a few transforms per THOUSAND, differently on every run -- a test that compares three rows of
+    a batch with the oracle does not see that, a second run of the same call does.  For the whole session the batched host-pointer methods of
+    HipFftImpl run TWICE on the same input and the two results must be the same bytes (the oracle comparison of the test itself then sees the
+    first).  KOFFT_TEST_TWICE=0 switches it off."""
+    if os.environ.get("KOFFT_TEST_TWICE", "1") == "0":
+        yield
+        return
+    import kofft_amd
+
+    cls = kofft_amd.HipFftImpl
+    saved = {name: getattr(cls, name) for name in ("fft_batch", "rfft_batch", "irfft_batch", "stft_into", "stft_magnitudes", "fftnd")}
+
+    def in_place(name):
+        real = saved[name]
+
+        def wrapper(self, data, *args, **kw):
+            snap = np.array(data, copy=True) if isinstance(data, np.ndarray) else None
+            real(self, data, *args, **kw)
+            if snap is not None:
+                real(self, snap, *args, **kw)
+                assert _nan_safe_equal(data, snap), f"{name}: two runs of the same call differ (a sporadic device fault)"
+        return wrapper
+
+    def returning(name):
+        real = saved[name]
+
+        def wrapper(self, *args, **kw):
+            first = real(self, *args, **kw)
+            second = real(self, *args, **kw)
+            a, b = (first, second) if isinstance(first, tuple) else ((first,), (second,))
+            for x, y in zip(a, b):
+                same = _nan_safe_equal(x, y) if isinstance(x, np.ndarray) else (x == y or (x != x and y != y))
+                assert same, f"{name}: two runs of the same call differ (a sporadic device fault)"
+            return first
+        return wrapper
+
+    for name in ("fft_batch", "fftnd"):
+        setattr(cls, name, in_place(name))
+    for name in ("rfft_batch", "irfft_batch", "stft_into", "stft_magnitudes"):
+        setattr(cls, name, returning(name))
+    yield
+    for name, fn in saved.items():
+        setattr(cls, name, fn)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The CPU oracle (oracle/pyoracle.py): test infrastructure only."""

@@ -1,4 +1,5 @@
 import sys, os
+os.environ.setdefault("KOFFT_HIP_HOST_PIPELINE", "0")  # one launch per call on the batch the case names (tests/conftest.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 os.chdir(ROOT)
 import numpy as np
