@@ -24,6 +24,9 @@ def pytest_configure(config):
     os.environ.setdefault("KOFFT_HIP_HOST_PIPELINE", "0")
 
 
+_TWICE_MAX_BYTES = 256 << 20  # (larger arrays: the second trip over PCIe costs more than it is likely to find)
+
+
 def _nan_safe_equal(a, b) -> bool:
     a = np.ascontiguousarray(a)
     b = np.ascontiguousarray(b)
@@ -48,7 +51,7 @@ def _every_batched_host_call_runs_twice():
         real = saved[name]
 
         def wrapper(self, data, *args, **kw):
-            snap = np.array(data, copy=True) if isinstance(data, np.ndarray) else None
+            snap = np.array(data, copy=True) if isinstance(data, np.ndarray) and data.nbytes <= _TWICE_MAX_BYTES else None
             real(self, data, *args, **kw)
             if snap is not None:
                 real(self, snap, *args, **kw)
@@ -60,6 +63,8 @@ def _every_batched_host_call_runs_twice():
 
         def wrapper(self, *args, **kw):
             first = real(self, *args, **kw)
+            if sum(x.nbytes for x in (first if isinstance(first, tuple) else (first,)) if isinstance(x, np.ndarray)) > _TWICE_MAX_BYTES:
+                return first
             second = real(self, *args, **kw)
             a, b = (first, second) if isinstance(first, tuple) else ((first,), (second,))
             for x, y in zip(a, b):
