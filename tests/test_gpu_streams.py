@@ -207,6 +207,42 @@ def test_host_pipeline_on_every_entry_point(oracle, monkeypatch):
     assert bits_equal(back, oracle.irfft(rp, 4096)) and bits_equal(rd, oracle.rfft(xd))
 
 
+@pytest.mark.parametrize("kind,dtype,n,batch", [
+    ("c", "c32", 1000, 20001),        # Bluestein through the chunks (160 MB each way)
+    ("c", "c32", 1 << 20, 17),        # rows of exactly 8 MiB (the largest the pipeline takes), one more than its smallest batch
+    ("c", "c64", 4096, 2051),
+    ("c", "c64", 1 << 16, 131),       # the factor path under every chunk
+    ("r", "f32", 1000, 40001),        # an even length that is not a power of two: the composed real route
+    ("r", "f64", 8192, 2100),
+    ("r", "f32", 1 << 17, 300),
+])
+def test_host_pipeline_shapes(oracle, monkeypatch, kind, dtype, n, batch):
+    """More shapes through the chunked host path (pipeline ON): chunk sizes that do not divide the batch, rows at the pipeline's size
+    limit, lengths that take the Bluestein arm / the factor path / the composed real route inside every chunk; every row, both directions."""
+    import kofft_amd
+
+    monkeypatch.setenv("KOFFT_HIP_HOST_PIPELINE", "1")
+    real = np.float64 if dtype in ("c64", "f64") else np.float32
+    f = kofft_amd.HipFftImpl(real)
+    rng = seeded(4300 + n + batch)
+    if kind == "c":
+        x = rand_c(rng, (batch, n), np.complex128 if dtype == "c64" else np.complex64)
+        y = x.copy()
+        f.fft_batch(y)
+        want = oracle.fft_inplace_mt(x.copy())
+        assert bits_equal(y, want), f"pipelined fft {dtype} n={n} x {batch}"
+        f.fft_batch(y, inverse=True)
+        assert bits_equal(y, oracle.fft_inplace_mt(want, inverse=True)), f"pipelined ifft {dtype} n={n} x {batch}"
+    else:
+        x = rng.uniform(-1, 1, (batch, n)).astype(real)
+        got = f.rfft_batch(x)
+        assert bits_equal(got, oracle.rfft_mt(x)), f"pipelined rfft {dtype} n={n} x {batch}"
+        back = f.irfft_batch(got, n)
+        rows = sorted({0, 1, batch // 8, batch // 8 + 1, batch // 2, batch - 2, batch - 1})  # around the chunk seams and the ends
+        assert bits_equal(back[rows], oracle.irfft(got[rows], n)), f"pipelined irfft {dtype} n={n} x {batch}"
+    f.close()
+
+
 def test_bench_two_rank_rehearsal_carries_the_single_process_gather_ab():
     """bench.py's N > 1 line on a one-GPU box: `--gpus 2 --rehearse-one-card` runs the whole two-rank protocol with
     both ranks on cuda:0 (gloo process group: NOT a measurement) and, after the per-rank part, rank 0 alone drives config #4 through
