@@ -83,6 +83,29 @@ struct BigColsIO {
             return v;
         }
     }
+    // pre() in two steps for the persistent tile kernel (round 6): the table entry through a descriptor -- requested BEFORE the next tile's
+    // prefetch is issued, see fft_tile_persist_kernel -- and the product
+    __device__ __forceinline__ rsrc_t pre_desc() const
+    {
+        return make_rsrc(pre_tab, (unsigned)((PRE == PRE_CHIRP ? (size_t)n_in : n) * sizeof(cpx<T>)));
+    }
+    __device__ __forceinline__ cpx<T> pre_fetch(const rsrc_t d, const unsigned elem) const
+    {
+        unsigned ec = elem;
+        if constexpr (PRE == PRE_CHIRP) ec = elem < n_in ? elem : n_in - 1;  // (as pre(): clamp the address, select the value)
+        return buf_load_cpx<T, AUX_DEFAULT>(d, (int)(ec * (unsigned)sizeof(cpx<T>)), 0);
+    }
+    __device__ __forceinline__ cpx<T> pre_apply(const cpx<T> v, const cpx<T> w, const unsigned elem) const
+    {
+        if constexpr (PRE == PRE_CHIRP) {
+            const cpx<T> a = cmul(v, w);
+            return elem < n_in ? a : mk<T>(T(0), T(0));
+        } else if constexpr (PRE == PRE_WINDOW) {
+            return mk<T>(v.re * w.re, v.im * w.im);
+        } else {
+            return v;
+        }
+    }
     __device__ __forceinline__ size_t xf_transform(size_t xf) const { return xf >> LB; }
     __device__ __forceinline__ unsigned in_off(size_t xf) const { return (unsigned)(xf & ((size_t(1) << LB) - 1)); }
     __device__ __forceinline__ int in_sl() const { return LB; }
@@ -564,6 +587,47 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 1024 ? 4 : 2)) void fft_tile_persi
     // put VALU writes to the store-data registers right behind 16-byte buffer stores that use an SGPR offset -- a
     // sequence the compiler does not pad, and one that stored the NEXT tile's values from a few lanes about once in
     // ten launches on gfx950.)
+    // A folded pointwise factor on the loads (PRE_CHIRP, PRE_WINDOW) needs a table entry per value.  Requested where it is used -- at the top
+    // of run_tile, BEHIND the next tile's prefetch -- waiting for it waited for the whole prefetch too (vmcnt counts in order): the windowed
+    // first factor of rfft32 2^18 ran 259 us per 512 MiB chunk against the plain one's 186, no load overlapping any arithmetic (round 6).
+    // Now the entries of tile t are requested BEFORE the prefetch of tile t + 1 is issued:
+    //   mode 1 (registers allow R more values: f32 at 8 points per thread / 256-thread blocks): they stay in flight beside the prefetch,
+    //          the product opens run_tile;
+    //   mode 2 (1024 threads at 128 registers with 16 points, every f64 kernel): the product is done first -- the prefetch leaves one L2
+    //          round trip later, and still runs under the tile's passes.
+    constexpr int PRE_MODE = io_pre<IO>::value == 0 ? 0 : ((sizeof(T) == 4 && (R <= 8 || BLOCK <= 256)) ? 1 : 2);
+    //   ... and in mode 1 they are usually RESIDENT: the walk advances by the grid size, the column tile of tile t is t mod (tiles per
+    //   transform), so with a grid that is a multiple of the tiles per transform (a power of two against CUs x workgroups per CU: the rule
+    //   unless the batch is tiny) a workgroup keeps its column tile for the whole launch, and the entries depend on the column and the row only.
+    cpx<T> pw[PRE_MODE != 0 ? R : 1];
+    bool pre_resident = false;
+    if constexpr (PRE_MODE == 1) {
+        const size_t tiles_per_xf = (size_t(1) << io.in_sl()) / XPB;
+        pre_resident = tpg == 1 && tiles_per_xf != 0 && (gridDim.x % tiles_per_xf) == 0;  // (workgroup-uniform)
+    }
+    auto pre_request = [&](const size_t t) {
+        if constexpr (PRE_MODE != 0) {
+            int tau = tau_launch, slot = slot_launch;
+            if constexpr (BLOCK >= 1024) asm volatile("" : "+v"(tau), "+v"(slot));
+            const rsrc_t pd = io.pre_desc();
+            const unsigned e0 = io.in_off(t * XPB + slot) + ((unsigned)tau << in_sl);
+#pragma unroll
+            for (int u = 0; u < R; ++u) pw[u] = io.pre_fetch(pd, e0 + ((unsigned)G0::in_index(0, u) << in_sl));
+        }
+    };
+    auto pre_product = [&](cpx<T> *cur, const size_t t) {
+        if (IO::kConjIn) {
+#pragma unroll
+            for (int u = 0; u < R; ++u) cur[u].im = -cur[u].im;  // ifft: conj on the way in (fft.rs:1163-1165)
+        }
+        if constexpr (PRE_MODE != 0) {
+            int tau = tau_launch, slot = slot_launch;
+            if constexpr (BLOCK >= 1024) asm volatile("" : "+v"(tau), "+v"(slot));
+            const unsigned e0 = io.in_off(t * XPB + slot) + ((unsigned)tau << in_sl);
+#pragma unroll
+            for (int u = 0; u < R; ++u) cur[u] = io.pre_apply(cur[u], pw[u], e0 + ((unsigned)G0::in_index(0, u) << in_sl));
+        }
+    };
     auto run_tile = [&](cpx<T> *cur, const size_t t, const bool do_store) {
         // 1024-thread instances (128 registers per thread): opaque copies of the thread's coordinates, taken per tile.  Every LDS base
         // of the exchanges and the thread part of the store offset depend on the thread only, so the compiler computes them once and
@@ -572,15 +636,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 1024 ? 4 : 2)) void fft_tile_persi
         int tau = tau_launch, slot = slot_launch;
         if constexpr (BLOCK >= 1024) asm volatile("" : "+v"(tau), "+v"(slot));
         const size_t xf = t * XPB + slot;
-        if (IO::kConjIn) {
-#pragma unroll
-            for (int u = 0; u < R; ++u) cur[u].im = -cur[u].im;  // ifft: conj on the way in (fft.rs:1163-1165)
-        }
-        if constexpr (io_pre<IO>::value != 0) {
-            const unsigned e0 = io.in_off(xf) + ((unsigned)tau << in_sl);
-#pragma unroll
-            for (int u = 0; u < R; ++u) cur[u] = io.pre(cur[u], e0 + ((unsigned)G0::in_index(0, u) << in_sl));
-        }
+        if constexpr (PRE_MODE != 2) pre_product(cur, t);  // (mode 2: done before the prefetch was issued)
         compute(std::integral_constant<int, 0>{}, cur, xf);
         if constexpr (NP > 1) { TileExchange<T, L, RL, XPB, SPLIT>::template run<0>(cur, smem_raw, tau, slot); compute(std::integral_constant<int, 1>{}, cur, xf); }
         if constexpr (NP > 2) { TileExchange<T, L, RL, XPB, SPLIT>::template run<1>(cur, smem_raw, tau, slot); compute(std::integral_constant<int, 2>{}, cur, xf); }
@@ -617,6 +673,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 1024 ? 4 : 2)) void fft_tile_persi
     };
 
     cpx<T> ra[R], rb[R];
+    if (pre_resident) pre_request(tile);
     issue_loads(ra, tile, true);
 #ifdef KOFFT_TILE_NO_MEM /* measurement only: the arithmetic and the exchanges without global traffic inside the loop */
 #define KOFFT_TILE_PREFETCH(CUR, NXT)
@@ -629,6 +686,11 @@ __global__ __launch_bounds__(BLOCK, (BLOCK >= 1024 ? 4 : 2)) void fft_tile_persi
     {                                                                                                    \
         const size_t ntile = next_tile(tile);                                                            \
         const bool more = ntile < ntiles; /* workgroup-uniform */                                        \
+        if constexpr (PRE_MODE != 0) {                                                                   \
+            if (!pre_resident) pre_request(tile);                                                        \
+            if constexpr (PRE_MODE == 2) pre_product(CUR, tile);                                         \
+            __builtin_amdgcn_sched_barrier(0); /* the table entries are requested ahead of the prefetch */ \
+        }                                                                                                \
         KOFFT_TILE_PREFETCH(CUR, NXT)                                                                    \
         __builtin_amdgcn_sched_barrier(0); /* keep the prefetch ahead of the first use of CUR */         \
         KOFFT_TILE_RUN(CUR);                                                                             \
