@@ -209,12 +209,26 @@ struct persist_acc { using type = NoAcc; };
 template <class IO>
 struct persist_acc<IO, true> { using type = typename IO::Acc; };
 
-template <typename T, int L, int RL, int EPI, class CFG, class IO>
+// kTwGlobal configurations (c64 n = 4096 / 8192: every pass after the first reads its table entries from global memory) take the NEXT
+// transform's loads in NP parts: one at the top of the step, the others each BEHIND a pass's table loads (round 6).  vmcnt counts in order: with the whole prefetch issued at
+// the top of the step, waiting for pass 1's entries waited for the prefetch -- the wavefront sat out the prefetch's landing after pass 0 and ran
+// passes 1 .. with nothing in flight.  `part(i)` is the kernel's callback that issues part i; the entries of a pass are loaded into registers
+// first (persist_load_tw), so that the order "entries, then the part, then the butterflies" is the program's, not the scheduler's.
+// (a part at the top of the step too -- pass 0 reads its entries through scalar loads -- measured better at n = 4096, two workgroups per CU, and worse
+// at n = 8192, one: same box, three rounds, against round 5's kernels 4096 +5.4 % with, +3.8 % without; 8192 +1.5 % with, +3.6 % without)
+#ifndef KOFFT_TWG_TOP_PART
+#define KOFFT_TWG_TOP_PART -1 /* -1: by size; 0 / 1: measurement builds */
+#endif
+__host__ __device__ constexpr bool persist_twg_top_part(int L) { return KOFFT_TWG_TOP_PART < 0 ? L <= 12 : KOFFT_TWG_TOP_PART != 0; }
+struct NoPrefetchParts {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+template <typename T, int L, int RL, int EPI, class CFG, class IO, class Parts = NoPrefetchParts>
 __device__ __forceinline__ void persist_transform(const typename persist_raw<IO, ((1 << L) >> RL)>::type *raw,
                                                   const PersistState<T, L, RL, EPI, IO, CFG> &st,
                                                   const IO &io, const cpx<T> *__restrict__ tw, cpx<T> *buf0, cpx<T> *buf1,
                                                   const size_t xf0, const int cnt, const int sub, const int tau,
-                                                  typename persist_acc<IO>::type &acc)
+                                                  typename persist_acc<IO>::type &acc, const Parts &part = Parts{})
 {
     // The wavefront's group: cnt (0 .. G) valid transforms starting at xf0; this lane belongs to number `sub`.
     constexpr int NBUF = CFG::NBUF;
@@ -277,7 +291,17 @@ __device__ __forceinline__ void persist_transform(const typename persist_raw<IO,
     // held in registers, 168 VGPRs spilled; an opaque copy of tau per transform keeps them a few VALU operations per pass)
     int tau_tw = tau;
     if constexpr (St::TWG) asm volatile("" : "+v"(tau_tw));
-    if constexpr (St::TWG) wg_compute<T, L, RL, 1>(cur, io, tw, xf, tau_tw);
+    auto pass_tw_global = [&](auto pass) {  // kTwGlobal: the pass's entries, then a part of the next transform's loads, then the butterflies
+        constexpr int P = decltype(pass)::value;
+        using Gp = PassGeom<L, RL, P>;
+        cpx<T> twr[Gp::G * ((1 << Gp::Q) - 1)];
+        persist_load_tw<T, L, RL, P>(twr, tau_tw, tw);
+        __builtin_amdgcn_sched_barrier(0);
+        part(P - (persist_twg_top_part(L) ? 0 : 1));
+        __builtin_amdgcn_sched_barrier(0);
+        persist_compute<T, L, RL, P>(cur, twr);
+    };
+    if constexpr (St::TWG) pass_tw_global(std::integral_constant<int, 1>{});
     else if constexpr (NP == 2 && CFG::kTwLastInLds) wg_compute<T, L, RL, 1>(cur, io, st.tw_lds, xf, tau);
     else persist_compute<T, L, RL, 1>(cur, st.tw1);
     if constexpr (NP >= 3) {
@@ -285,7 +309,7 @@ __device__ __forceinline__ void persist_transform(const typename persist_raw<IO,
         persist_lds_scatter<T, L, RL, 1>(cur, buf1, st.sc);
         exchange_sync<WAVE>();
         persist_lds_gather<T, L, RL, 2>(cur, buf1, st.g2);
-        if constexpr (St::TWG) wg_compute<T, L, RL, 2>(cur, io, tw, xf, tau_tw);
+        if constexpr (St::TWG) pass_tw_global(std::integral_constant<int, 2>{});
         else if constexpr (NP == 3 && CFG::kTwLastInLds) wg_compute<T, L, RL, 2>(cur, io, st.tw_lds, xf, tau);
         else persist_compute<T, L, RL, 2>(cur, st.tw2);
     }
@@ -294,7 +318,7 @@ __device__ __forceinline__ void persist_transform(const typename persist_raw<IO,
         persist_lds_scatter<T, L, RL, 2>(cur, buf0, st.sc);
         exchange_sync<WAVE>();
         persist_lds_gather<T, L, RL, 3>(cur, buf0, st.g3);
-        if constexpr (St::TWG) wg_compute<T, L, RL, 3>(cur, io, tw, xf, tau_tw);
+        if constexpr (St::TWG) pass_tw_global(std::integral_constant<int, 3>{});
         else if constexpr (CFG::kTwLastInLds) wg_compute<T, L, RL, 3>(cur, io, st.tw_lds, xf, tau);
         else persist_compute<T, L, RL, 3>(cur, st.tw3);
     }
@@ -527,7 +551,35 @@ __global__ __launch_bounds__(CFG::BLOCK, CFG::MINW) void fft_persist_kernel(cons
         if constexpr (io_has_acc<IO>::value) io.acc_finish(acc);
     };
 
-    if constexpr (DEPTH == 1) {
+    if constexpr (DEPTH == 1 && St::TWG && !(RawSel::pair || RawSel::pair_lds)) {
+        // kTwGlobal: the next transform's loads in NP - 1 parts behind the passes' table loads (persist_transform)
+        constexpr bool TOP = persist_twg_top_part(L);
+        constexpr int PARTS = TOP ? NP : NP - 1;  // (part 0 at the top of the step,) part p behind pass p's entries
+#define KOFFT_PERSIST_STEP_PARTS(CUR, NXT, LEAVE)                                                                    \
+    {                                                                                                                \
+        const size_t nbase = base + step;                                                                            \
+        const bool more = nbase < batch; /* workgroup-uniform */                                                     \
+        const rsrc_t nd = io.in_desc_n(nbase + wslot, group_cnt(nbase));                                             \
+        auto part = [&](const int i) {                                                                               \
+            _Pragma("unroll") for (int u = 0; u < R; ++u)                                                            \
+                if (u * PARTS / R == i) NXT[u] = io.fetch_d(nd, in_lane_bytes, FirstG::in_index(0, u), in_row_off);  \
+        };                                                                                                           \
+        if constexpr (TOP) {                                                                                         \
+            part(0);                                                                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                                       \
+        }                                                                                                            \
+        persist_transform<T, L, RL, EPI, CFG>(CUR, st, io, tw, buf0, buf1, base + wslot, group_cnt(base), sub, tau, acc, part); \
+        if (!more) LEAVE;                                                                                            \
+        base = nbase;                                                                                                \
+    }
+        KOFFT_PERSIST_STEP_PARTS(ra, rb, { finish(); return; })
+        for (;;) {
+            KOFFT_PERSIST_STEP_PARTS(rb, ra, break)
+            KOFFT_PERSIST_STEP_PARTS(ra, rb, break)
+        }
+        finish();
+#undef KOFFT_PERSIST_STEP_PARTS
+    } else if constexpr (DEPTH == 1) {
         // One step: issue the NEXT transform's loads into NXT, then run the transform held in CUR.
 #define KOFFT_PERSIST_STEP(CUR, NXT, LEAVE)                                                                          \
     {                                                                                                                \
