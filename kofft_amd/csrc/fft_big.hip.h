@@ -1208,6 +1208,15 @@ struct BlueStftSrc {
     }
 };
 
+#ifndef KOFFT_BLUE_CHIRP_REG
+#define KOFFT_BLUE_CHIRP_REG 1 /* 0: measurement builds -- the input product's chirp entries read per transform, as in rounds 4-5 */
+#endif
+template <typename T>
+__host__ __device__ constexpr bool bluestein_chirp_resident(int L, int wg_per_cu)
+{
+    // f32, two workgroups of 256 threads per CU (256 registers each: m = 2048 / 4096 use 208 / 194 + 16)
+    return KOFFT_BLUE_CHIRP_REG && sizeof(T) == 4 && wg_per_cu <= 2 && (L == 11 || L == 12);
+}
 template <typename T, int L, int RL, int BLOCK, int WG_PER_CU, bool INVERSE, class SRC = BlueRowsSrc<T, INVERSE>>
 __global__ __launch_bounds__(BLOCK, WG_PER_CU * BLOCK / 256 /* wavefronts per SIMD */) void bluestein_persist_kernel(const SRC src, cpx<T> *__restrict__ out,
                                                                                         const cpx<T> *__restrict__ chirp,
@@ -1245,6 +1254,18 @@ __global__ __launch_bounds__(BLOCK, WG_PER_CU * BLOCK / 256 /* wavefronts per SI
     const int g1 = lds_pad(WgGeom<L, RL, 1>::in_index(tau, 0));
     const int g2 = NP >= 3 ? lds_pad(WgGeom<L, RL, (NP >= 3 ? 2 : 0)>::in_index(tau, 0)) : 0;
     const int g3 = NP >= 4 ? lds_pad(WgGeom<L, RL, (NP >= 4 ? 3 : 0)>::in_index(tau, 0)) : 0;
+    // The chirp entries of the INPUT product (R / 2 of them: the upper half of the padded input is zeros) depend on the thread only.  Read per
+    // transform at the top of its work they cost an exposed L2 round trip each time; where the register budget allows (KOFFT_BLUE_CHIRP_REG)
+    // they are read once (round 6).
+    constexpr bool CH_REG = bluestein_chirp_resident<T>(L, WG_PER_CU);
+    cpx<T> chin[CH_REG ? R / 2 : 1];
+    if constexpr (CH_REG) {
+#pragma unroll
+        for (int u = 0; u < R / 2; ++u) {
+            const int i = G0::in_index(tau, u);
+            chin[u] = chirp[i < n ? i : n - 1];
+        }
+    }
 
     // m = (2n - 1).next_power_of_two() >= 2n: elements m/2 .. m-1 of the padded input are zeros and outputs m/2 .. m-1 are never stored, for
     // every n of this m -- half of the loads, chirp entries and stores are decided at compile time (RH registers of input in flight)
@@ -1295,7 +1316,10 @@ __global__ __launch_bounds__(BLOCK, WG_PER_CU * BLOCK / 256 /* wavefronts per SI
         for (int u = 0; u < RH; ++u) {
             const int i = G0::in_index(tau_t, u);
             const cpx<T> x = src.finish(raw[u], xf, i);
-            const cpx<T> a = cmul(x, chirp[i < n ? i : n - 1]);
+            cpx<T> ce;
+            if constexpr (CH_REG) ce = chin[u];
+            else ce = chirp[i < n ? i : n - 1];
+            const cpx<T> a = cmul(x, ce);
             v[u] = i < n ? a : mk<T>(T(0), T(0));
         }
 #pragma unroll
