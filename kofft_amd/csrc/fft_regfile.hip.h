@@ -346,6 +346,20 @@ __global__ __launch_bounds__(1024, 4) void fft_regfile_persist_kernel(const IO i
             // opaque copy: the loads cannot be hoisted).
             const rsrc_t wd = make_rsrc(io.win, (unsigned)Gm::N * (unsigned)ES);
             const int wl = tau_a() * ES;
+#ifndef KOFFT_RF_WINDOW_CHUNKS
+            constexpr bool kWinIntoCur = rf_rfft_epi<IO>::value;  // (RowWindowIO -- the two-pass form behind KOFFT_HIP_RFFT_REGFILE_EPI=0 -- spills 9 registers this way: chunks)
+#else
+            constexpr bool kWinIntoCur = false;
+#endif
+            if constexpr (kWinIntoCur) {
+            // Round 6: the pairs are loaded INTO cur[] -- the registers this step is about to write anyway -- all R at once, and multiplied in
+            // place: one L2 round trip per transform.  (Rounds 4-5 took them through 8 (f32) / 4 (f64) temporaries at a time: R / 8 .. R / 4 round
+            // trips, each one exposed -- nothing else is in flight at the top of a transform.)
+#pragma unroll
+            for (int u = 0; u < R; ++u) cur[u] = buf_load_cpx<T, AUX_DEFAULT>(wd, wl, u * Gm::TPT * ES);
+#pragma unroll
+            for (int u = 0; u < R; ++u) cur[u] = mk<T>(raw[u].re * cur[u].re, raw[u].im * cur[u].im);
+            } else {
             constexpr int WC = sizeof(T) == 4 ? 8 : 4;  // (f64: eight pairs at a time spill a register)
 #pragma unroll
             for (int c = 0; c < R; c += WC) {
@@ -354,6 +368,7 @@ __global__ __launch_bounds__(1024, 4) void fft_regfile_persist_kernel(const IO i
                 for (int j = 0; j < WC; ++j) wv[j] = buf_load_cpx<T, AUX_DEFAULT>(wd, wl, (c + j) * Gm::TPT * ES);
 #pragma unroll
                 for (int j = 0; j < WC; ++j) cur[c + j] = mk<T>(raw[c + j].re * wv[j].re, raw[c + j].im * wv[j].im);
+            }
             }
         } else if constexpr (rf_irfft_pre<IO>::value) {
             // Round 6: element e = u TPT + p of the pre-pass needs bin e (this thread's prefetched raw[u]: it holds position p = tauA of every
